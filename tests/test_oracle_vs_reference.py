@@ -1,0 +1,86 @@
+"""CPU, build container only: oracle/restatement.py against the live reference model.
+
+Skipped wherever /root/reference is absent (the GPU box).  Imports the reference's own
+mmidas/nn_model.py (forward :297, loss :495) through oracle/ref_loader.py and checks the
+restatement in fp64 (where the two must agree to rounding) and fp32 on fresh random cases, i.e.
+cases that are not in the committed fixtures.
+"""
+import warnings
+
+import pytest
+import torch
+
+from oracle import ref_loader as RL
+from oracle import restatement as R
+
+pytestmark = pytest.mark.skipif(not RL.reference_available(), reason="/root/reference not present")
+
+CASES = [
+    # A, B, D, H, L, C, S, hard, s_drop
+    (2, 24, 40, 12, 4, 6, 2, False, 0.0),
+    (3, 33, 50, 10, 3, 8, 2, False, 0.3),
+    (4, 20, 36, 8, 4, 5, 1, True, 0.0),
+]
+
+
+def _mk(ref, cfg, dtype):
+    A, B, D, H, L, C, S, hard, sdrop = cfg
+    torch.manual_seed(99)
+    m = ref.mixVAE_model(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5,
+                         s_drop=sdrop, n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=hard,
+                         variational=True, device="cpu", eps=1e-8, momentum=0.01, ref_prior=False,
+                         loss_mode="MSE")
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5,
+                s_drop=sdrop, n_arm=A, hard=hard)
+    return m, h
+
+
+@pytest.mark.parametrize("cfg", CASES)
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+def test_restatement_equals_reference(cfg, dtype, tol):
+    warnings.simplefilter("ignore")
+    ref = RL.load_reference_nn_model()
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        m, h = _mk(ref, cfg, dtype)
+        A, B, D = cfg[:3]
+        sd = R.init_state_dict(h, 99, dtype=dtype)
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, sd[k]), k          # same constructor RNG order
+        x = R.synthetic_batch(B, D, seed=5, dtype=dtype)
+        noise = R.draw_noise(h, B, seed=11)
+        m.train()
+        out, lo, _ = RL.reference_step(m, x.expand(A, -1, -1), 1.0, noise)
+        lo[0].backward()
+        out2, lt, grads = R.grads_autograd(sd, [x] * A, h, noise)
+        _, _, gman, _ = R.grads_manual(R.init_state_dict(h, 99, dtype=dtype), [x] * A, h, noise)
+        rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert abs(float(lt[0]) - float(lo[0])) <= tol * abs(float(lo[0]))
+        for i in (0, 3, 4, 5, 6, 7, 8, 9):
+            for a in range(A):
+                assert rel(out2[i][a], out[i][a]) < max(tol, 1e-12), (i, a)
+        for k, p in m.named_parameters():
+            assert rel(grads[k], p.grad) < tol, k
+            assert rel(gman[k], p.grad) < tol, k
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                assert rel(sd[k], v) < max(tol, 1e-12), k
+    finally:
+        torch.set_default_dtype(old)
+
+
+def test_two_reference_snapshots_agree():
+    """build/lib snapshot has identical arithmetic to the current file."""
+    warnings.simplefilter("ignore")
+    ref, old = RL.load_reference_nn_model(), RL.load_reference_nn_model_old()
+    cfg = CASES[0]
+    A, B, D = cfg[:3]
+    res = []
+    for mod in (ref, old):
+        m, h = _mk(mod, cfg, torch.float32)
+        x = R.synthetic_batch(B, D, seed=5)
+        m.train()
+        out, lo, _ = RL.reference_step(m, x.expand(A, -1, -1), 1.0, R.draw_noise(h, B, seed=11))
+        res.append(float(lo[0]))
+    assert res[0] == res[1]
