@@ -1,0 +1,208 @@
+"""ctypes binding of libmmvae_hip.so (C ABI: include/mmvae.h).
+
+This is the only door between the Python host code and the HIP kernels.  There is no CPU or
+PyTorch fallback: if the shared library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmmvae_hip.so")
+
+N_PARAM_TENSORS = 28
+N_BN = 6
+MAX_ARMS = 8
+
+# tensor order of mmvae_param_layout_t (include/mmvae.h)
+PARAM_NAMES = [
+    "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias",
+    "fc5.weight", "fc5.bias", "fcc.weight", "fcc.bias", "fc_mu.weight", "fc_sigma.weight", "fc_mu.bias",
+    "fc_sigma.bias", "fc6.weight", "fc6.bias", "fc7.weight", "fc7.bias", "fc8.weight", "fc8.bias",
+    "fc9.weight", "fc9.bias", "fc10.weight", "fc10.bias", "fc11.weight", "fc11.bias",
+]
+BN_NAMES = ["batch_l1", "batch_l2", "batch_l3", "batch_l4", "batch_l5", "batch_s"]
+
+WS_IDS = {name: i for i, name in enumerate([
+    "x_low", "c_prob", "c", "c_smp", "s_mean", "s_logvar", "s_smp", "y_soft",
+    "r1", "r2", "r3", "r4", "r5", "d6", "d7", "d8", "d9", "d10", "zin", "dz11", "dz1", "gzin", "gzc", "g5",
+    "bn_mean1",
+])}
+
+LOSS_TOTAL, LOSS_JOINT, LOSS_CENT, LOSS_CDIST, LOSS_CL2, LOSS_REC0 = 0, 1, 2, 3, 4, 5
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("A", "B", "D", "H", "L", "C", "S")]
+
+
+class Hyper(C.Structure):
+    _fields_ = [("tau", C.c_float), ("temp", C.c_float), ("beta", C.c_float), ("lam", C.c_float),
+                ("eps", C.c_float), ("bn_momentum", C.c_float), ("x_drop", C.c_float), ("s_drop", C.c_float),
+                ("hard", C.c_int32), ("training", C.c_int32), ("eval_flag", C.c_int32)]
+
+
+class Noise(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("_pad", C.c_int32), ("x_mask", C.c_void_p), ("u_gumbel", C.c_void_p),
+                ("u_state", C.c_void_p), ("s_mask", C.c_void_p), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class ParamLayout(C.Structure):
+    _fields_ = [("per_arm", C.c_int64), ("offset", C.c_int64 * N_PARAM_TENSORS),
+                ("rows", C.c_int64 * N_PARAM_TENSORS), ("cols", C.c_int64 * N_PARAM_TENSORS),
+                ("bn_per_arm", C.c_int64), ("bn_mean_offset", C.c_int64 * N_BN),
+                ("bn_var_offset", C.c_int64 * N_BN), ("bn_dim", C.c_int64 * N_BN)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmmvae_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or python distributed-vae_amd/build.py). "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, f32, i32 = C.c_void_p, C.c_int64, C.c_float, C.c_int
+    L.mmvae_abi_version.restype = C.c_int
+    L.mmvae_last_error_string.restype = C.c_char_p
+    L.mmvae_check_dims.argtypes = [C.POINTER(Dims)]
+    L.mmvae_param_layout.argtypes = [C.POINTER(Dims), C.POINTER(ParamLayout)]
+    L.mmvae_workspace_bytes.argtypes = [C.POINTER(Dims)]
+    L.mmvae_workspace_bytes.restype = C.c_size_t
+    L.mmvae_ws_offset.argtypes = [C.POINTER(Dims), C.c_int]
+    L.mmvae_ws_offset.restype = i64
+    L.mmvae_set_split.argtypes = [C.c_int, C.c_int]
+    L.mmvae_forward.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp, i32,
+                                vp, C.c_size_t, vp]
+    L.mmvae_loss.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, C.c_size_t, vp, vp]
+    L.mmvae_backward.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, i64, f32, vp,
+                                 C.c_size_t, vp, vp]
+    L.mmvae_adam_step.argtypes = [i64, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
+    L.mmvae_train_step.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp,
+                                   C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
+    L.mmvae_dump_noise.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, vp]
+    for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_set_split", "mmvae_forward", "mmvae_loss",
+               "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise"):
+        getattr(L, fn).restype = C.c_int
+    if L.mmvae_abi_version() != 1:
+        raise NativeError("libmmvae_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().mmvae_last_error_string().decode()
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise NativeError(f"{what} failed (code {rc}): {msg}")
+
+
+def param_layout(dims: Dims) -> ParamLayout:
+    pl = ParamLayout()
+    check(lib().mmvae_param_layout(C.byref(dims), C.byref(pl)), "mmvae_param_layout")
+    return pl
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_noise(explicit: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, offset: int = 0) -> Noise:
+    """explicit: dict with x_mask (uint8 [A,B,D]), u_gumbel, u_state (float32), s_mask -> mode 0;
+    otherwise Philox mode keyed by (seed, offset)."""
+    n = Noise()
+    if explicit is not None:
+        n.mode = 0
+        n.x_mask = explicit["x_mask"].data_ptr() if explicit.get("x_mask") is not None else None
+        n.u_gumbel = explicit["u_gumbel"].data_ptr() if explicit.get("u_gumbel") is not None else None
+        n.u_state = explicit["u_state"].data_ptr() if explicit.get("u_state") is not None else None
+        n.s_mask = explicit["s_mask"].data_ptr() if explicit.get("s_mask") is not None else None
+    else:
+        n.mode = 1
+        n.seed = seed & 0xFFFFFFFFFFFFFFFF
+        n.offset = offset & 0xFFFFFFFFFFFFFFFF
+    return n
+
+
+class Engine:
+    """Owns the workspace for one (dims, device) and issues the C-ABI calls on torch's current stream."""
+
+    def __init__(self, A, B, D, H, L, Cc, S, device):
+        self.dims = Dims(A, B, D, H, L, Cc, S)
+        check(lib().mmvae_check_dims(C.byref(self.dims)), "mmvae_check_dims")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise NativeError("the HIP engine needs a GPU device (no CPU fallback)")
+        self.ws_bytes = int(lib().mmvae_workspace_bytes(C.byref(self.dims)))
+        self.ws = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
+        assert self.ws.data_ptr() % 256 == 0
+        self.loss_buf = torch.zeros(5 + 3 * A, dtype=torch.float32, device=self.device)
+
+    def ws_view(self, name: str, width: int) -> torch.Tensor:
+        off = int(lib().mmvae_ws_offset(C.byref(self.dims), WS_IDS[name]))
+        if off < 0:
+            raise NativeError(f"unknown workspace region {name}")
+        d = self.dims
+        return self.ws[off: off + d.A * d.B * width].view(d.A, d.B, width)
+
+    def ws_raw(self, name: str, numel: int) -> torch.Tensor:
+        off = int(lib().mmvae_ws_offset(C.byref(self.dims), WS_IDS[name]))
+        return self.ws[off: off + numel]
+
+    def forward(self, hyper: Hyper, noise: Noise, params, bn_running, nbt, x, x_arm_stride, x_rec, need_grad):
+        check(lib().mmvae_forward(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params), _ptr(bn_running),
+                                  _ptr(nbt), _ptr(x), x_arm_stride, _ptr(x_rec), int(need_grad), _ptr(self.ws),
+                                  self.ws_bytes, _stream()), "mmvae_forward")
+
+    def loss(self, hyper: Hyper) -> torch.Tensor:
+        check(lib().mmvae_loss(C.byref(self.dims), C.byref(hyper), _ptr(self.ws), self.ws_bytes, _ptr(self.loss_buf),
+                               _stream()), "mmvae_loss")
+        return self.loss_buf
+
+    def backward(self, hyper: Hyper, noise: Noise, params, x, x_arm_stride, grads, grad_scale=1.0):
+        check(lib().mmvae_backward(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params), _ptr(x),
+                                   x_arm_stride, float(grad_scale), _ptr(self.ws), self.ws_bytes, _ptr(grads),
+                                   _stream()), "mmvae_backward")
+
+    def train_step(self, hyper, noise, params, bn_running, nbt, x, x_arm_stride, grads, do_adam, exp_avg,
+                   exp_avg_sq, step, lr, b1=0.9, b2=0.999, adam_eps=1e-8, wd=0.0, decoupled=False):
+        check(lib().mmvae_train_step(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params),
+                                     _ptr(bn_running), _ptr(nbt), _ptr(x), x_arm_stride, _ptr(self.ws), self.ws_bytes,
+                                     _ptr(grads), _ptr(self.loss_buf), int(do_adam), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                     int(step), lr, b1, b2, adam_eps, wd, int(decoupled), _stream()),
+              "mmvae_train_step")
+        return self.loss_buf
+
+    def dump_noise(self, hyper: Hyper, noise: Noise):
+        d = self.dims
+        xm = torch.empty(d.A, d.B, d.D, dtype=torch.uint8, device=self.device)
+        ug = torch.empty(d.A, d.B, d.C, dtype=torch.float32, device=self.device)
+        us = torch.empty(d.A, d.B, d.S, dtype=torch.float32, device=self.device)
+        sm = torch.empty(d.A, d.B, d.S, dtype=torch.uint8, device=self.device)
+        check(lib().mmvae_dump_noise(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(xm), _ptr(ug), _ptr(us),
+                                     _ptr(sm), _stream()), "mmvae_dump_noise")
+        return {"x_mask": xm, "u_gumbel": ug, "u_state": us, "s_mask": sm}
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, decoupled=False):
+    check(lib().mmvae_adam_step(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), int(step),
+                                lr, b1, b2, eps, wd, int(decoupled), _stream()), "mmvae_adam_step")

@@ -1,0 +1,337 @@
+// extern "C" surface of libmmvae_hip.so (see include/mmvae.h) and the per-step launch sequence.
+#include "common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace mmvae {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int g_split[4] = {0, 0, 0, 0};
+
+Splits default_splits(const mmvae_dims& d) {
+    auto pick = [](int base_blocks, int target, int cap) {
+        int k = cdiv(target, base_blocks > 0 ? base_blocks : 1);
+        if (k > cap) k = cap;
+        if (k < 1) k = 1;
+        return k;
+    };
+    Splits s;
+    const int nb64 = cdiv(d.B, 64);
+    s.ks_fc1 = g_split[0] > 0 ? g_split[0] : pick(nb64 * d.A, 1024, 16);
+    s.ks_fc1 = min(s.ks_fc1, max(1, cdiv(d.D, 32)));
+    s.ns_fc11 = g_split[1] > 0 ? g_split[1] : pick(nb64 * d.A, 1024, 16);
+    s.ns_fc11 = min(s.ns_fc11, max(1, cdiv(d.D, 64)));
+    s.ks_dw = g_split[2] > 0 ? g_split[2] : pick(cdiv(d.D, 64) * d.A, 1024, 16);
+    s.ks_dw = min(s.ks_dw, max(1, cdiv(d.B, 32)));
+    s.ks_small = g_split[3] > 0 ? g_split[3] : pick(N_SMALL * d.A, 512, 32);
+    s.ks_small = min(s.ks_small, max(1, cdiv(d.B, 32)));
+    return s;
+}
+
+POff make_poff(const mmvae_dims& d) {
+    POff p{};
+    const int64_t D = d.D, H = d.H, L = d.L, C = d.C, S = d.S;
+    const int64_t sizes[MMVAE_N_PARAM_TENSORS] = {
+        H * D, H, H * H, H, H * H, H, H * H, H, L * H, L, C * L, C, S * (L + C), S * (L + C), S, S,
+        L * (C + S), L, H * L, H, H * H, H, H * H, H, H * H, H, D * H, D};
+    int64_t off = 0;
+    for (int t = 0; t < MMVAE_N_PARAM_TENSORS; ++t) {
+        // fc_sigma.w directly follows fc_mu.w, fc_sigma.b directly follows fc_mu.b: the state head is
+        // one [2S, L+C] matrix for the kernels
+        if (t != 13 && t != 15) off = cdiv64(off, 4) * 4;
+        p.o[t] = off;
+        off += sizes[t];
+    }
+    p.per_arm = cdiv64(off, 64) * 64;
+    const int64_t bn[MMVAE_N_BN] = {H, H, H, H, L, S};
+    off = 0;
+    for (int i = 0; i < MMVAE_N_BN; ++i) {
+        p.bn_mean[i] = off; off += bn[i];
+        p.bn_var[i] = off; off += bn[i];
+    }
+    p.bn_per_arm = off;
+    return p;
+}
+
+Layout make_layout(const mmvae_dims& d) {
+    Layout L{};
+    const int64_t A = d.A, B = d.B, D = d.D, H = d.H, Ld = d.L, C = d.C, S = d.S;
+    L.nblk32 = cdiv(d.B, 32);
+    L.nblk64 = cdiv(d.B, 64);
+    L.sp = default_splits(d);
+    int64_t off = 0;
+    auto take = [&](int64_t n) { const int64_t o = off; off += cdiv64(n, 64) * 64; return o; };
+    const int64_t nb = L.nblk32;
+    for (int i = 0; i < 5; ++i) {
+        const int64_t W = (i == 4) ? Ld : H;
+        L.R[i] = take(A * B * W);
+        L.bn_mean[i] = take(A * W);
+        L.bn_rstd[i] = take(A * W);
+        L.bn_part[i] = take(A * nb * 2 * W);
+    }
+    L.XLOW = take(A * B * Ld); L.CPROB = take(A * B * C); L.CC = take(A * B * C); L.YSOFT = take(A * B * C);
+    L.CSMP = take(A * B * C); L.Y = take(A * B * (Ld + C)); L.MS = take(A * B * 2 * S); L.MU = take(A * B * S);
+    L.LV = take(A * B * S); L.SS = take(A * B * S); L.ZIN = take(A * B * (C + S));
+    for (int i = 0; i < 5; ++i) L.Dk[i] = take(A * B * (i == 0 ? Ld : H));
+    L.c_part = take(A * nb * 2 * C); L.c_mean = take(A * C); L.c_iv = take(A * C);
+    L.lat_part = take(A * nb * 2);
+    L.fc1_slab = take((int64_t)L.sp.ks_fc1 * A * B * NP);
+    L.fc11_part = take(A * L.nblk64 * L.sp.ns_fc11 * 2);
+    L.GD10_slab = take((int64_t)L.sp.ns_fc11 * A * B * H);
+    L.DZ11 = take(A * B * D);
+    L.couple_part = take(nb * 2);
+    L.T_part = take(nb * A * C); L.T = take(A * C);
+    for (int i = 1; i <= 10; ++i) L.DZ[i] = take(A * B * ((i == 5 || i == 6) ? Ld : H));
+    L.GZIN = take(A * B * (C + S)); L.GMS = take(A * B * 2 * S); L.GZC = take(A * B * C);
+    for (int i = 1; i <= 5; ++i) {
+        const int64_t W = (i == 5) ? Ld : H;
+        L.G[i] = take(A * B * W);
+        L.bnb_part[i] = take(A * nb * 2 * W);
+        L.bnb_sum[i] = take(A * 2 * W);
+    }
+    L.dw1_slab = take((int64_t)L.sp.ks_dw * A * H * D);
+    L.dw11_slab = take((int64_t)L.sp.ks_dw * A * D * NP);
+    L.small_slab = take((int64_t)L.sp.ks_small * A * N_SMALL * NP * SMALL_LD);
+    L.loss_scratch = take(4096);
+    L.total = off;
+    return L;
+}
+
+static int check_dims(const mmvae_dims* d) {
+    if (!d) { set_error("dims is null"); return MMVAE_E_BADARG; }
+    if (d->A < 1 || d->B < 2 || d->D < 1 || d->H < 1 || d->L < 1 || d->C < 1 || d->S < 1) {
+        set_error("non-positive dimension (A=%d B=%d D=%d H=%d L=%d C=%d S=%d; B must be >= 2 for batch statistics)",
+                  d->A, d->B, d->D, d->H, d->L, d->C, d->S);
+        return MMVAE_E_BADARG;
+    }
+    if (d->A > MMVAE_MAX_ARMS || d->H > 128 || d->C > 128 || d->L > 64 || 2 * d->S > 64 || d->L + d->C > 255 ||
+        d->C + d->S > 255) {
+        set_error("unsupported shape: need A<=%d, fc_dim<=128, n_categories<=128, lowD_dim<=64, state_dim<=32, "
+                  "lowD+C<=255, C+S<=255 (got A=%d H=%d C=%d L=%d S=%d)",
+                  MMVAE_MAX_ARMS, d->A, d->H, d->C, d->L, d->S);
+        return MMVAE_E_UNSUPPORTED;
+    }
+    return 0;
+}
+
+static int make_ctx(Ctx& c, const mmvae_dims* d, const mmvae_hyper* h, void* ws, size_t ws_bytes, void* stream) {
+    if (int rc = check_dims(d)) return rc;
+    if (!h || !ws) { set_error("null hyper / workspace"); return MMVAE_E_BADARG; }
+    c.d = *d;
+    c.h = *h;
+    c.lay = make_layout(*d);
+    c.po = make_poff(*d);
+    if ((size_t)c.lay.total * sizeof(float) > ws_bytes) {
+        set_error("workspace too small: need %zu bytes, got %zu", (size_t)c.lay.total * sizeof(float), ws_bytes);
+        return MMVAE_E_WORKSPACE;
+    }
+    if (reinterpret_cast<uintptr_t>(ws) & 255) { set_error("workspace must be 256-byte aligned"); return MMVAE_E_BADARG; }
+    c.ws = reinterpret_cast<float*>(ws);
+    c.stream = reinterpret_cast<hipStream_t>(stream);
+    return 0;
+}
+
+static int check_noise(const Ctx& c, const mmvae_noise* nz) {
+    if (!nz) { set_error("noise descriptor is null"); return MMVAE_E_BADARG; }
+    if (nz->mode == 0) {
+        if (c.h.training && c.h.x_drop > 0.f && !nz->x_mask) { set_error("explicit noise: x_mask is null"); return MMVAE_E_BADARG; }
+        if (!c.h.eval_flag && !nz->u_gumbel) { set_error("explicit noise: u_gumbel is null"); return MMVAE_E_BADARG; }
+        if (!nz->u_state) { set_error("explicit noise: u_state is null"); return MMVAE_E_BADARG; }
+        if (c.h.training && c.h.s_drop > 0.f && !nz->s_mask) { set_error("explicit noise: s_mask is null"); return MMVAE_E_BADARG; }
+    } else if (nz->mode != 1) {
+        set_error("noise mode must be 0 (explicit) or 1 (philox)");
+        return MMVAE_E_BADARG;
+    }
+    if (c.h.x_drop < 0.f || c.h.x_drop >= 1.f || c.h.s_drop < 0.f || c.h.s_drop >= 1.f) {
+        set_error("dropout probabilities must be in [0,1)");
+        return MMVAE_E_BADARG;
+    }
+    return 0;
+}
+
+static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
+                      const float* x, int64_t xs, float* x_rec, int need_grad) {
+    int rc;
+    if ((rc = launch_fc1_fwd(c, nz, params, x, xs))) return rc;
+    if ((rc = launch_stats_finalize(c, 0, bn_running, nbt))) return rc;
+    for (int layer = 2; layer <= 5; ++layer) {
+        if ((rc = launch_chain_fwd_enc(c, layer, params))) return rc;
+        if ((rc = launch_stats_finalize(c, layer - 1, bn_running, nbt))) return rc;
+    }
+    if ((rc = launch_lat_fwd(c, nz, params))) return rc;
+    if ((rc = launch_stats_finalize(c, 5, nullptr, nullptr))) return rc;
+    if ((rc = launch_chain_fwd_dec(c, params))) return rc;
+    if ((rc = launch_fc11_fused(c, params, x, xs, x_rec, need_grad))) return rc;
+    return 0;
+}
+
+static int do_loss(const Ctx& c, float* loss_out) {
+    int rc;
+    if ((rc = launch_couple(c))) return rc;
+    return launch_loss_finalize(c, loss_out);
+}
+
+static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs,
+                       float grad_scale, float* grads) {
+    int rc;
+    if ((rc = launch_chain_bwd_dec(c, params))) return rc;
+    if ((rc = launch_lat_bwd(c, nz, params))) return rc;
+    if ((rc = launch_bnb_finalize(c, 5))) return rc;
+    for (int layer = 5; layer >= 2; --layer) {
+        if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
+        if ((rc = launch_bnb_finalize(c, layer - 1))) return rc;
+    }
+    if ((rc = launch_bn_bwd_apply1(c))) return rc;
+    if ((rc = launch_dw_big(c, nz, x, xs))) return rc;
+    if ((rc = launch_dw_small(c))) return rc;
+    return launch_reduce_grads(c, grads, grad_scale);
+}
+
+}  // namespace mmvae
+
+using namespace mmvae;
+
+extern "C" {
+
+int mmvae_abi_version(void) { return 1; }
+const char* mmvae_last_error_string(void) { return g_err; }
+int mmvae_check_dims(const mmvae_dims* d) { return check_dims(d); }
+
+int mmvae_set_split(int which, int value) {
+    if (which < 0 || which > 3 || value < 0 || value > 64) { set_error("bad split"); return MMVAE_E_BADARG; }
+    g_split[which] = value;
+    return 0;
+}
+
+int mmvae_param_layout(const mmvae_dims* d, mmvae_param_layout_t* out) {
+    if (int rc = check_dims(d)) return rc;
+    if (!out) { set_error("out is null"); return MMVAE_E_BADARG; }
+    const POff p = make_poff(*d);
+    const int64_t D = d->D, H = d->H, L = d->L, C = d->C, S = d->S;
+    const int64_t rows[MMVAE_N_PARAM_TENSORS] = {H, H, H, H, H, H, H, H, L, L, C, C, S, S, S, S, L, L, H, H, H, H, H, H, H, H, D, D};
+    const int64_t cols[MMVAE_N_PARAM_TENSORS] = {D, 1, H, 1, H, 1, H, 1, H, 1, L, 1, L + C, L + C, 1, 1, C + S, 1, L, 1, H, 1, H, 1, H, 1, H, 1};
+    out->per_arm = p.per_arm;
+    for (int t = 0; t < MMVAE_N_PARAM_TENSORS; ++t) { out->offset[t] = p.o[t]; out->rows[t] = rows[t]; out->cols[t] = cols[t]; }
+    out->bn_per_arm = p.bn_per_arm;
+    const int64_t bn[MMVAE_N_BN] = {H, H, H, H, L, S};
+    for (int i = 0; i < MMVAE_N_BN; ++i) { out->bn_mean_offset[i] = p.bn_mean[i]; out->bn_var_offset[i] = p.bn_var[i]; out->bn_dim[i] = bn[i]; }
+    return 0;
+}
+
+size_t mmvae_workspace_bytes(const mmvae_dims* d) {
+    if (check_dims(d)) return 0;
+    return (size_t)make_layout(*d).total * sizeof(float);
+}
+
+int64_t mmvae_ws_offset(const mmvae_dims* d, int id) {
+    if (check_dims(d)) return -1;
+    const Layout L = make_layout(*d);
+    switch (id) {
+        case MMVAE_WS_X_LOW: return L.XLOW;
+        case MMVAE_WS_C_PROB: return L.CPROB;
+        case MMVAE_WS_C: return L.CC;
+        case MMVAE_WS_C_SMP: return L.CSMP;
+        case MMVAE_WS_S_MEAN: return L.MU;
+        case MMVAE_WS_S_LOGVAR: return L.LV;
+        case MMVAE_WS_S_SMP: return L.SS;
+        case MMVAE_WS_Y_SOFT: return L.YSOFT;
+        case MMVAE_WS_R1: return L.R[0];
+        case MMVAE_WS_R2: return L.R[1];
+        case MMVAE_WS_R3: return L.R[2];
+        case MMVAE_WS_R4: return L.R[3];
+        case MMVAE_WS_R5: return L.R[4];
+        case MMVAE_WS_D6: return L.Dk[0];
+        case MMVAE_WS_D7: return L.Dk[1];
+        case MMVAE_WS_D8: return L.Dk[2];
+        case MMVAE_WS_D9: return L.Dk[3];
+        case MMVAE_WS_D10: return L.Dk[4];
+        case MMVAE_WS_ZIN: return L.ZIN;
+        case MMVAE_WS_DZ11: return L.DZ11;
+        case MMVAE_WS_DZ1: return L.DZ[1];
+        case MMVAE_WS_GZIN: return L.GZIN;
+        case MMVAE_WS_GZC: return L.GZC;
+        case MMVAE_WS_G5: return L.G[5];
+        case MMVAE_WS_BN_MEAN1: return L.bn_mean[0];
+        default: set_error("unknown workspace id %d", id); return -1;
+    }
+}
+
+int mmvae_forward(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, const float* params,
+                  float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride, float* x_rec, int need_grad,
+                  void* ws, size_t ws_bytes, void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (!params || !x) { set_error("null params / x"); return MMVAE_E_BADARG; }
+    if (int rc = check_noise(c, nz)) return rc;
+    if (need_grad && !h->training) { set_error("need_grad requires training mode (batch statistics)"); return MMVAE_E_UNSUPPORTED; }
+    return do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, x_rec, need_grad);
+}
+
+int mmvae_loss(const mmvae_dims* d, const mmvae_hyper* h, void* ws, size_t ws_bytes, float* loss_out, void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (!loss_out) { set_error("loss_out is null"); return MMVAE_E_BADARG; }
+    return do_loss(c, loss_out);
+}
+
+int mmvae_backward(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, const float* params,
+                   const float* x, int64_t x_arm_stride, float grad_scale, void* ws, size_t ws_bytes, float* grads,
+                   void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (!params || !x || !grads) { set_error("null params / x / grads"); return MMVAE_E_BADARG; }
+    if (int rc = check_noise(c, nz)) return rc;
+    if (!h->training) { set_error("backward requires training mode"); return MMVAE_E_UNSUPPORTED; }
+    return do_backward(c, nz, params, x, x_arm_stride, grad_scale, grads);
+}
+
+int mmvae_adam_step(int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t step,
+                    float lr, float beta1, float beta2, float adam_eps, float weight_decay, int decoupled,
+                    void* stream) {
+    if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || step < 1) {
+        set_error("adam: bad argument");
+        return MMVAE_E_BADARG;
+    }
+    return launch_adam(n, params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, adam_eps, weight_decay, decoupled,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, float* params,
+                     float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes,
+                     float* grads, float* loss_out, int do_adam, float* exp_avg, float* exp_avg_sq, int64_t step,
+                     float lr, float beta1, float beta2, float adam_eps, float weight_decay, int decoupled,
+                     void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (!params || !x || !grads || !loss_out) { set_error("null params / x / grads / loss_out"); return MMVAE_E_BADARG; }
+    if (int rc = check_noise(c, nz)) return rc;
+    if (!h->training) { set_error("train_step requires training mode"); return MMVAE_E_UNSUPPORTED; }
+    int rc;
+    if ((rc = do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, nullptr, 1))) return rc;
+    if ((rc = do_loss(c, loss_out))) return rc;
+    if ((rc = do_backward(c, nz, params, x, x_arm_stride, 1.f, grads))) return rc;
+    if (do_adam) {
+        if (!exp_avg || !exp_avg_sq || step < 1) { set_error("adam state missing"); return MMVAE_E_BADARG; }
+        const int64_t n = c.po.per_arm * d->A;
+        return launch_adam(n, params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, adam_eps, weight_decay,
+                           decoupled, c.stream);
+    }
+    return 0;
+}
+
+int mmvae_dump_noise(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, uint8_t* x_mask,
+                     float* u_gumbel, float* u_state, uint8_t* s_mask, void* stream) {
+    if (int rc = check_dims(d)) return rc;
+    if (!h || !nz) { set_error("null hyper / noise"); return MMVAE_E_BADARG; }
+    return launch_dump_noise(*d, *h, nz, x_mask, u_gumbel, u_state, s_mask, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,412 @@
+// Small-layer chains (every Linear whose dimensions are <= 128 x 256): a row block of 32 cells is
+// carried through up to five layers inside one workgroup, activations staying in LDS, weights
+// staged per layer.  MFMA fp32 32x32x2; wave w owns output columns [32w, 32w+32).
+//
+//   k_chain_fwd   encoder fc2..fc5 one layer per launch (BatchNorm needs the whole batch between
+//                 layers: nn_model.py:265-268), decoder fc6..fc10 in one launch (:277-284)
+//   k_chain_bwd   their autograd: dZ = G .* relu'(out); G_prev = dZ W; with the BatchNorm backward
+//                 folded into the prologue and its batch sums emitted by the epilogue
+#include "common.hpp"
+
+namespace mmvae {
+
+#define HIP_LAUNCH_CHECK(what)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            set_error("%s: %s", what, hipGetErrorString(e_));                         \
+            return MMVAE_E_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+struct FwdLayer {
+    int64_t w_off, b_off;   // inside one arm's parameter segment
+    int64_t out_off;        // workspace, [A,B,N]
+    int K, N, act;          // act: 1 = ReLU, 0 = identity
+};
+struct ChainFwdArgs {
+    int nlayers;
+    FwdLayer L[5];
+    int64_t x_off;          // workspace, [A,B,K0]
+    int K0;
+    int64_t bn_mean_off, bn_rstd_off;   // [A,K0] or -1: input is BatchNorm(x)
+    int64_t stats_part_off;             // [A][nblk][2][N_last] or -1
+    int B, ld, wrows;
+    int64_t per_arm;
+};
+
+// stage W [N][K] (global, row-major) into LDS rows [0, rows_pad) x cols [0, cols_pad), zero padded
+__device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restrict__ W, int N, int K,
+                                        int rows_pad, int cols_pad) {
+    const int c4n = cols_pad / 4;
+    const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+    for (int idx = threadIdx.x; idx < rows_pad * c4n; idx += blockDim.x) {
+        const int row = idx / c4n, col = (idx % c4n) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < N) {
+            const float* p = W + (int64_t)row * K + col;
+            if (vec && col + 3 < K) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (col < K) v.x = p[0];
+                if (col + 1 < K) v.y = p[1];
+                if (col + 2 < K) v.z = p[2];
+                if (col + 3 < K) v.w = p[3];
+            }
+        }
+        *reinterpret_cast<float4*>(&Ws[row * ld + col]) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const float* __restrict__ params,
+                                                   float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                 // [32][ld]
+    float* Ws = smem + 32 * a.ld;     // [wrows][ld]
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int B = a.B, ld = a.ld;
+    const int nvalid = min(32, B - b0);
+    const float* P = params + (int64_t)arm * a.per_arm;
+
+    // ---- input tile (optionally BatchNorm-normalised), zero padded to a multiple of 8 columns
+    {
+        const float* X = ws + a.x_off + (int64_t)arm * B * a.K0;
+        const float* mu = a.bn_mean_off >= 0 ? ws + a.bn_mean_off + (int64_t)arm * a.K0 : nullptr;
+        const float* rs = a.bn_rstd_off >= 0 ? ws + a.bn_rstd_off + (int64_t)arm * a.K0 : nullptr;
+        const int kp = rup(a.K0, 8);
+        for (int idx = tid; idx < 32 * kp; idx += 256) {
+            const int row = idx / kp, col = idx % kp;
+            float v = 0.f;
+            if (row < nvalid && col < a.K0) {
+                v = X[(int64_t)(b0 + row) * a.K0 + col];
+                if (mu) v = (v - mu[col]) * rs[col];
+            }
+            Xs[row * ld + col] = v;
+        }
+    }
+    for (int l = 0; l < a.nlayers; ++l) {
+        const FwdLayer& Lr = a.L[l];
+        const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
+        stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
+        __syncthreads();
+        f32x16 acc = zero16();
+        const bool active = wv * 32 < NPad;
+        if (active) mma_nt(acc, Xs, ld, 0, Ws, ld, wv * 32, KP / 8);
+        __syncthreads();   // every wave has finished reading Xs / Ws
+        const int col = wv * 32 + (lane & 31);
+        const bool last = (l + 1 == a.nlayers);
+        float vals[16];
+        if (active) {
+            const float bias = (col < N) ? P[Lr.b_off + col] : 0.f;
+            float* out = ws + Lr.out_off + (int64_t)arm * B * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, lane);
+                float v = 0.f;
+                if (col < N && row < nvalid) {
+                    v = acc[r] + bias;
+                    if (Lr.act) v = fmaxf(v, 0.f);
+                    out[(int64_t)(b0 + row) * N + col] = v;
+                }
+                vals[r] = v;
+                // next layer's input: zero beyond N (up to the next multiple of 8) and beyond nvalid
+                if (col < rup(N, 8)) Xs[row * ld + col] = v;
+            }
+        }
+        if (last && a.stats_part_off >= 0) {
+            // per-block column mean and M2 over the nvalid rows; lanes l and l^32 share a column
+            if (active) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += vals[r];
+                s += __shfl_xor(s, 32, 64);
+                const float mean = s / (float)nvalid;
+                float m2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lane);
+                    if (row < nvalid) { const float dl = vals[r] - mean; m2 += dl * dl; }
+                }
+                m2 += __shfl_xor(m2, 32, 64);
+                if (lane < 32 && col < N) {
+                    float* p = ws + a.stats_part_off + (((int64_t)arm * gridDim.x + blk) * 2) * N;
+                    p[col] = mean;
+                    p[N + col] = m2;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct BwdLayer {
+    int64_t w_off;      // [N][K]
+    int64_t dz_off;     // workspace [A,B,N]: dZ of this layer (stored)
+    int64_t act_off;    // workspace [A,B,N]: saved output of this layer (ReLU mask), -1 = identity
+    int K, N;
+};
+struct ChainBwdArgs {
+    int nlayers;
+    BwdLayer L[5];          // backward order
+    int64_t g_off;          // [nslab][A,B,N0] gradient w.r.t. the output of L[0] (after its BN if any)
+    int nslab;
+    int64_t slab_stride;
+    int64_t bnb_sum_off;    // [A][2][N0] batch sums (sum G, sum G*xhat) or -1: BN backward prologue
+    int64_t bn_mean_off, bn_rstd_off;   // statistics of L[0]'s output, [A,N0]
+    int64_t gout_off;       // [A,B,Klast]
+    int64_t part_off;       // [A][nblk][2][Klast] or -1: sums of gout and gout*xhat_prev
+    int64_t rprev_off, rprev_mean_off, rprev_rstd_off;   // the BN input that produced the chain input
+    int B, ld, wrows;
+    int64_t per_arm;
+};
+
+__global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const float* __restrict__ params,
+                                                   float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Gs = smem;                // [32][ld]
+    float* Ws = smem + 32 * a.ld;    // [128][ld]  rows = n (output features), cols = k (input features)
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int B = a.B, ld = a.ld;
+    const int nvalid = min(32, B - b0);
+    const float* P = params + (int64_t)arm * a.per_arm;
+
+    // ---- prologue: dZ of the first (= last forward) layer
+    {
+        const BwdLayer& L0 = a.L[0];
+        const int N = L0.N, np = rup(N, 8);
+        const float* act = L0.act_off >= 0 ? ws + L0.act_off + (int64_t)arm * B * N : nullptr;
+        float* dz = ws + L0.dz_off + (int64_t)arm * B * N;
+        const float* s1 = a.bnb_sum_off >= 0 ? ws + a.bnb_sum_off + (int64_t)arm * 2 * N : nullptr;
+        const float* mu = a.bnb_sum_off >= 0 ? ws + a.bn_mean_off + (int64_t)arm * N : nullptr;
+        const float* rs = a.bnb_sum_off >= 0 ? ws + a.bn_rstd_off + (int64_t)arm * N : nullptr;
+        const float invB = 1.f / (float)B;
+        for (int idx = tid; idx < 32 * np; idx += 256) {
+            const int row = idx / np, col = idx % np;
+            float v = 0.f;
+            if (row < nvalid && col < N) {
+                const int64_t e = (int64_t)(b0 + row) * N + col;
+                float g = 0.f;
+                for (int s = 0; s < a.nslab; ++s) g += ws[a.g_off + (int64_t)s * a.slab_stride + (int64_t)arm * B * N + e];
+                const float av = act ? act[e] : 1.f;
+                if (s1) {
+                    const float xh = (av - mu[col]) * rs[col];
+                    g = rs[col] * (g - s1[col] * invB - xh * (s1[N + col] * invB));
+                }
+                v = (!act || av > 0.f) ? g : 0.f;
+                dz[e] = v;
+            }
+            Gs[row * ld + col] = v;
+        }
+    }
+    for (int l = 0; l < a.nlayers; ++l) {
+        const BwdLayer& Lr = a.L[l];
+        const int K = Lr.K, N = Lr.N, NP8 = rup(N, 8), KPad = rup(K, 32);
+        stage_w(Ws, ld, P + Lr.w_off, N, K, NP8, KPad);
+        __syncthreads();
+        f32x16 acc = zero16();
+        const bool active = wv * 32 < KPad;
+        if (active) mma_nn(acc, Gs, ld, 0, Ws, ld, wv * 32, NP8 / 8);
+        __syncthreads();
+        const int col = wv * 32 + (lane & 31);
+        const bool last = (l + 1 == a.nlayers);
+        if (active) {
+            if (!last) {
+                const BwdLayer& Ln = a.L[l + 1];   // its N == this K
+                const float* act = Ln.act_off >= 0 ? ws + Ln.act_off + (int64_t)arm * B * K : nullptr;
+                float* dz = ws + Ln.dz_off + (int64_t)arm * B * K;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lane);
+                    float v = 0.f;
+                    if (col < K && row < nvalid) {
+                        const int64_t e = (int64_t)(b0 + row) * K + col;
+                        v = (!act || act[e] > 0.f) ? acc[r] : 0.f;
+                        dz[e] = v;
+                    }
+                    Gs[row * ld + col] = v;
+                }
+            } else {
+                float* go = ws + a.gout_off + (int64_t)arm * B * K;
+                float s1 = 0.f, s2 = 0.f;
+                const bool want = a.part_off >= 0;
+                const float* rp = want ? ws + a.rprev_off + (int64_t)arm * B * K : nullptr;
+                float mu = 0.f, rs = 0.f;
+                if (want && col < K) {
+                    mu = ws[a.rprev_mean_off + (int64_t)arm * K + col];
+                    rs = ws[a.rprev_rstd_off + (int64_t)arm * K + col];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lane);
+                    if (col < K && row < nvalid) {
+                        const int64_t e = (int64_t)(b0 + row) * K + col;
+                        go[e] = acc[r];
+                        if (want) {
+                            s1 += acc[r];
+                            s2 += acc[r] * ((rp[e] - mu) * rs);
+                        }
+                    }
+                }
+                if (want) {
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lane < 32 && col < K) {
+                        float* p = ws + a.part_off + (((int64_t)arm * gridDim.x + blk) * 2) * K;
+                        p[col] = s1;
+                        p[K + col] = s2;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// DZ1 = BNbackward(G1) .* relu'(R1): elementwise, one thread per element
+__global__ void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ R,
+                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                               const float* __restrict__ sums, float* __restrict__ DZ, int A, int B, int W) {
+    const int64_t n = (int64_t)A * B * W;
+    const float invB = 1.f / (float)B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % W);
+        const int arm = (int)(i / ((int64_t)B * W));
+        const float r = R[i];
+        const float mu = mean[arm * W + col], rs = rstd[arm * W + col];
+        const float xh = (r - mu) * rs;
+        const float g = rs * (G[i] - sums[(arm * 2) * W + col] * invB - xh * (sums[(arm * 2 + 1) * W + col] * invB));
+        DZ[i] = r > 0.f ? g : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+// forward: activations and weights are K-contiguous rows -> ld = max width rounded to 8, + 4
+// (ld/4 odd: conflict-free ds_read_b128); weights need rup(N,32) rows.
+// backward: weight tile is [N rows][K cols] read along K by lane -> ld = rup(K,32) + 4, rup(N,8) rows.
+static int fwd_ld(int maxdim) { return rup(maxdim, 8) + 4; }
+static int bwd_ld(int maxdim) { return rup(maxdim, 32) + 4; }
+static size_t chain_smem(int ld, int wrows) { return (size_t)(32 * ld + wrows * ld) * sizeof(float); }
+
+int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params) {
+    // layer in 2..5: out = relu(BN_{layer-1}(R_{layer-1}) W^T + b), statistics of the output
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    ChainFwdArgs a{};
+    a.nlayers = 1;
+    const int i = layer - 1;   // index into R / bn arrays of this layer's output
+    const int N = (layer == 5) ? d.L : d.H;
+    a.L[0] = FwdLayer{c.po.o[2 * (layer - 1)], c.po.o[2 * (layer - 1) + 1], L.R[i], d.H, N, 1};
+    a.x_off = L.R[i - 1];
+    a.K0 = d.H;
+    a.bn_mean_off = L.bn_mean[i - 1];
+    a.bn_rstd_off = L.bn_rstd[i - 1];
+    a.stats_part_off = L.bn_part[i];
+    a.B = d.B;
+    a.ld = fwd_ld(d.H);
+    a.wrows = rup(N, 32);
+    a.per_arm = c.po.per_arm;
+    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+                       c.ws);
+    HIP_LAUNCH_CHECK("k_chain_fwd<enc>");
+    return 0;
+}
+
+int launch_chain_fwd_dec(const Ctx& c, const float* params) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    ChainFwdArgs a{};
+    a.nlayers = 5;
+    a.L[0] = FwdLayer{c.po.o[16], c.po.o[17], L.Dk[0], d.C + d.S, d.L, 1};   // fc6
+    a.L[1] = FwdLayer{c.po.o[18], c.po.o[19], L.Dk[1], d.L, d.H, 1};         // fc7
+    a.L[2] = FwdLayer{c.po.o[20], c.po.o[21], L.Dk[2], d.H, d.H, 1};
+    a.L[3] = FwdLayer{c.po.o[22], c.po.o[23], L.Dk[3], d.H, d.H, 1};
+    a.L[4] = FwdLayer{c.po.o[24], c.po.o[25], L.Dk[4], d.H, d.H, 1};
+    a.x_off = L.ZIN;
+    a.K0 = d.C + d.S;
+    a.bn_mean_off = a.bn_rstd_off = -1;
+    a.stats_part_off = -1;
+    a.B = d.B;
+    a.ld = fwd_ld(max(max(d.H, d.L), d.C + d.S));
+    a.wrows = rup(max(d.H, d.L), 32);
+    a.per_arm = c.po.per_arm;
+    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+                       c.ws);
+    HIP_LAUNCH_CHECK("k_chain_fwd<dec>");
+    return 0;
+}
+
+int launch_chain_bwd_dec(const Ctx& c, const float* params) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    ChainBwdArgs a{};
+    a.nlayers = 5;
+    a.L[0] = BwdLayer{c.po.o[24], L.DZ[10], L.Dk[4], d.H, d.H};          // fc10
+    a.L[1] = BwdLayer{c.po.o[22], L.DZ[9], L.Dk[3], d.H, d.H};
+    a.L[2] = BwdLayer{c.po.o[20], L.DZ[8], L.Dk[2], d.H, d.H};
+    a.L[3] = BwdLayer{c.po.o[18], L.DZ[7], L.Dk[1], d.L, d.H};           // fc7: K = L
+    a.L[4] = BwdLayer{c.po.o[16], L.DZ[6], L.Dk[0], d.C + d.S, d.L};     // fc6: K = C+S
+    a.g_off = L.GD10_slab;
+    a.nslab = L.sp.ns_fc11;
+    a.slab_stride = (int64_t)d.A * d.B * d.H;
+    a.bnb_sum_off = -1;
+    a.bn_mean_off = a.bn_rstd_off = -1;
+    a.gout_off = L.GZIN;
+    a.part_off = -1;
+    a.rprev_off = a.rprev_mean_off = a.rprev_rstd_off = -1;
+    a.B = d.B;
+    a.ld = bwd_ld(max(max(d.H, d.L), d.C + d.S));
+    a.wrows = rup(max(d.H, d.L), 8);
+    a.per_arm = c.po.per_arm;
+    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+                       c.ws);
+    HIP_LAUNCH_CHECK("k_chain_bwd<dec>");
+    return 0;
+}
+
+int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
+    // layer in 5..2: G[layer] is the gradient w.r.t. BN_layer's output
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    ChainBwdArgs a{};
+    a.nlayers = 1;
+    const int i = layer - 1;
+    const int N = (layer == 5) ? d.L : d.H;
+    a.L[0] = BwdLayer{c.po.o[2 * (layer - 1)], L.DZ[layer], L.R[i], d.H, N};
+    a.g_off = L.G[layer];
+    a.nslab = 1;
+    a.slab_stride = 0;
+    a.bnb_sum_off = L.bnb_sum[layer];
+    a.bn_mean_off = L.bn_mean[i];
+    a.bn_rstd_off = L.bn_rstd[i];
+    a.gout_off = L.G[layer - 1];
+    a.part_off = L.bnb_part[layer - 1];
+    a.rprev_off = L.R[i - 1];
+    a.rprev_mean_off = L.bn_mean[i - 1];
+    a.rprev_rstd_off = L.bn_rstd[i - 1];
+    a.B = d.B;
+    a.ld = bwd_ld(max(d.H, N));
+    a.wrows = rup(N, 8);
+    a.per_arm = c.po.per_arm;
+    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+                       c.ws);
+    HIP_LAUNCH_CHECK("k_chain_bwd<enc>");
+    return 0;
+}
+
+int launch_bn_bwd_apply1(const Ctx& c) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    const int64_t n = (int64_t)d.A * d.B * d.H;
+    const int blocks = (int)imin64(2048, cdiv64(n, 256));
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(blocks), dim3(256), 0, c.stream, c.ws + L.G[1], c.ws + L.R[0],
+                       c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_sum[1], c.ws + L.DZ[1], d.A, d.B, d.H);
+    HIP_LAUNCH_CHECK("k_bn_bwd_apply");
+    return 0;
+}
+
+}  // namespace mmvae

@@ -1,0 +1,260 @@
+// Internal header of libmmvae_hip.so: shapes, workspace layout, and the gfx950 device helpers
+// (fp32 MFMA tile products out of LDS, wave reductions, Philox) shared by every kernel file.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mmvae.h"
+
+namespace mmvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+constexpr int ROWS32 = 32;   // row block of the small-layer / row-wise kernels
+constexpr int NP = 128;      // padded width of every narrow (<=128) dimension in MFMA tiles
+constexpr int SMALL_LD = 256; // row stride of a small-layer dW slab: [N<=128][K+1<=256]
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ inline int rup(int a, int b) { return cdiv(a, b) * b; }
+__host__ __device__ inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------------------------------
+// Workspace layout (offsets in floats).  Authoritative copy; Python asks through
+// mmvae_ws_offset().
+// ------------------------------------------------------------------------------------------
+struct Splits {
+    int ks_fc1;   // split-K of fc1 forward
+    int ns_fc11;  // column splits of the fused fc11 kernel
+    int ks_dw;    // batch splits of the dW1 / dW11 GEMMs
+    int ks_small; // batch splits of the batched small-layer dW GEMM
+};
+
+constexpr int N_SMALL = 12;  // fc2 fc3 fc4 fc5 fcc musig fc6 fc7 fc8 fc9 fc10 + fc1.bias
+
+struct Layout {
+    int nblk32;   // ceil(B/32)
+    int nblk64;   // ceil(B/64)
+    Splits sp;
+    // forward, saved for backward
+    int64_t R[5];                  // R1..R4 [A,B,H], R5 [A,B,L]
+    int64_t bn_mean[5], bn_rstd[5];  // [A,W]
+    int64_t bn_part[5];            // [A][nblk32][2][W]   (block mean, block M2)
+    int64_t XLOW, CPROB, CC, YSOFT, CSMP, Y, MS, MU, LV, SS, ZIN;
+    int64_t Dk[5];                 // D6 [A,B,L], D7..D10 [A,B,H]
+    int64_t c_part, c_mean, c_iv;  // [A][nblk32][2][C], [A,C], [A,C]
+    int64_t lat_part;              // [A][nblk32][2]  (kl sum, entropy sum)
+    int64_t fc1_slab;              // [KS][A][B][NP]
+    int64_t fc11_part;             // [A][nblk64*NS][2] (squared error sum, mismatch count)
+    int64_t GD10_slab;             // [NS][A][B][H]
+    int64_t DZ11;                  // [A][B][D]
+    int64_t couple_part;           // [nblk32][2]  (pair distance sum, pair l2 sum)
+    int64_t T_part, T;             // [nblk32][A][C], [A][C]
+    // backward
+    int64_t DZ[11];                // DZ[1..4] [A,B,H], DZ[5] [A,B,L], DZ[6] [A,B,L], DZ[7..10] [A,B,H]
+    int64_t GZIN, GMS, GZC, G[6];  // G[5] [A,B,L] (grad wrt x_low); G[1..4] [A,B,H] grad wrt BN_i output
+    int64_t bnb_part[6], bnb_sum[6];  // [A][nblk32][2][W], [A][2][W]   (index 1..5)
+    int64_t dw1_slab;              // [KS][A][H][D]
+    int64_t dw11_slab;             // [KS][A][D][NP]
+    int64_t small_slab;            // [KS][A][N_SMALL][NP*SMALL_LD]
+    int64_t loss_scratch;          // small
+    int64_t total;
+};
+
+Layout make_layout(const mmvae_dims& d);
+Splits default_splits(const mmvae_dims& d);
+
+// Per-arm parameter offsets (floats) -- mirrors mmvae_param_layout_t
+struct POff {
+    int64_t per_arm;
+    int64_t o[MMVAE_N_PARAM_TENSORS];
+    int64_t bn_per_arm;
+    int64_t bn_mean[MMVAE_N_BN], bn_var[MMVAE_N_BN];
+};
+POff make_poff(const mmvae_dims& d);
+
+void set_error(const char* fmt, ...);
+
+#ifdef __HIPCC__
+// ------------------------------------------------------------------------------------------
+// Device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// Row of accumulator register r for this lane in a 32x32 MFMA result (col = lane & 31).
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// acc[32x32] += A[32 x K] * Bt[32 x K]^T.  Both tiles are LDS images with K contiguous
+// (rows a_row0.. of At, rows b_row0.. of Bt).  `kgroups` groups of 8 k's.  Each lane fetches
+// 4 consecutive k's with one ds_read_b128 and feeds 4 MFMAs: the k order inside a group is
+// permuted identically for A and B, which leaves the dot product unchanged.
+__device__ __forceinline__ void mma_nt(f32x16& acc, const float* At, int lda, int a_row0,
+                                       const float* Bt, int ldb, int b_row0, int kgroups) {
+    const int lane = lane_id();
+    const float* pa = At + (a_row0 + (lane & 31)) * lda + 4 * (lane >> 5);
+    const float* pb = Bt + (b_row0 + (lane & 31)) * ldb + 4 * (lane >> 5);
+    for (int g = 0; g < kgroups; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(pa + 8 * g);
+        const float4 b = *reinterpret_cast<const float4*>(pb + 8 * g);
+        acc = mfma32(a.x, b.x, acc);
+        acc = mfma32(a.y, b.y, acc);
+        acc = mfma32(a.z, b.z, acc);
+        acc = mfma32(a.w, b.w, acc);
+    }
+}
+
+// acc[32x32] += A[32 x K] * Bk[K x 32]; A as above (K contiguous), Bk an LDS image [k][n] with n
+// contiguous (columns n0..n0+31).
+__device__ __forceinline__ void mma_nn(f32x16& acc, const float* At, int lda, int a_row0,
+                                       const float* Bk, int ldb, int n0, int kgroups) {
+    const int lane = lane_id();
+    const float* pa = At + (a_row0 + (lane & 31)) * lda + 4 * (lane >> 5);
+    const float* pb = Bk + (4 * (lane >> 5)) * ldb + n0 + (lane & 31);
+    for (int g = 0; g < kgroups; ++g) {
+        const float4 a = *reinterpret_cast<const float4*>(pa + 8 * g);
+        const float* q = pb + (8 * g) * ldb;
+        acc = mfma32(a.x, q[0], acc);
+        acc = mfma32(a.y, q[ldb], acc);
+        acc = mfma32(a.z, q[2 * ldb], acc);
+        acc = mfma32(a.w, q[3 * ldb], acc);
+    }
+}
+
+// acc[32x32] += Pk[K x 32]^T * Qk[K x 32]; both LDS images [k][.] with the non-k index contiguous.
+// ksteps = K/2.
+__device__ __forceinline__ void mma_tn(f32x16& acc, const float* Pk, int ldp, int m0,
+                                       const float* Qk, int ldq, int n0, int ksteps) {
+    const int lane = lane_id();
+    const float* pa = Pk + (lane >> 5) * ldp + m0 + (lane & 31);
+    const float* pb = Qk + (lane >> 5) * ldq + n0 + (lane & 31);
+#pragma unroll 4
+    for (int s = 0; s < ksteps; ++s) {
+        acc = mfma32(pa[2 * s * ldp], pb[2 * s * ldq], acc);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- Philox4x32-10 -----------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0;
+        const uint64_t p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// Noise streams of the Philox mode.  Counter = (element group, stream id, step); key = seed.
+enum { STREAM_XMASK = 0, STREAM_GUMBEL = 1, STREAM_STATE = 2, STREAM_SMASK = 3 };
+
+struct NoiseDev {
+    int mode;
+    const uint8_t* x_mask;
+    const float* u_gumbel;
+    const float* u_state;
+    const uint8_t* s_mask;
+    uint32_t k0, k1;       // seed
+    uint32_t step_lo, step_hi;
+    uint32_t x_keep_thr;   // keep iff u32 < thr  (thr = (1-p) * 2^32, saturated)
+    uint32_t s_keep_thr;
+};
+
+__host__ __device__ inline uint32_t keep_threshold(float p_drop) {
+    double k = (1.0 - (double)p_drop) * 4294967296.0;
+    if (k >= 4294967295.0) return 0xFFFFFFFFu;
+    if (k <= 0.0) return 0u;
+    return (uint32_t)k;
+}
+
+// 4 random words for elements [4*g, 4*g+3] of stream (arm, kind).
+__device__ __forceinline__ u32x4 noise_words(const NoiseDev& nz, int arm, int kind, uint64_t group) {
+    return philox4x32((uint32_t)group, (uint32_t)(group >> 32), (uint32_t)(arm * 4 + kind) ^ (nz.step_hi << 8),
+                      nz.step_lo, nz.k0, nz.k1);
+}
+__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ uint32_t pick(const u32x4& w, int i) {
+    return i == 0 ? w.x : (i == 1 ? w.y : (i == 2 ? w.z : w.w));
+}
+// scalar access helpers (used by the row-wise kernels; the GEMM loaders use the vector form)
+__device__ __forceinline__ float noise_uniform(const NoiseDev& nz, int arm, int kind, uint64_t idx) {
+    const u32x4 w = noise_words(nz, arm, kind, idx >> 2);
+    return u01(pick(w, (int)(idx & 3)));
+}
+__device__ __forceinline__ bool noise_keep(const NoiseDev& nz, int arm, int kind, uint64_t idx, uint32_t thr) {
+    const u32x4 w = noise_words(nz, arm, kind, idx >> 2);
+    const uint32_t v = pick(w, (int)(idx & 3));
+    return thr == 0xFFFFFFFFu ? true : (v < thr);
+}
+#endif  // __HIPCC__
+
+// ------------------------------------------------------------------------------------------
+// Launch context handed to the stage launchers (host)
+// ------------------------------------------------------------------------------------------
+struct Ctx {
+    mmvae_dims d;
+    mmvae_hyper h;
+    Layout lay;
+    POff po;
+    float* ws;
+    hipStream_t stream;
+};
+
+#ifdef __HIPCC__
+NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h);
+#endif
+
+// stage launchers (one per kernel family); each returns 0 or MMVAE_E_LAUNCH
+int launch_fc1_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs);
+int launch_stats_finalize(const Ctx& c, int layer /*0..4 BN, 5 = c stats*/, float* bn_running, int64_t* nbt);
+int launch_chain_fwd_enc(const Ctx& c, int layer /*2..5*/, const float* params);
+int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params);
+int launch_chain_fwd_dec(const Ctx& c, const float* params);
+int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
+int launch_couple(const Ctx& c);
+int launch_loss_finalize(const Ctx& c, float* loss_out);
+int launch_chain_bwd_dec(const Ctx& c, const float* params);
+int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params);
+int launch_bnb_finalize(const Ctx& c, int layer /*1..5*/);
+int launch_chain_bwd_enc(const Ctx& c, int layer /*5..2*/, const float* params);
+int launch_bn_bwd_apply1(const Ctx& c);
+int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t xs);
+int launch_dw_small(const Ctx& c);
+int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale);
+int launch_adam(int64_t n, float* p, const float* g, float* m, float* v, int64_t step, float lr, float b1,
+                float b2, float eps, float wd, int decoupled, hipStream_t s);
+int launch_dump_noise(const mmvae_dims& d, const mmvae_hyper& h, const mmvae_noise* nz, uint8_t* x_mask,
+                      float* u_gumbel, float* u_state, uint8_t* s_mask, hipStream_t s);
+
+}  // namespace mmvae

@@ -1,0 +1,841 @@
+// Row-wise (one wavefront per cell) kernels and the small reductions between them:
+//
+//   k_stats_finalize  block (mean, M2) partials -> batch mean / rstd (BatchNorm1d, nn_model.py:208-255,
+//                     running statistics included) or mean / inv_var (nn_model.py:75-77)
+//   k_lat_fwd         x_low = BN5(R5); c_prob = softmax(fcc x_low); c = softmax(c_prob/tau);
+//                     Gumbel-softmax sample; state head; reparameterise; decoder input
+//                     (nn_model.py:268-269, :337-351, :413-493)
+//   k_couple          pairwise coupling terms over arms (nn_model.py:558-569)
+//   k_loss_finalize   scalars of nn_model.py:542-598
+//   k_lat_bwd         autograd of k_lat_fwd + coupling / entropy / KL terms
+//   k_bnb_finalize    batch sums for the BatchNorm backward
+//   k_reduce          slabs -> flat gradient buffer;  k_adam: torch.optim.Adam(W) update
+//
+// Wave reductions only (no MFMA): these tensors are [B, <=128] and HBM/L2 resident.
+#include "common.hpp"
+#include <math.h>
+
+namespace mmvae {
+
+#define HIP_LAUNCH_CHECK(what)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            set_error("%s: %s", what, hipGetErrorString(e_));                         \
+            return MMVAE_E_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+constexpr int CPL = 2;   // categories per lane: C <= 128
+
+NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h) {
+    NoiseDev n{};
+    n.mode = nz ? nz->mode : 0;
+    if (nz) {
+        n.x_mask = nz->x_mask; n.u_gumbel = nz->u_gumbel; n.u_state = nz->u_state; n.s_mask = nz->s_mask;
+        n.k0 = (uint32_t)nz->seed; n.k1 = (uint32_t)(nz->seed >> 32);
+        n.step_lo = (uint32_t)nz->offset; n.step_hi = (uint32_t)(nz->offset >> 32);
+    }
+    n.x_keep_thr = keep_threshold(h.x_drop);
+    n.s_keep_thr = keep_threshold(h.s_drop);
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics finalisation.  part: [A][nblk][2][W] (block mean, block M2 over min(32, B-32*blk) rows)
+// kind 0: BatchNorm -> mean, rstd = 1/sqrt(M2/B + eps); running_mean/var momentum update.
+// kind 1: inv_var   -> mean, iv   = 1/sqrt(M2/(B-1) + eps)
+// grid (A), 128 threads (W <= 128).  Chan's pairwise update keeps the variance exact to rounding.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_stats_finalize(const float* __restrict__ part, int nblk, int B, int W, int kind, float eps,
+                                 float momentum, float* __restrict__ mean_out, float* __restrict__ second_out,
+                                 float* __restrict__ run_mean, float* __restrict__ run_var, int64_t run_arm_stride,
+                                 int64_t* __restrict__ nbt, int nbt_index) {
+    const int arm = blockIdx.x, col = threadIdx.x;
+    if (col < W) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int b = 0; b < nblk; ++b) {
+            const float nb = (float)min(32, B - 32 * b);
+            const float* p = part + (((int64_t)arm * nblk + b) * 2) * W;
+            const float mb = p[col], m2b = p[W + col];
+            const float nn = n + nb;
+            const float dl = mb - mean;
+            mean += dl * (nb / nn);
+            m2 += m2b + dl * dl * (n * nb / nn);
+            n = nn;
+        }
+        mean_out[arm * W + col] = mean;
+        if (kind == 0) {
+            second_out[arm * W + col] = 1.0f / sqrtf(m2 / (float)B + eps);
+            if (run_mean) {
+                float* rm = run_mean + arm * run_arm_stride;
+                float* rv = run_var + arm * run_arm_stride;
+                const float var_u = m2 / (float)max(B - 1, 1);
+                rm[col] = (1.f - momentum) * rm[col] + momentum * mean;
+                rv[col] = (1.f - momentum) * rv[col] + momentum * var_u;
+            }
+        } else {
+            second_out[arm * W + col] = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
+        }
+    }
+    if (kind == 0 && nbt && threadIdx.x == 0) nbt[arm * MMVAE_N_BN + nbt_index] += 1;
+}
+
+// eval mode: statistics come from the running buffers
+__global__ void k_stats_from_running(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                     int64_t run_arm_stride, int W, float eps, float* __restrict__ mean_out,
+                                     float* __restrict__ rstd_out) {
+    const int arm = blockIdx.x, col = threadIdx.x;
+    if (col < W) {
+        mean_out[arm * W + col] = run_mean[arm * run_arm_stride + col];
+        rstd_out[arm * W + col] = 1.0f / sqrtf(run_var[arm * run_arm_stride + col] + eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct LatArgs {
+    int A, B, L, C, S;
+    float tau, temp, eps, s_drop;
+    int hard, training, eval_flag;
+    int64_t per_arm, o_wc, o_bc, o_wms, o_bms;
+    // workspace offsets
+    int64_t R5, mean5, rstd5, XLOW, CPROB, CC, YSOFT, CSMP, Y, MS, MU, LV, SS, ZIN, c_part, lat_part;
+    // backward only
+    int64_t GZIN, GMS, GZC, G5, bnb_part5, T, c_mean, c_iv;
+    float am1, beta, lam;
+};
+
+__device__ __forceinline__ float gumbel_u(const NoiseDev& nz, int arm, int B, int C, int b, int col) {
+    if (nz.mode == 0) return nz.u_gumbel[((int64_t)arm * B + b) * C + col];
+    return noise_uniform(nz, arm, STREAM_GUMBEL, (uint64_t)b * C + col);
+}
+__device__ __forceinline__ float state_u(const NoiseDev& nz, int arm, int B, int S, int b, int s) {
+    if (nz.mode == 0) return nz.u_state[((int64_t)arm * B + b) * S + s];
+    return noise_uniform(nz, arm, STREAM_STATE, (uint64_t)b * S + s);
+}
+__device__ __forceinline__ bool state_keep(const NoiseDev& nz, int arm, int B, int S, int b, int s) {
+    if (nz.mode == 0) return nz.s_mask[((int64_t)arm * B + b) * S + s] != 0;
+    return noise_keep(nz, arm, STREAM_SMASK, (uint64_t)b * S + s, nz.s_keep_thr);
+}
+
+// grid (ceil(B/32), A), 256 threads; wave w handles rows b0 + w, b0 + w + 4, ...
+__global__ __launch_bounds__(256) void k_lat_fwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
+                                                 float* __restrict__ ws) {
+    __shared__ float sh_mean[4][CPL * 64], sh_m2[4][CPL * 64], sh_cnt[4], sh_red[4][2];
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int B = a.B, L = a.L, C = a.C, S = a.S;
+    const float* P = params + (int64_t)arm * a.per_arm;
+    const float* Wc = P + a.o_wc;     // [C][L]
+    const float* bc = P + a.o_bc;
+    const float* Wms = P + a.o_wms;   // [2S][L+C]
+    const float* bms = P + a.o_bms;   // [2S]
+    const int64_t ab = (int64_t)arm * B;
+    const float eps = a.eps;
+
+    float cnt = 0.f, cm[CPL] = {0.f, 0.f}, cM2[CPL] = {0.f, 0.f};
+    float kl_acc = 0.f, ent_acc = 0.f;
+    const float mu5 = lane < L ? ws[a.mean5 + arm * L + lane] : 0.f;
+    const float rs5 = lane < L ? ws[a.rstd5 + arm * L + lane] : 0.f;
+
+    for (int row = wv; row < 32; row += 4) {
+        const int b = b0 + row;
+        if (b >= B) break;   // wave-uniform
+        // ---- x_low = BN5(R5)
+        float xl = 0.f;
+        if (lane < L) {
+            xl = (ws[a.R5 + (ab + b) * L + lane] - mu5) * rs5;
+            ws[a.XLOW + (ab + b) * L + lane] = xl;
+            ws[a.Y + (ab + b) * (L + C) + lane] = xl;
+        }
+        // ---- zc = fcc(x_low); c_prob = softmax(zc)
+        float z[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; z[t] = col < C ? bc[col] : 0.f; }
+        for (int k = 0; k < L; ++k) {
+            const float xk = __shfl(xl, k, 64);
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) z[t] += xk * Wc[col * L + k]; }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) m = fmaxf(m, z[t]);
+        m = wave_max(m);
+        float e[CPL], ssum = 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) { e[t] = (lane + 64 * t < C) ? expf(z[t] - m) : 0.f; ssum += e[t]; }
+        ssum = wave_sum(ssum);
+        float cp[CPL], cc[CPL], lc[CPL], ys[CPL], cs[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) cp[t] = e[t] / ssum;
+        // ---- c = softmax(c_prob / tau)
+        m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) m = fmaxf(m, cp[t] / a.tau);
+        m = wave_max(m);
+        ssum = 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) { e[t] = (lane + 64 * t < C) ? expf(cp[t] / a.tau - m) : 0.f; ssum += e[t]; }
+        ssum = wave_sum(ssum);
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) { cc[t] = e[t] / ssum; lc[t] = logf(cc[t] + eps); }
+        // ---- Gumbel-softmax sample
+        bool hard = a.hard != 0;
+        if (a.eval_flag) {
+            hard = true;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) ys[t] = cc[t];
+        } else {
+            float lg[CPL];
+            m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int col = lane + 64 * t;
+                lg[t] = 0.f;
+                if (col < C) {
+                    const float U = gumbel_u(nz, arm, B, C, b, col);
+                    const float g = -logf(-logf(U + eps) + eps);
+                    lg[t] = (lc[t] + g) / a.temp;
+                    m = fmaxf(m, lg[t]);
+                }
+            }
+            m = wave_max(m);
+            ssum = 0.f;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { e[t] = (lane + 64 * t < C) ? expf(lg[t] - m) : 0.f; ssum += e[t]; }
+            ssum = wave_sum(ssum);
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) ys[t] = e[t] / ssum;
+        }
+        if (hard) {
+            float mv = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) mv = fmaxf(mv, ys[t]);
+            mv = wave_max(mv);
+            int cand = 1 << 30;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C && ys[t] == mv) cand = min(cand, lane + 64 * t);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const float hv = (lane + 64 * t == cand) ? 1.f : 0.f;
+                cs[t] = (hv - ys[t]) + ys[t];   // (y_hard - y).detach() + y, nn_model.py:492
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) cs[t] = ys[t];
+        }
+        // ---- store, accumulate statistics
+        cnt += 1.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int col = lane + 64 * t;
+            if (col < C) {
+                const int64_t o = (ab + b) * C + col;
+                ws[a.CPROB + o] = cp[t];
+                ws[a.CC + o] = cc[t];
+                ws[a.YSOFT + o] = ys[t];
+                ws[a.CSMP + o] = cs[t];
+                ws[a.Y + (ab + b) * (L + C) + L + col] = cs[t];
+                ws[a.ZIN + (ab + b) * (C + S) + col] = cs[t];
+                ent_acc += cc[t] * lc[t];
+                const float dl = cc[t] - cm[t];
+                cm[t] += dl / cnt;
+                cM2[t] += dl * (cc[t] - cm[t]);
+            }
+        }
+        // ---- state head: [mu | sigma_pre] = y [Wmu; Wsigma]^T + b
+        float mso = 0.f;
+        for (int o = 0; o < 2 * S; ++o) {
+            const float* w = Wms + (int64_t)o * (L + C);
+            float p = lane < L ? xl * w[lane] : 0.f;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) p += cs[t] * w[L + col]; }
+            p = wave_sum(p) + bms[o];
+            if (lane == o) mso = p;
+        }
+        if (lane < 2 * S) ws[a.MS + (ab + b) * 2 * S + lane] = mso;
+        const float sg = __shfl(mso, (lane + S) & 63, 64);
+        if (lane < S) {
+            const float mu = mso;
+            const float var = 1.f / (1.f + expf(-sg));
+            const float lv = logf(var + eps);
+            const float sd = sqrtf(expf(lv));
+            const float U = state_u(nz, arm, B, S, b, lane);
+            const float sv = U * sd + mu;
+            float sin_ = sv;
+            if (a.training && a.s_drop > 0.f) sin_ = state_keep(nz, arm, B, S, b, lane) ? sv / (1.f - a.s_drop) : 0.f;
+            ws[a.MU + (ab + b) * S + lane] = mu;
+            ws[a.LV + (ab + b) * S + lane] = lv;
+            ws[a.SS + (ab + b) * S + lane] = sv;
+            ws[a.ZIN + (ab + b) * (C + S) + C + lane] = sin_;
+            kl_acc += 1.f + lv - mu * mu - expf(lv);
+        }
+    }
+    // ---- block partials
+    kl_acc = wave_sum(kl_acc);
+    ent_acc = wave_sum(ent_acc);
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) { sh_mean[wv][lane + 64 * t] = cm[t]; sh_m2[wv][lane + 64 * t] = cM2[t]; }
+    if (lane == 0) { sh_cnt[wv] = cnt; sh_red[wv][0] = kl_acc; sh_red[wv][1] = ent_acc; }
+    __syncthreads();
+    const int col = threadIdx.x;
+    if (col < C) {
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            const float nb = sh_cnt[w];
+            if (nb > 0.f) {
+                const float nn = n + nb, dl = sh_mean[w][col] - mean;
+                mean += dl * (nb / nn);
+                m2 += sh_m2[w][col] + dl * dl * (n * nb / nn);
+                n = nn;
+            }
+        }
+        float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
+        p[col] = mean;
+        p[C + col] = m2;
+    }
+    if (threadIdx.x == 0) {
+        float* p = ws + a.lat_part + ((int64_t)arm * gridDim.x + blk) * 2;
+        p[0] = sh_red[0][0] + sh_red[1][0] + sh_red[2][0] + sh_red[3][0];
+        p[1] = sh_red[0][1] + sh_red[1][1] + sh_red[2][1] + sh_red[3][1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// coupling: for every cell, over all arms.  u_a = log(c_a + eps) * iv_a
+//   dist += sum_{a<b} |u_a - u_b|^2 ;  l2 += sum_{a<b} |c_smp_a - c_smp_b|^2
+//   T_part[a][k] += G_a[k] * log(c_a[k] + eps),  G_a = (2 lam / B) (A u_a - sum_b u_b)
+// grid (ceil(B/32)), 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_couple(int A, int B, int C, float eps, float lam, const float* __restrict__ CCp,
+                                                const float* __restrict__ CSMPp, const float* __restrict__ civ,
+                                                float* __restrict__ couple_part, float* __restrict__ T_part) {
+    __shared__ float shT[4][MMVAE_MAX_ARMS][CPL * 64];
+    __shared__ float sh_red[4][2];
+    const int blk = blockIdx.x, b0 = blk * 32;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float iv[MMVAE_MAX_ARMS][CPL], Tacc[MMVAE_MAX_ARMS][CPL];
+#pragma unroll
+    for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int col = lane + 64 * t;
+            iv[aa][t] = (aa < A && col < C) ? civ[aa * C + col] : 0.f;
+            Tacc[aa][t] = 0.f;
+        }
+    float dist = 0.f, l2 = 0.f;
+    const float coefG = 2.f * lam / (float)B;
+    for (int row = wv; row < 32; row += 4) {
+        const int b = b0 + row;
+        if (b >= B) break;
+        float u[MMVAE_MAX_ARMS][CPL], lc[MMVAE_MAX_ARMS][CPL], cs[MMVAE_MAX_ARMS][CPL], us[CPL] = {0.f, 0.f};
+#pragma unroll
+        for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) {
+                const int col = lane + 64 * t;
+                u[aa][t] = lc[aa][t] = cs[aa][t] = 0.f;
+                if (aa < A && col < C) {
+                    const int64_t o = ((int64_t)aa * B + b) * C + col;
+                    lc[aa][t] = logf(CCp[o] + eps);
+                    u[aa][t] = lc[aa][t] * iv[aa][t];
+                    cs[aa][t] = CSMPp[o];
+                    us[t] += u[aa][t];
+                }
+            }
+#pragma unroll
+        for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa) {
+            if (aa < A) {
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const float G = coefG * ((float)A * u[aa][t] - us[t]);
+                    Tacc[aa][t] += G * lc[aa][t];
+                }
+#pragma unroll
+                for (int bb = aa + 1; bb < MMVAE_MAX_ARMS; ++bb) {
+                    if (bb < A) {
+#pragma unroll
+                        for (int t = 0; t < CPL; ++t) {
+                            const float du = u[aa][t] - u[bb][t];
+                            const float dc = cs[aa][t] - cs[bb][t];
+                            dist += du * du;
+                            l2 += dc * dc;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    dist = wave_sum(dist);
+    l2 = wave_sum(l2);
+#pragma unroll
+    for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) shT[wv][aa][lane + 64 * t] = Tacc[aa][t];
+    if (lane == 0) { sh_red[wv][0] = dist; sh_red[wv][1] = l2; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A * C; i += 256) {
+        const int aa = i / C, col = i % C;
+        T_part[((int64_t)blk * A + aa) * C + col] = shT[0][aa][col] + shT[1][aa][col] + shT[2][aa][col] + shT[3][aa][col];
+    }
+    if (threadIdx.x == 0) {
+        couple_part[blk * 2] = sh_red[0][0] + sh_red[1][0] + sh_red[2][0] + sh_red[3][0];
+        couple_part[blk * 2 + 1] = sh_red[0][1] + sh_red[1][1] + sh_red[2][1] + sh_red[3][1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// loss scalars (one block).  Sums the per-block partials in double.
+// ---------------------------------------------------------------------------------------------
+__device__ double block_sum_d(double v, double* sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int C, float beta, float lam,
+                                                       const float* __restrict__ fc11_part, int n11,
+                                                       const float* __restrict__ lat_part, int nblk,
+                                                       const float* __restrict__ couple_part,
+                                                       const float* __restrict__ T_part, float* __restrict__ T,
+                                                       float* __restrict__ out) {
+    __shared__ double sh[256];
+    const int tid = threadIdx.x;
+    const double PI2 = 6.283185307179586;
+    double sum_ind = 0.0, sum_ent = 0.0;
+    for (int a = 0; a < A; ++a) {
+        double se = 0.0, mm = 0.0, kl = 0.0, en = 0.0;
+        for (int i = tid; i < n11; i += 256) {
+            se += fc11_part[((int64_t)a * n11 + i) * 2];
+            mm += fc11_part[((int64_t)a * n11 + i) * 2 + 1];
+        }
+        for (int i = tid; i < nblk; i += 256) {
+            kl += lat_part[((int64_t)a * nblk + i) * 2];
+            en += lat_part[((int64_t)a * nblk + i) * 2 + 1];
+        }
+        se = block_sum_d(se, sh); mm = block_sum_d(mm, sh); kl = block_sum_d(kl, sh); en = block_sum_d(en, sh);
+        const double rec = 0.5 * se / B + 0.5 * (100.0 * mm / ((double)B * D));   // nn_model.py:544-546
+        const double ll = se / ((double)B * D) + B * log(PI2);                     // :542
+        const double klv = -0.5 * kl / B;                                          // :43-44
+        if (tid == 0) {
+            out[MMVAE_LOSS_REC0 + a] = (float)rec;
+            out[MMVAE_LOSS_REC0 + A + a] = (float)klv;
+            out[MMVAE_LOSS_REC0 + 2 * A + a] = (float)ll;
+        }
+        sum_ind += rec + beta * klv;
+        sum_ent += en / B;
+    }
+    double ds = 0.0, l2 = 0.0;
+    for (int i = tid; i < nblk; i += 256) { ds += couple_part[i * 2]; l2 += couple_part[i * 2 + 1]; }
+    ds = block_sum_d(ds, sh) / B;
+    l2 = block_sum_d(l2, sh) / B;
+    const double npairs = A > 1 ? A * (A - 1) / 2.0 : 1.0;
+    const double sum_c_ents = (A - 1) * sum_ent;   // every arm is in A-1 pairs
+    const double joint = lam * ds + sum_c_ents + npairs * ((C / 2.0) * log(PI2) - 0.5 * log(2.0 * lam));   // :581-586
+    const double total = (A > 1 ? A - 1 : 1) * sum_ind + joint;                                           // :587
+    if (tid == 0) {
+        out[MMVAE_LOSS_TOTAL] = (float)total;
+        out[MMVAE_LOSS_JOINT] = (float)joint;
+        out[MMVAE_LOSS_CENT] = (float)(sum_c_ents / npairs);
+        out[MMVAE_LOSS_CDIST] = (float)(ds / npairs);
+        out[MMVAE_LOSS_CL2] = (float)(l2 / npairs);
+    }
+    for (int i = tid; i < A * C; i += 256) {
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += T_part[(int64_t)b * A * C + i];
+        T[i] = (float)t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of the latent block.  grid (ceil(B/32), A), 256 threads, one wave per cell.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lat_bwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
+                                                 float* __restrict__ ws) {
+    __shared__ float sh_s[4][2][64];
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int A = a.A, B = a.B, L = a.L, C = a.C, S = a.S;
+    const float* P = params + (int64_t)arm * a.per_arm;
+    const float* Wc = P + a.o_wc;
+    const float* Wms = P + a.o_wms;
+    const int64_t ab = (int64_t)arm * B;
+    const float eps = a.eps, invB = 1.f / (float)B;
+    const float coefG = 2.f * a.lam * invB;
+
+    float Tk[CPL], cmean[CPL], ivm[CPL], ivall[MMVAE_MAX_ARMS][CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const int col = lane + 64 * t;
+        Tk[t] = col < C ? ws[a.T + arm * C + col] : 0.f;
+        cmean[t] = col < C ? ws[a.c_mean + arm * C + col] : 0.f;
+        ivm[t] = col < C ? ws[a.c_iv + arm * C + col] : 0.f;
+#pragma unroll
+        for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa) ivall[aa][t] = (aa < A && col < C) ? ws[a.c_iv + aa * C + col] : 0.f;
+    }
+    float s1 = 0.f, s2 = 0.f;   // BN5 backward sums for column `lane` (< L)
+
+    for (int row = wv; row < 32; row += 4) {
+        const int b = b0 + row;
+        if (b >= B) break;
+        // ---- state head backward (lanes < S)
+        float gms = 0.f;   // lane o < 2S: d loss / d MS[o]
+        {
+            float gmu = 0.f, gsig = 0.f;
+            if (lane < S) {
+                float gs = ws[a.GZIN + (ab + b) * (C + S) + C + lane];
+                if (a.training && a.s_drop > 0.f)
+                    gs = state_keep(nz, arm, B, S, b, lane) ? gs / (1.f - a.s_drop) : 0.f;
+                const float mu = ws[a.MU + (ab + b) * S + lane];
+                const float lv = ws[a.LV + (ab + b) * S + lane];
+                const float sg = ws[a.MS + (ab + b) * 2 * S + S + lane];
+                const float var = 1.f / (1.f + expf(-sg));
+                const float U = state_u(nz, arm, B, S, b, lane);
+                const float elv = expf(lv);
+                gmu = gs + a.am1 * a.beta * mu * invB;
+                const float glv = gs * U * 0.5f * sqrtf(elv) + a.am1 * a.beta * (-0.5f * invB) * (1.f - elv);
+                const float gvar = glv / (var + eps);
+                gsig = gvar * var * (1.f - var);
+            }
+            const float gsig_sh = __shfl(gsig, (lane - S) & 63, 64);   // lane S+s takes lane s's gsig
+            if (lane < S) gms = gmu;
+            else if (lane < 2 * S) gms = gsig_sh;
+            if (lane < 2 * S) ws[a.GMS + (ab + b) * 2 * S + lane] = gms;
+        }
+        // ---- gy = gms [Wmu; Wsigma]
+        float gxl = 0.f, gcs[CPL] = {0.f, 0.f};
+        for (int o = 0; o < 2 * S; ++o) {
+            const float go = __shfl(gms, o, 64);
+            const float* w = Wms + (int64_t)o * (L + C);
+            if (lane < L) gxl += go * w[lane];
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) gcs[t] += go * w[L + col]; }
+        }
+        // ---- gradient w.r.t. the sample, through the Gumbel softmax to c
+        float cc[CPL], lc[CPL], gc[CPL], ys[CPL], usum[CPL] = {0.f, 0.f};
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int col = lane + 64 * t;
+            cc[t] = lc[t] = gc[t] = ys[t] = 0.f;
+            if (col < C) {
+                const int64_t o = (ab + b) * C + col;
+                cc[t] = ws[a.CC + o];
+                lc[t] = logf(cc[t] + eps);
+                ys[t] = ws[a.YSOFT + o];
+                gcs[t] += ws[a.GZIN + (ab + b) * (C + S) + col];
+                dot += ys[t] * gcs[t];
+#pragma unroll
+                for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+                    if (aa < A) usum[t] += logf(ws[a.CC + ((int64_t)aa * B + b) * C + col] + eps) * ivall[aa][t];
+            }
+        }
+        if (a.eval_flag) {
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) gc[t] = gcs[t];
+        } else {
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) gc[t] = (ys[t] * (gcs[t] - dot) / a.temp) / (cc[t] + eps);
+        }
+        // ---- coupling / entropy terms on c (nn_model.py:558-569)
+        float dot2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int col = lane + 64 * t;
+            if (col < C) {
+                const float G = coefG * ((float)A * lc[t] * ivm[t] - usum[t]);
+                gc[t] += (float)(A - 1) * (lc[t] + cc[t] / (cc[t] + eps)) * invB;
+                gc[t] += G * ivm[t] / (cc[t] + eps);
+                gc[t] += (Tk[t] * (-0.5f) * ivm[t] * ivm[t] * ivm[t]) * 2.f * (cc[t] - cmean[t]) / (float)(B - 1);
+                dot2 += cc[t] * gc[t];
+            } else {
+                gc[t] = 0.f;
+            }
+        }
+        dot2 = wave_sum(dot2);
+        // ---- double softmax backward
+        float gq[CPL], cp[CPL], dot3 = 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int col = lane + 64 * t;
+            gq[t] = cc[t] * (gc[t] - dot2) / a.tau;
+            cp[t] = col < C ? ws[a.CPROB + (ab + b) * C + col] : 0.f;
+            dot3 += cp[t] * gq[t];
+        }
+        dot3 = wave_sum(dot3);
+        float gzc[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int col = lane + 64 * t;
+            gzc[t] = cp[t] * (gq[t] - dot3);
+            if (col < C) ws[a.GZC + (ab + b) * C + col] = gzc[t];
+        }
+        // ---- g5 = gy[:, :L] + gzc Wc
+        float g5 = 0.f;
+        for (int k = 0; k < L; ++k) {
+            float p = 0.f;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) p += gzc[t] * Wc[col * L + k]; }
+            p = wave_sum(p);
+            if (lane == k) g5 = gxl + p;
+        }
+        if (lane < L) {
+            ws[a.G5 + (ab + b) * L + lane] = g5;
+            s1 += g5;
+            s2 += g5 * ws[a.XLOW + (ab + b) * L + lane];
+        }
+    }
+    sh_s[wv][0][lane] = s1;
+    sh_s[wv][1][lane] = s2;
+    __syncthreads();
+    if (threadIdx.x < L) {
+        const int k = threadIdx.x;
+        float* p = ws + a.bnb_part5 + (((int64_t)arm * gridDim.x + blk) * 2) * L;
+        p[k] = sh_s[0][0][k] + sh_s[1][0][k] + sh_s[2][0][k] + sh_s[3][0][k];
+        p[L + k] = sh_s[0][1][k] + sh_s[1][1][k] + sh_s[2][1][k] + sh_s[3][1][k];
+    }
+}
+
+// sums [A][nblk][2][W] -> [A][2][W]
+__global__ void k_bnb_finalize(const float* __restrict__ part, int nblk, int W, float* __restrict__ out) {
+    const int arm = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * W; i += blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part[((int64_t)arm * nblk + b) * 2 * W + i];
+        out[(int64_t)arm * 2 * W + i] = (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// slabs -> flat gradient buffer
+// ---------------------------------------------------------------------------------------------
+struct RedDesc {
+    const float* slab; int64_t ks_stride, arm_stride; int ld, col0;
+    int rows, cols;
+    int64_t dst_off; int dst_ld;
+    float scale;
+};
+constexpr int MAX_RED = 28;
+struct RedDescs { RedDesc d[MAX_RED]; };
+
+__global__ void k_reduce(const RedDescs ds, int KSbig, int KSsmall, int nbig, float* __restrict__ grads,
+                         int64_t per_arm) {
+    const int di = blockIdx.y, arm = blockIdx.z;
+    const RedDesc& d = ds.d[di];
+    const int KS = di < nbig ? KSbig : KSsmall;
+    const int64_t n = (int64_t)d.rows * d.cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d.cols), cidx = (int)(i % d.cols);
+        const float* p = d.slab + (int64_t)arm * d.arm_stride + (int64_t)r * d.ld + d.col0 + cidx;
+        float s = 0.f;
+        for (int k = 0; k < KS; ++k) s += p[(int64_t)k * d.ks_stride];
+        grads[(int64_t)arm * per_arm + d.dst_off + (int64_t)r * d.dst_ld + cidx] = s * d.scale;
+    }
+}
+
+__global__ void k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, float lr_bc1, float inv_sqrt_bc2, float b1, float b2, float eps,
+                       float wd, float lr, int decoupled) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pi = p[i], gi = g[i];
+        if (wd != 0.f) {
+            if (decoupled) pi *= (1.f - lr * wd);
+            else gi += wd * pi;
+        }
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = pi - lr_bc1 * (mi / denom);
+    }
+}
+
+__global__ void k_dump_noise(NoiseDev nz, int A, int B, int D, int C, int S, uint8_t* x_mask, float* u_gumbel,
+                             float* u_state, uint8_t* s_mask) {
+    const int64_t nx = (int64_t)A * B * D, ng = (int64_t)A * B * C, ns = (int64_t)A * B * S;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x_mask)
+        for (int64_t i = i0; i < nx; i += stride) {
+            const int arm = (int)(i / ((int64_t)B * D));
+            x_mask[i] = noise_keep(nz, arm, STREAM_XMASK, (uint64_t)(i % ((int64_t)B * D)), nz.x_keep_thr) ? 1 : 0;
+        }
+    if (u_gumbel)
+        for (int64_t i = i0; i < ng; i += stride) {
+            const int arm = (int)(i / ((int64_t)B * C));
+            u_gumbel[i] = noise_uniform(nz, arm, STREAM_GUMBEL, (uint64_t)(i % ((int64_t)B * C)));
+        }
+    for (int64_t i = i0; i < ns; i += stride) {
+        const int arm = (int)(i / ((int64_t)B * S));
+        if (u_state) u_state[i] = noise_uniform(nz, arm, STREAM_STATE, (uint64_t)(i % ((int64_t)B * S)));
+        if (s_mask) s_mask[i] = noise_keep(nz, arm, STREAM_SMASK, (uint64_t)(i % ((int64_t)B * S)), nz.s_keep_thr) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+static LatArgs make_lat_args(const Ctx& c) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    LatArgs a{};
+    a.A = d.A; a.B = d.B; a.L = d.L; a.C = d.C; a.S = d.S;
+    a.tau = c.h.tau; a.temp = c.h.temp; a.eps = c.h.eps; a.s_drop = c.h.s_drop;
+    a.hard = c.h.hard; a.training = c.h.training; a.eval_flag = c.h.eval_flag;
+    a.per_arm = c.po.per_arm; a.o_wc = c.po.o[10]; a.o_bc = c.po.o[11]; a.o_wms = c.po.o[12]; a.o_bms = c.po.o[14];
+    a.R5 = L.R[4]; a.mean5 = L.bn_mean[4]; a.rstd5 = L.bn_rstd[4];
+    a.XLOW = L.XLOW; a.CPROB = L.CPROB; a.CC = L.CC; a.YSOFT = L.YSOFT; a.CSMP = L.CSMP; a.Y = L.Y; a.MS = L.MS;
+    a.MU = L.MU; a.LV = L.LV; a.SS = L.SS; a.ZIN = L.ZIN; a.c_part = L.c_part; a.lat_part = L.lat_part;
+    a.GZIN = L.GZIN; a.GMS = L.GMS; a.GZC = L.GZC; a.G5 = L.G[5]; a.bnb_part5 = L.bnb_part[5];
+    a.T = L.T; a.c_mean = L.c_mean; a.c_iv = L.c_iv;
+    a.am1 = (float)(d.A > 1 ? d.A - 1 : 1); a.beta = c.h.beta; a.lam = c.h.lam;
+    return a;
+}
+
+int launch_stats_finalize(const Ctx& c, int layer, float* bn_running, int64_t* nbt) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    if (layer == 5) {   // statistics of c for inv_var
+        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A), dim3(128), 0, c.stream, c.ws + L.c_part, L.nblk32, d.B, d.C, 1,
+                           c.h.eps, 0.f, c.ws + L.c_mean, c.ws + L.c_iv, (float*)nullptr, (float*)nullptr, (int64_t)0,
+                           (int64_t*)nullptr, 0);
+        HIP_LAUNCH_CHECK("k_stats_finalize<c>");
+        return 0;
+    }
+    const int W = (layer == 4) ? d.L : d.H;
+    float* rm = bn_running ? bn_running + c.po.bn_mean[layer] : nullptr;
+    float* rv = bn_running ? bn_running + c.po.bn_var[layer] : nullptr;
+    if (c.h.training) {
+        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A), dim3(128), 0, c.stream, c.ws + L.bn_part[layer], L.nblk32, d.B,
+                           W, 0, c.h.eps, c.h.bn_momentum, c.ws + L.bn_mean[layer], c.ws + L.bn_rstd[layer], rm, rv,
+                           c.po.bn_per_arm, nbt, layer);
+        HIP_LAUNCH_CHECK("k_stats_finalize");
+    } else {
+        if (!bn_running) { set_error("eval-mode forward needs bn_running"); return MMVAE_E_BADARG; }
+        hipLaunchKernelGGL(k_stats_from_running, dim3(d.A), dim3(128), 0, c.stream, rm, rv, c.po.bn_per_arm, W, c.h.eps,
+                           c.ws + L.bn_mean[layer], c.ws + L.bn_rstd[layer]);
+        HIP_LAUNCH_CHECK("k_stats_from_running");
+    }
+    return 0;
+}
+
+int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
+    LatArgs a = make_lat_args(c);
+    NoiseDev nd = make_noise_dev(nz, c.h);
+    hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblk32, c.d.A), dim3(256), 0, c.stream, a, nd, params, c.ws);
+    HIP_LAUNCH_CHECK("k_lat_fwd");
+    return 0;
+}
+
+int launch_couple(const Ctx& c) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    hipLaunchKernelGGL(k_couple, dim3(L.nblk32), dim3(256), 0, c.stream, d.A, d.B, d.C, c.h.eps, c.h.lam, c.ws + L.CC,
+                       c.ws + L.CSMP, c.ws + L.c_iv, c.ws + L.couple_part, c.ws + L.T_part);
+    HIP_LAUNCH_CHECK("k_couple");
+    return 0;
+}
+
+int launch_loss_finalize(const Ctx& c, float* loss_out) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C, c.h.beta, c.h.lam,
+                       c.ws + L.fc11_part, L.nblk64 * L.sp.ns_fc11, c.ws + L.lat_part, L.nblk32, c.ws + L.couple_part,
+                       c.ws + L.T_part, c.ws + L.T, loss_out);
+    HIP_LAUNCH_CHECK("k_loss_finalize");
+    return 0;
+}
+
+int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
+    LatArgs a = make_lat_args(c);
+    NoiseDev nd = make_noise_dev(nz, c.h);
+    hipLaunchKernelGGL(k_lat_bwd, dim3(c.lay.nblk32, c.d.A), dim3(256), 0, c.stream, a, nd, params, c.ws);
+    HIP_LAUNCH_CHECK("k_lat_bwd");
+    return 0;
+}
+
+int launch_bnb_finalize(const Ctx& c, int layer) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    const int W = (layer == 5) ? d.L : d.H;
+    hipLaunchKernelGGL(k_bnb_finalize, dim3(d.A), dim3(256), 0, c.stream, c.ws + L.bnb_part[layer], L.nblk32, W,
+                       c.ws + L.bnb_sum[layer]);
+    HIP_LAUNCH_CHECK("k_bnb_finalize");
+    return 0;
+}
+
+int launch_reduce_grads(const Ctx& c, float* grads, float gscale) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    const int A = d.A, H = d.H, D = d.D, Ld = d.L, C = d.C, S = d.S;
+    RedDescs ds{};
+    int n = 0;
+    const float xscale = (c.h.training && c.h.x_drop > 0.f) ? 1.f / (1.f - c.h.x_drop) : 1.f;
+    // big: fc1.w, fc11.w, fc11.b
+    ds.d[n++] = RedDesc{c.ws + L.dw1_slab, (int64_t)A * H * D, (int64_t)H * D, D, 0, H, D, c.po.o[0], D, gscale * xscale};
+    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * NP, (int64_t)D * NP, NP, 0, D, H, c.po.o[26], H, gscale};
+    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * NP, (int64_t)D * NP, NP, H, D, 1, c.po.o[27], 1, gscale};
+    const int nbig = n;
+    const int64_t sks = (int64_t)A * N_SMALL * NP * SMALL_LD, sarm = (int64_t)N_SMALL * NP * SMALL_LD;
+    auto small = [&](int i, int N, int K, int64_t w_off, int64_t b_off) {
+        const float* s = c.ws + L.small_slab + (int64_t)i * NP * SMALL_LD;
+        if (K > 0) ds.d[n++] = RedDesc{s, sks, sarm, SMALL_LD, 0, N, K, w_off, K, gscale};
+        ds.d[n++] = RedDesc{s, sks, sarm, SMALL_LD, K, N, 1, b_off, 1, gscale};
+    };
+    small(0, H, H, c.po.o[2], c.po.o[3]);
+    small(1, H, H, c.po.o[4], c.po.o[5]);
+    small(2, H, H, c.po.o[6], c.po.o[7]);
+    small(3, Ld, H, c.po.o[8], c.po.o[9]);
+    small(4, C, Ld, c.po.o[10], c.po.o[11]);
+    small(5, 2 * S, Ld + C, c.po.o[12], c.po.o[14]);   // fc_mu / fc_sigma are adjacent in the flat layout
+    small(6, Ld, C + S, c.po.o[16], c.po.o[17]);
+    small(7, H, Ld, c.po.o[18], c.po.o[19]);
+    small(8, H, H, c.po.o[20], c.po.o[21]);
+    small(9, H, H, c.po.o[22], c.po.o[23]);
+    small(10, H, H, c.po.o[24], c.po.o[25]);
+    small(11, H, 0, 0, c.po.o[1]);                     // fc1.b = column sums of dZ1
+    const int64_t big_elems = (int64_t)max(H, 1) * D;
+    const int gx = (int)imin64(1024, cdiv64(big_elems, 256));
+    hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, L.sp.ks_dw, L.sp.ks_small, nbig, grads,
+                       c.po.per_arm);
+    HIP_LAUNCH_CHECK("k_reduce<big>");
+    RedDescs ds2{};
+    for (int i = nbig; i < n; ++i) ds2.d[i - nbig] = ds.d[i];
+    hipLaunchKernelGGL(k_reduce, dim3(64, n - nbig, A), dim3(256), 0, c.stream, ds2, L.sp.ks_dw, L.sp.ks_small, 0, grads,
+                       c.po.per_arm);
+    HIP_LAUNCH_CHECK("k_reduce<small>");
+    return 0;
+}
+
+int launch_adam(int64_t n, float* p, const float* g, float* m, float* v, int64_t step, float lr, float b1, float b2,
+                float eps, float wd, int decoupled, hipStream_t s) {
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    const int blocks = (int)imin64(4096, cdiv64(n, 256));
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, n, p, g, m, v, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
+                       b1, b2, eps, wd, lr, decoupled);
+    HIP_LAUNCH_CHECK("k_adam");
+    return 0;
+}
+
+int launch_dump_noise(const mmvae_dims& d, const mmvae_hyper& h, const mmvae_noise* nz, uint8_t* x_mask,
+                      float* u_gumbel, float* u_state, uint8_t* s_mask, hipStream_t s) {
+    NoiseDev nd = make_noise_dev(nz, h);
+    hipLaunchKernelGGL(k_dump_noise, dim3(2048), dim3(256), 0, s, nd, d.A, d.B, d.D, d.C, d.S, x_mask, u_gumbel, u_state,
+                       s_mask);
+    HIP_LAUNCH_CHECK("k_dump_noise");
+    return 0;
+}
+
+}  // namespace mmvae

@@ -1,0 +1,200 @@
+/*
+ * mmvae.h -- C ABI of the MI355X-native cpl-mixVAE train-step engine (libmmvae_hip.so).
+ *
+ * The reference (AllenInstitute/distributed-vae) has no FFI / operator layer: its hot path is
+ * plain PyTorch.  This header is therefore the boundary the build
+ * *introduces*; each entry point names the reference code it replaces:
+ *
+ *   mmvae_forward      mixVAE_model.forward          mmidas/nn_model.py:297-368
+ *                      (encoder :263-269, double softmax :337, gumbel_softmax :430-493,
+ *                       intermed :271-275, reparameterize :413-428, decoder :277-287)
+ *   mmvae_loss         mixVAE_model.loss             mmidas/nn_model.py:495-598 (helpers :39-86)
+ *   mmvae_backward     _loss.backward()              mmidas/cpl_mixvae.py:462 (autograd of the above)
+ *   mmvae_adam_step    optimizer.step()              mmidas/cpl_mixvae.py:274,:463; train.py:144-147
+ *   mmvae_train_step   the per-batch driver          mmidas/cpl_mixvae.py:434-463
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-owned DEVICE memory (fp32 unless
+ *     noted); the library never allocates or frees device memory and keeps no global mutable
+ *     state besides the last error string (thread-local).
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, with no
+ *     hidden synchronisation.
+ *   - return value: 0 = ok, <0 = error (MMVAE_E_*); mmvae_last_error_string() explains.
+ *   - layouts are row-major.  Parameters live in ONE flat fp32 buffer, arm-major:
+ *     params[a * per_arm + offset[t]], t indexing the 28 tensors listed at mmvae_param_layout;
+ *     weights keep PyTorch's [out, in] layout so state_dict tensors are views of the buffer.
+ */
+#ifndef MMVAE_H
+#define MMVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMVAE_OK 0
+#define MMVAE_E_BADARG (-1)      /* null pointer, non-positive size ...                       */
+#define MMVAE_E_UNSUPPORTED (-2) /* shape outside the kernels' limits (see mmvae_check_dims)  */
+#define MMVAE_E_LAUNCH (-3)      /* hipLaunch / runtime failure                               */
+#define MMVAE_E_WORKSPACE (-4)   /* workspace too small                                       */
+
+#define MMVAE_MAX_ARMS 8
+#define MMVAE_N_PARAM_TENSORS 28
+#define MMVAE_N_BN 6
+
+/* A arms, B cells per batch (this rank), D genes, H fc_dim, L lowD_dim, C n_categories,
+ * S state_dim  (mixVAE_model.__init__, nn_model.py:112-134). */
+typedef struct mmvae_dims {
+    int32_t A, B, D, H, L, C, S;
+} mmvae_dims;
+
+typedef struct mmvae_hyper {
+    float tau;         /* nn_model.py:337                                   */
+    float temp;        /* Gumbel-softmax temperature, :455                  */
+    float beta;        /* KL weight, :551                                   */
+    float lam;         /* coupling weight, :581                             */
+    float eps;         /* self.eps, also the BatchNorm eps, :211            */
+    float bn_momentum; /* :211                                              */
+    float x_drop;      /* input dropout p, :165/:264                        */
+    float s_drop;      /* state dropout p, :166/:278                        */
+    int32_t hard;      /* straight-through one-hot sample, :486-493         */
+    int32_t training;  /* module.training: batch-stat BN + dropout active   */
+    int32_t eval_flag; /* forward(eval=True): no Gumbel noise, hard sample, :340-343 */
+} mmvae_hyper;
+
+/* Noise descriptor.  mode 0 = explicit buffers (parity tests; the reference's RNG stream cannot
+ * be replayed on a GPU), mode 1 = in-kernel Philox4x32-10 keyed by (seed, offset), the
+ * throughput mode.  Consumption order of the reference per arm: bernoulli[B,D] -> rand[B,C] ->
+ * rand_like[B,S] -> bernoulli[B,S] iff s_drop>0. */
+typedef struct mmvae_noise {
+    int32_t mode;
+    int32_t _pad;
+    const uint8_t *x_mask;  /* [A,B,D] keep-mask (1 = keep), used iff training && x_drop>0 */
+    const float *u_gumbel;  /* [A,B,C] U(0,1), used iff !eval_flag                         */
+    const float *u_state;   /* [A,B,S] U(0,1) (uniform, as nn_model.py:427 draws it)       */
+    const uint8_t *s_mask;  /* [A,B,S] keep-mask, used iff training && s_drop>0            */
+    uint64_t seed;
+    uint64_t offset;        /* advance by 1 per step                                       */
+} mmvae_noise;
+
+/* Where things are, in floats.  Filled by mmvae_param_layout. Tensor order t = 0..27:
+ *  0 fc1.w[H,D] 1 fc1.b 2 fc2.w[H,H] 3 fc2.b 4 fc3.w 5 fc3.b 6 fc4.w 7 fc4.b 8 fc5.w[L,H] 9 fc5.b
+ * 10 fcc.w[C,L] 11 fcc.b 12 fc_mu.w[S,L+C] 13 fc_sigma.w[S,L+C] 14 fc_mu.b 15 fc_sigma.b
+ * 16 fc6.w[L,C+S] 17 fc6.b 18 fc7.w[H,L] 19 fc7.b 20 fc8.w 21 fc8.b 22 fc9.w 23 fc9.b
+ * 24 fc10.w 25 fc10.b 26 fc11.w[D,H] 27 fc11.b */
+typedef struct mmvae_param_layout_t {
+    int64_t per_arm;                          /* floats per arm (padded)            */
+    int64_t offset[MMVAE_N_PARAM_TENSORS];    /* within one arm's segment           */
+    int64_t rows[MMVAE_N_PARAM_TENSORS];      /* out features (or length for bias)  */
+    int64_t cols[MMVAE_N_PARAM_TENSORS];      /* in features (1 for bias)           */
+    /* BatchNorm running buffers: one flat fp32 buffer, arm-major; per arm
+     * [mean_i, var_i] for batch_l1..batch_l5, batch_s (nn_model.py:208-255) */
+    int64_t bn_per_arm;
+    int64_t bn_mean_offset[MMVAE_N_BN];
+    int64_t bn_var_offset[MMVAE_N_BN];
+    int64_t bn_dim[MMVAE_N_BN];
+} mmvae_param_layout_t;
+
+/* Scalars written by mmvae_loss / mmvae_train_step into `loss_out` (device, fp32):
+ *  [0] total  [1] loss_joint  [2] mean neg-joint-entropy  [3] mean simplex distance
+ *  [4] mean l2 distance  then rec[A], kl[A], ll[A]   (the 9-tuple of nn_model.py:588-598). */
+#define MMVAE_LOSS_TOTAL 0
+#define MMVAE_LOSS_JOINT 1
+#define MMVAE_LOSS_CENT 2
+#define MMVAE_LOSS_CDIST 3
+#define MMVAE_LOSS_CL2 4
+#define MMVAE_LOSS_REC0 5
+#define MMVAE_LOSS_FLOATS(A) (5 + 3 * (A))
+
+/* Named workspace regions, for callers that return forward outputs as views and for tests that
+ * localise a failing kernel.  All per-arm arrays are [A, B, width]. */
+typedef enum mmvae_ws_id {
+    MMVAE_WS_X_LOW = 0, /* [A,B,L]  BN5 output                (forward out 3) */
+    MMVAE_WS_C_PROB,    /* [A,B,C]  softmax(fcc)              (forward out 9) */
+    MMVAE_WS_C,         /* [A,B,C]  softmax(c_prob/tau)       (forward out 4) */
+    MMVAE_WS_C_SMP,     /* [A,B,C]  Gumbel-softmax sample     (forward out 6) */
+    MMVAE_WS_S_MEAN,    /* [A,B,S]                            (forward out 7) */
+    MMVAE_WS_S_LOGVAR,  /* [A,B,S]                            (forward out 8) */
+    MMVAE_WS_S_SMP,     /* [A,B,S]                            (forward out 5) */
+    MMVAE_WS_Y_SOFT,    /* [A,B,C]  soft sample (== C_SMP unless hard) */
+    MMVAE_WS_R1, MMVAE_WS_R2, MMVAE_WS_R3, MMVAE_WS_R4, /* [A,B,H] relu(fc_i), pre-BN */
+    MMVAE_WS_R5,        /* [A,B,L] */
+    MMVAE_WS_D6,        /* [A,B,L] */
+    MMVAE_WS_D7, MMVAE_WS_D8, MMVAE_WS_D9, MMVAE_WS_D10, /* [A,B,H] */
+    MMVAE_WS_ZIN,       /* [A,B,C+S] decoder input */
+    MMVAE_WS_DZ11,      /* [A,B,D] d loss / d fc11 pre-activation */
+    MMVAE_WS_DZ1,       /* [A,B,H] d loss / d fc1 pre-activation  */
+    MMVAE_WS_GZIN,      /* [A,B,C+S] */
+    MMVAE_WS_GZC,       /* [A,B,C]  d loss / d fcc output */
+    MMVAE_WS_G5,        /* [A,B,L]  d loss / d x_low */
+    MMVAE_WS_BN_MEAN1,  /* [A,H] batch mean of R1 (then BN_MEAN1+i for layer i+1) */
+    MMVAE_WS_COUNT_
+} mmvae_ws_id;
+
+/* ---- queries (host only, no GPU needed) ------------------------------------------------- */
+int mmvae_abi_version(void);
+const char *mmvae_last_error_string(void);
+/* 0 if the kernels support these dims (H,C,L<=128, L+C,C+S<=256, A<=MMVAE_MAX_ARMS, ...). */
+int mmvae_check_dims(const mmvae_dims *d);
+int mmvae_param_layout(const mmvae_dims *d, mmvae_param_layout_t *out);
+/* bytes of caller-provided workspace that forward/loss/backward/train_step need */
+size_t mmvae_workspace_bytes(const mmvae_dims *d);
+/* offset (in floats) of a named region inside the workspace, or -1 */
+int64_t mmvae_ws_offset(const mmvae_dims *d, int ws_id);
+
+/* ---- compute (device pointers, asynchronous on stream) ----------------------------------- */
+
+/* x: [B,D] shared by all arms when x_arm_stride == 0 (cpl_mixvae.py:425 x.expand(A,-1,-1)),
+ * else arm a reads x + a*x_arm_stride (floats).
+ * bn_running: flat running mean/var (updated in place when training); num_batches_tracked:
+ * int64 [A*6] incremented when training (may be NULL).
+ * x_rec: optional [A,B,D] output (forward out 0); NULL = do not materialise.
+ * need_grad != 0 additionally stores what backward needs (dZ11, fc10-grad slabs).
+ * All other forward outputs stay in `ws` (see mmvae_ws_offset). */
+int mmvae_forward(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,
+                  const float *params, float *bn_running, int64_t *num_batches_tracked,
+                  const float *x, int64_t x_arm_stride, float *x_rec, int need_grad,
+                  void *ws, size_t ws_bytes, void *stream);
+
+/* Finishes the loss scalars from what forward left in ws.  Must follow mmvae_forward on the same
+ * ws/stream. */
+int mmvae_loss(const mmvae_dims *d, const mmvae_hyper *h, void *ws, size_t ws_bytes,
+               float *loss_out, void *stream);
+
+/* Gradient of loss_out[0] * grad_scale w.r.t. every parameter into `grads` (flat, same layout
+ * as params; fully overwritten).  Needs forward(need_grad=1) + loss on the same ws. */
+int mmvae_backward(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,
+                   const float *params, const float *x, int64_t x_arm_stride, float grad_scale,
+                   void *ws, size_t ws_bytes, float *grads, void *stream);
+
+/* torch.optim.Adam / AdamW semantics on a flat buffer of n floats. step >= 1. */
+int mmvae_adam_step(int64_t n, float *params, const float *grads, float *exp_avg,
+                    float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2,
+                    float adam_eps, float weight_decay, int decoupled, void *stream);
+
+/* forward + loss + backward (+ Adam when do_adam) for one batch: cpl_mixvae.py:434-463.
+ * With do_adam == 0 the caller all-reduces `grads` (data parallel) and then calls
+ * mmvae_adam_step itself. */
+int mmvae_train_step(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,
+                     float *params, float *bn_running, int64_t *num_batches_tracked,
+                     const float *x, int64_t x_arm_stride, void *ws, size_t ws_bytes,
+                     float *grads, float *loss_out, int do_adam, float *exp_avg,
+                     float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2,
+                     float adam_eps, float weight_decay, int decoupled, void *stream);
+
+/* Writes the noise the Philox mode (nz->mode == 1) would use, in explicit-buffer form, so a test
+ * can replay a Philox step through mode 0.  Any output pointer may be NULL. */
+int mmvae_dump_noise(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,
+                     uint8_t *x_mask, float *u_gumbel, float *u_state, uint8_t *s_mask,
+                     void *stream);
+
+/* Tuning knobs (process-wide, host side): split factors of the three large GEMMs.
+ * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW split over the batch. 0 = auto. */
+int mmvae_set_split(int which, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMVAE_H */
