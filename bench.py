@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- cells/sec through one full cpl-mixVAE train step (forward + loss + backward + Adam).
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "synthetic-10x-v1"): A=2 arms, per-GPU batch
+B=5000 cells x D=5000 genes, H=100, L=10, C=92, S=2, fp32, x_drop=0.5, in-kernel Philox noise, the batch
+already resident in HBM.  A "step" = one batch through mmvae_train_step (cpl_mixvae.py:434-463).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
+
+N>1 is plain data parallelism: each rank trains on its own shard of cells, ONE RCCL all-reduce
+(average) of the flat gradient buffer per step, Adam on every rank ("weak" scaling: per-GPU batch fixed).
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  "roofline":     dominant kernel (k_fc11_fused: x_rec GEMM + loss + dZ11 + d(d10) GEMM), algorithmic
+                  FLOPs per launch / its average duration measured with HIP events on the launch stream,
+                  against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
+  "cpu_baseline": the oracle (oracle/restatement.py, kind "port": the reference's arithmetic restated,
+                  pinned to the reference by tests/) timed on this box's host cores on the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_cell_arm(D, H, L, C, S):
+    """MAC_fwd = 2DH + 6H^2 + 2HL + LC + 2(L+C)S + (S+C)L;
+    FLOP/cell-arm = 3*2*MAC_fwd - 2DH (backward = 2x forward minus the unused dX of fc1)."""
+    mac = 2 * D * H + 6 * H * H + 2 * H * L + L * C + 2 * (L + C) * S + (S + C) * L
+    return 6 * mac - 2 * D * H
+
+
+def bytes_per_cell_arm(D, H, P, B):
+    """20 D + 80 H + 36 P / B  (fp32)."""
+    return 20 * D + 80 * H + 36 * P / B
+
+
+def synthetic_rows(n, d, seed, device):
+    """synthetic-10x-v1, generated on the device in chunks."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = (torch.rand(n, d, generator=g, device=device) < 0.2).float()
+    x *= torch.randn(n, d, generator=g, device=device).abs() * 3.0
+    return x
+
+
+def cpu_baseline(args, D, H, L, C, S, A, B):
+    """The oracle timed on the host cores (rank 0, N=1 only); bounded to ~10-30 s."""
+    from oracle import restatement as R
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # a one-GPU box exposes every host core but grants a 16-core CPU share; more threads than that
+    # only oversubscribe (measured: 256 threads -> 74 s/step)
+    cores = min(cores, args.cpu_threads)
+    torch.set_num_threads(cores)
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, n_arm=A)
+    sd = R.init_state_dict(h, 546)
+    x = R.synthetic_batch(B, D)
+    nsteps = args.cpu_steps
+    times = []
+    st = None
+    for s in range(nsteps + 1):
+        t0 = time.time()
+        noise = R.draw_noise(h, B, seed=100 + s)          # dropout mask generation is part of the
+        _, st = R.train_steps(sd, [x], h, [noise], lr=1e-3, opt_state=st)   # reference's step (bernoulli_)
+        dt = time.time() - t0
+        if s > 0:
+            times.append(dt)
+        if sum(times) > 25.0:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "cells/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} full steps of the same workload (A={A}, B={B}, D={D}) after 1 warm-up, median; "
+                      f"includes drawing the dropout masks on the host as the reference does",
+            "ms_per_step": med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--arms", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=5000)
+    ap.add_argument("--genes", type=int, default=5000)
+    ap.add_argument("--cells", type=int, default=50000, help="cells resident per GPU (batches cycle through them)")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd import _native as N
+    from distributed_vae_amd import dist as DD
+    from distributed_vae_amd.cpl_mixvae import FusedAdam
+    from distributed_vae_amd.nn_model import mixVAE_model
+
+    A, B, D = args.arms, args.batch, args.genes
+    H, L, C, S = 100, 10, 92, 2
+    torch.manual_seed(546)
+    model = mixVAE_model(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0,
+                         n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev,
+                         eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE").to(dev)
+    model.train()
+    opt = FusedAdam(model, lr=1e-3)
+    if world > 1:
+        DD.broadcast_flat(model.flat_parameters())
+    # this rank's shard of cells, resident in HBM
+    nb = max(1, args.cells // B)
+    data = synthetic_rows(nb * B, D, 546 + rank, dev)
+    batches = [data[i * B:(i + 1) * B] for i in range(nb)]
+
+    def step(i):
+        xs = batches[i % nb].expand(A, -1, -1)
+        if world > 1:
+            buf = model.fused_train_step(xs, 1.0, opt, do_adam=False)
+            DD.allreduce_mean_(model.flat_grad())
+            opt.step()
+            return buf
+        return model.fused_train_step(xs, 1.0, opt, do_adam=True)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        buf = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_last = float(buf[0])
+
+    P = 0
+    lay = N.param_layout(N.Dims(A, B, D, H, L, C, S))
+    for t in range(N.N_PARAM_TENSORS):
+        P += int(lay.rows[t]) * int(lay.cols[t])
+    fl_cell = A * flops_per_cell_arm(D, H, L, C, S)
+    by_cell = A * bytes_per_cell_arm(D, H, P, B)
+    cells_per_s = world * B * args.steps / dt
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = measure_stages(model, batches[0], A, B, D, H)
+        roof["step_flops_frac_of_fp32_mfma_peak"] = cells_per_s / world * fl_cell / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        roof["step_bytes_frac_of_hbm_peak"] = cells_per_s / world * by_cell / (PEAK_HBM_GBS * 1e9)
+
+    out = {
+        "metric": "cells/sec per train step (fwd+loss+bwd+opt)",
+        "value": cells_per_s,
+        "unit": "cells/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"cpl_mixVAE A={A} arms, synthetic-10x-v1 {args.cells} cells x {D} genes per GPU, "
+                               f"batch {B}/GPU, fp32, H=100 L=10 C=92 S=2, x_drop=0.5, Adam lr=1e-3",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "noise": "in-kernel Philox4x32-10",
+                   "flop_per_cell": fl_cell, "bytes_per_cell": by_cell, "last_loss": loss_last},
+    }
+    if roof is not None:
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, D, H, L, C, S, A, B)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+STAGES = {
+    # id: (kernel(s), algorithmic FLOPs per launch as a function of (A,B,D,H), algorithmic HBM bytes)
+    0: ("k_fc1_fwd+k_fc1_epi", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D),
+    1: ("k_fc11_fused", lambda A, B, D, H: A * 2 * 2.0 * B * D * H, lambda A, B, D, H: A * 2 * 4.0 * B * D),
+    2: ("k_gemm_tn<dW1>+<dW11>", lambda A, B, D, H: A * 2 * 2.0 * B * D * H, lambda A, B, D, H: A * 2 * 4.0 * B * D),
+}
+
+
+def measure_stages(model, x, A, B, D, H):
+    """Per-launch duration of the MFMA-bound stages, measured live with HIP events on the stream the
+    kernels are launched on (torch's current stream), each stage replayed alone on a workspace that a
+    full forward+loss+backward has prepared (mmvae_debug_stage).  The dominant one is reported as the
+    roofline object; FLOPs are the algorithmic ones of SURVEY.md 8(d) (padding H->104/128 not counted)."""
+    from distributed_vae_amd import _native as N
+
+    eng = model._engine
+    hyper = model._hyper(1.0, False)
+    noise = N.make_noise(None, 99, 1)
+    eng.forward(hyper, noise, model._flat, model._bn_flat, None, x, 0, None, True)
+    eng.loss(hyper)
+    eng.backward(hyper, noise, model._flat, x, 0, model._flat_grad)
+    stream = torch.cuda.current_stream()
+    res = {}
+    for sid, (name, fl, by) in STAGES.items():
+        for _ in range(3):
+            eng.debug_stage(sid, hyper, noise, model._flat, x, 0)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        ev0.record(stream)
+        for _ in range(reps):
+            eng.debug_stage(sid, hyper, noise, model._flat, x, 0)
+        ev1.record(stream)
+        ev1.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+        res[name] = {"avg_launch_ms": ms, "tflops": fl(A, B, D, H) / (ms * 1e-3) / 1e12,
+                     "algorithmic_GBs": by(A, B, D, H) / (ms * 1e-3) / 1e9}
+    dom = max(res, key=lambda k: res[k]["avg_launch_ms"])
+    ach = res[dom]["tflops"]
+    return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": res[dom]["avg_launch_ms"],
+            "stages": res}
+
+
+if __name__ == "__main__":
+    main()

@@ -94,9 +94,11 @@ def lib():
     L.mmvae_adam_step.argtypes = [i64, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
     L.mmvae_train_step.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp,
                                    C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
+    L.mmvae_debug_stage.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), i32, vp, vp, i64, vp,
+                                    C.c_size_t, vp, vp]
     L.mmvae_dump_noise.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, vp]
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_set_split", "mmvae_forward", "mmvae_loss",
-               "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise"):
+               "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage"):
         getattr(L, fn).restype = C.c_int
     if L.mmvae_abi_version() != 1:
         raise NativeError("libmmvae_hip.so ABI version mismatch")
@@ -191,6 +193,11 @@ class Engine:
                                      int(step), lr, b1, b2, adam_eps, wd, int(decoupled), _stream()),
               "mmvae_train_step")
         return self.loss_buf
+
+    def debug_stage(self, stage: int, hyper: Hyper, noise: Noise, params, x, x_arm_stride, grads=None):
+        check(lib().mmvae_debug_stage(C.byref(self.dims), C.byref(hyper), C.byref(noise), int(stage), _ptr(params),
+                                      _ptr(x), x_arm_stride, _ptr(self.ws), self.ws_bytes, _ptr(grads), _stream()),
+              "mmvae_debug_stage")
 
     def dump_noise(self, hyper: Hyper, noise: Noise):
         d = self.dims

@@ -1,0 +1,257 @@
+"""Drop-in for the hot path of the reference trainer ``mmidas/cpl_mixvae.py::cpl_mixVAE``.
+
+Mirrors ``__init__`` (:153-186), ``init_model`` (:193-286), ``load_model`` (:317-321) and the
+training loop of ``train`` (:323-492: per-batch driver :415-478, epoch reductions :480-492,
+checkpoints :777-788) on top of the fused HIP train step.  Out of the hot path and therefore not
+here: augmenter, pruning phase, wandb/matplotlib reporting.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _native as N
+from . import dist as D
+from .nn_model import VAEConfig, mixVAE_model  # noqa: F401
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW semantics (cpl_mixvae.py:274, train.py:144-147) as ONE HIP kernel over
+    the model's flat parameter buffer.  ``state_dict()`` is torch.optim.Adam-compatible so reference
+    checkpoints (``optimizer_state_dict``, cpl_mixvae.py:783-786) load and save unchanged."""
+
+    def __init__(self, model: mixVAE_model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 decoupled=False):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(list(model.parameters()), defaults)
+        self.model = model
+        self.decoupled = bool(decoupled)
+        self.step_count = 0
+        self.exp_avg = self.exp_avg_sq = None
+
+    def _bind(self, model=None):
+        flat = self.model.flat_parameters()
+        if self.exp_avg is None or self.exp_avg.device != flat.device or self.exp_avg.numel() != flat.numel():
+            old = (self.exp_avg, self.exp_avg_sq)
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+            if old[0] is not None and old[0].numel() == flat.numel():
+                self.exp_avg.copy_(old[0])
+                self.exp_avg_sq.copy_(old[1])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._bind()
+        self.step_count += 1
+        g = self.param_groups[0]
+        N.adam_step(self.model.flat_parameters(), self.model.flat_grad(), self.exp_avg, self.exp_avg_sq,
+                    self.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                    self.decoupled)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.flat_grad().zero_()
+
+    def _views(self, buf):
+        lay, A = self.model._layout, self.model.n_arm
+        out = {}
+        for a in range(A):
+            for t in range(N.N_PARAM_TENSORS):
+                p = self.model._param_of(t, a)
+                o = a * int(lay.per_arm) + int(lay.offset[t])
+                out[id(p)] = buf[o: o + p.numel()].view(p.shape)
+        return [out[id(p)] for p in self.model.parameters()]
+
+    def state_dict(self):
+        self._bind()
+        m, v = self._views(self.exp_avg), self._views(self.exp_avg_sq)
+        n = len(m)
+        state = {}
+        if self.step_count > 0:
+            for i in range(n):
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m[i].clone(),
+                            "exp_avg_sq": v[i].clone()}
+        groups = []
+        for g in self.param_groups:
+            gg = {k: v_ for k, v_ in g.items() if k != "params"}
+            gg["params"] = list(range(n))
+            groups.append(gg)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        self._bind()
+        m, v = self._views(self.exp_avg), self._views(self.exp_avg_sq)
+        for i, st in sd.get("state", {}).items():
+            i = int(i)
+            m[i].copy_(st["exp_avg"])
+            v[i].copy_(st["exp_avg_sq"])
+            self.step_count = int(float(st["step"]))
+        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in src:
+                    g[k] = tuple(src[k]) if k == "betas" else src[k]
+
+
+def get_device(device=None) -> torch.device:
+    """cpl_mixvae.py:110-125."""
+    if device in ("cpu", "mps"):
+        return torch.device(device)
+    if device == "cuda":
+        return torch.device("cuda")
+    if isinstance(device, int):
+        torch.cuda.set_device(device)
+        return torch.device("cuda", device)
+    if isinstance(device, torch.device):
+        return device
+    if device is None:
+        return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    return torch.device(device)
+
+
+class cpl_mixVAE:
+    def __init__(self, saving_folder="", aug_file="", device=None, eps=1e-8, save_flag=True, load_weights=True):
+        self.eps = eps
+        self.save = save_flag
+        self.folder = saving_folder
+        self.aug_file = aug_file
+        self.models = []
+        self.device = get_device(device)
+        if aug_file:
+            raise NotImplementedError("the pre-trained augmenter (cpl_mixvae.py:128-150, :422-423) is outside the "
+                                      "HIP hot path; train on raw x.expand (cpl_mixvae.py:425)")
+        self.aug_model, self.aug_param, self.netA = None, None, None
+
+    def init_model(self, n_categories, state_dim, input_dim, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.2,
+                   lr=0.001, lam=1, lam_pc=1, n_arm=2, temp=1.0, tau=0.005, beta=1.0, hard=False, variational=True,
+                   ref_prior=False, trained_model="", n_pr=0, momentum=0.01, mode="MSE"):
+        """cpl_mixvae.py:193-286."""
+        self.lowD_dim = lowD_dim
+        self.n_categories = n_categories
+        self.state_dim = state_dim
+        self.input_dim = input_dim
+        self.temp = temp
+        self.n_arm = n_arm
+        self.fc_dim = fc_dim
+        self.ref_prior = ref_prior
+        self.model = mixVAE_model(input_dim=input_dim, fc_dim=fc_dim, n_categories=n_categories,
+                                  state_dim=state_dim, lowD_dim=lowD_dim, x_drop=x_drop, s_drop=s_drop, n_arm=n_arm,
+                                  lam=lam, lam_pc=lam_pc, tau=tau, beta=beta, hard=hard, variational=variational,
+                                  device=self.device, eps=self.eps, ref_prior=ref_prior, momentum=momentum,
+                                  loss_mode=mode)
+        self.model = self.model.to(self.device)
+        self.optimizer = FusedAdam(self.model, lr=lr)
+        if len(trained_model) > 0:
+            loaded = torch.load(trained_model, map_location="cpu", weights_only=True)
+            self.model.load_state_dict(loaded["model_state_dict"])
+            self.optimizer.load_state_dict(loaded["optimizer_state_dict"])
+            self.init = False
+            self.n_pr = n_pr
+        else:
+            self.init = True
+            self.n_pr = 0
+
+    def load_model(self, trained_model):
+        """cpl_mixvae.py:317-321."""
+        loaded = torch.load(trained_model, map_location="cpu", weights_only=True)
+        self.model.load_state_dict(loaded["model_state_dict"])
+        self.current_time = time.strftime("%Y-%m-%d-%H-%M-%S")
+
+    def save_checkpoint(self, path):
+        """Checkpoint dict of cpl_mixvae.py:783-786."""
+        torch.save({"model_state_dict": self.model.state_dict(),
+                    "optimizer_state_dict": self.optimizer.state_dict()}, path)
+
+    # ---------------------------------------------------------------------------------------
+    def train_step(self, x: torch.Tensor):
+        """One batch of cpl_mixvae.py:416-463 (x -> device, x.expand over arms, zero_grad, forward,
+        loss, backward, optimizer step).  Returns the device loss vector; no host synchronisation."""
+        x = x.to(self.device, non_blocking=True)
+        xs = x.expand(self.n_arm, -1, -1)
+        if D.is_dist():
+            buf = self.model.fused_train_step(xs, self.temp, self.optimizer, do_adam=False)
+            D.allreduce_mean_(self.model.flat_grad())
+            self.optimizer.step()
+            return buf
+        return self.model.fused_train_step(xs, self.temp, self.optimizer, do_adam=True)
+
+    def train(self, train_loader, test_loader, n_epoch, n_epoch_p=0, c_p=0, c_onehot=0, min_con=0.5,
+              max_prun_it=0, rank=None, run=None, ws=1, good_enuf_consensus=0.75):
+        """Training loop of cpl_mixvae.py:397-492 (+ validation loss :665-775 and the 10-epoch
+        checkpoint :777-788).  Pruning (:996-1444) is disabled upstream and not offered."""
+        A, Dm = self.n_arm, self.input_dim
+        dev = self.device
+        if not self.init:
+            return {}
+        if self.n_arm == 1:
+            raise ZeroDivisionError("division by zero")   # nn_model.py:592-594
+        if D.is_dist():
+            D.broadcast_flat(self.model.flat_parameters())
+        hist = {"losses": [], "loss_joints": [], "loss_recs": [[] for _ in range(A)], "c_ents": [], "c_l2_dists": [],
+                "c_dists": [], "validation_loss": [], "epoch_times": []}
+        self.current_time = time.strftime("%Y-%m-%d-%H-%M-%S")
+        for e in range(n_epoch):
+            t0 = time.time()
+            self.model.train()
+            acc = torch.zeros(5 + 3 * A, dtype=torch.float32, device=dev)   # sums of the loss vector
+            nb = 0
+            for batch in train_loader:
+                x = batch[0] if isinstance(batch, (tuple, list)) else batch
+                acc += self.train_step(x)                                    # :469-475 without .item()
+                nb += 1
+            red = torch.cat([acc, torch.tensor([float(nb)], device=dev)])
+            D.allreduce_sum_(red)                                            # :480-483 folded into one
+            red = red.cpu().numpy()
+            nsteps = red[-1]
+            nws = D.dist.get_world_size() if D.is_dist() else 1
+            Bs = max(nb, 1)
+            hist["losses"].append(red[N.LOSS_TOTAL] / nsteps)                # :485
+            hist["loss_joints"].append(red[N.LOSS_JOINT] / nws / Bs)
+            hist["c_ents"].append(red[N.LOSS_CENT] / nws / Bs)
+            hist["c_l2_dists"].append(red[N.LOSS_CL2] / nws / Bs)
+            hist["c_dists"].append(red[N.LOSS_CDIST] / nsteps)
+            for a in range(A):
+                hist["loss_recs"][a].append(red[N.LOSS_REC0 + a] / Dm / nsteps)   # :475, :491
+            # validation loss (cpl_mixvae.py:665-775): eval mode, no Gumbel noise, hard sample
+            val = self.validate(test_loader) if test_loader is not None else float("nan")
+            hist["validation_loss"].append(val)
+            dt = time.time() - t0
+            hist["epoch_times"].append(dt)
+            if rank in (None, 0, dev) or not D.is_dist():
+                print(f"epoch {e} | loss: {hist['losses'][-1]:.2f} | rec: {hist['loss_recs'][0][-1]:.2f} | "
+                      f"distance: {hist['c_dists'][-1]:.2f} | l2 distance: {hist['c_l2_dists'][-1]:.2f} | "
+                      f"val: {val:.2f} | time: {dt:.2f}", flush=True)
+            if run:
+                run.log({"train/total-loss": hist["losses"][-1], "train/joint-loss": hist["loss_joints"][-1],
+                         "train/negative-joint-entropy": hist["c_ents"][-1],
+                         "train/simplex-distance": hist["c_dists"][-1], "train/l2-distance": hist["c_l2_dists"][-1],
+                         "train/time": dt, "validation/rec-loss": val})
+            if self.save and self.folder and (e > 0) and (e % 10 == 0):    # :777-788
+                os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
+                self.save_checkpoint(os.path.join(self.folder, "model", f"cpl_mixVAE_model_epoch_{e}.pth"))
+        if self.save and self.folder:
+            os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
+            self.save_checkpoint(os.path.join(self.folder, "model",
+                                              f"cpl_mixVAE_model_before_pruning_A{A}_{self.current_time}.pth"))
+        return hist
+
+    @torch.no_grad()
+    def validate(self, loader) -> float:
+        """Mean over arms and batches of rec_loss / D in eval mode (cpl_mixvae.py:700-747)."""
+        self.model.eval()
+        tot, n = 0.0, 0
+        for batch in loader:
+            x = (batch[0] if isinstance(batch, (tuple, list)) else batch).to(self.device)
+            if x.shape[0] < 2:
+                continue
+            xs = x.expand(self.n_arm, -1, -1)
+            out = self.model(xs, self.temp, 0.0, eval=True)
+            lt = self.model.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)
+            tot += float(lt[1].mean()) / self.input_dim
+            n += 1
+        self.model.train()
+        return tot / max(n, 1)

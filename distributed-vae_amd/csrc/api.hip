@@ -98,7 +98,7 @@ Layout make_layout(const mmvae_dims& d) {
         L.bnb_sum[i] = take(A * 2 * W);
     }
     L.dw1_slab = take((int64_t)L.sp.ks_dw * A * H * D);
-    L.dw11_slab = take((int64_t)L.sp.ks_dw * A * D * NP);
+    L.dw11_slab = take((int64_t)L.sp.ks_dw * A * D * DW11_LD);
     L.small_slab = take((int64_t)L.sp.ks_small * A * N_SMALL * NP * SMALL_LD);
     L.loss_scratch = take(4096);
     L.total = off;
@@ -325,6 +325,27 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
                            decoupled, c.stream);
     }
     return 0;
+}
+
+int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, int stage,
+                      const float* params, const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes,
+                      float* grads, void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (!params || !x) { set_error("null params / x"); return MMVAE_E_BADARG; }
+    if (int rc = check_noise(c, nz)) return rc;
+    switch (stage) {
+        case 0: return launch_fc1_fwd(c, nz, params, x, x_arm_stride);
+        case 1: return launch_fc11_fused(c, params, x, x_arm_stride, nullptr, 1);
+        case 2: return launch_dw_big(c, nz, x, x_arm_stride);
+        case 3: return launch_dw_small(c);
+        case 4: return launch_chain_fwd_dec(c, params);
+        case 5: return launch_chain_bwd_dec(c, params);
+        case 6: return launch_lat_fwd(c, nz, params);
+        case 7: return launch_lat_bwd(c, nz, params);
+        case 8: if (!grads) { set_error("grads is null"); return MMVAE_E_BADARG; } return launch_reduce_grads(c, grads, 1.f);
+        default: set_error("unknown stage %d", stage); return MMVAE_E_BADARG;
+    }
 }
 
 int mmvae_dump_noise(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, uint8_t* x_mask,

@@ -206,13 +206,21 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const f
         const int K = Lr.K, N = Lr.N, NP8 = rup(N, 8), KPad = rup(K, 32);
         stage_w(Ws, ld, P + Lr.w_off, N, K, NP8, KPad);
         __syncthreads();
-        f32x16 acc = zero16();
-        const bool active = wv * 32 < KPad;
-        if (active) mma_nn(acc, Gs, ld, 0, Ws, ld, wv * 32, NP8 / 8);
+        // input width K may reach 255 (fc6: K = C + S): up to 8 column tiles, two per wave
+        f32x16 accs[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int ct = wv + 4 * ti;
+            if (ct * 32 < KPad) mma_nn(accs[ti], Gs, ld, 0, Ws, ld, ct * 32, NP8 / 8);
+        }
         __syncthreads();
-        const int col = wv * 32 + (lane & 31);
         const bool last = (l + 1 == a.nlayers);
-        if (active) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int ct = wv + 4 * ti;
+            if (ct * 32 >= KPad) continue;
+            const f32x16 acc = accs[ti];
+            const int col = ct * 32 + (lane & 31);
             if (!last) {
                 const BwdLayer& Ln = a.L[l + 1];   // its N == this K
                 const float* act = Ln.act_off >= 0 ? ws + Ln.act_off + (int64_t)arm * B * K : nullptr;

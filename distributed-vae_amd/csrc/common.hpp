@@ -12,6 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int WAVE = 64;
 constexpr int ROWS32 = 32;   // row block of the small-layer / row-wise kernels
 constexpr int NP = 128;      // padded width of every narrow (<=128) dimension in MFMA tiles
+constexpr int DW11_LD = 132;  // row stride of the dW11 slab: H weights + 1 bias column, H <= 128
 constexpr int SMALL_LD = 256; // row stride of a small-layer dW slab: [N<=128][K+1<=256]
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -55,7 +56,7 @@ struct Layout {
     int64_t GZIN, GMS, GZC, G[6];  // G[5] [A,B,L] (grad wrt x_low); G[1..4] [A,B,H] grad wrt BN_i output
     int64_t bnb_part[6], bnb_sum[6];  // [A][nblk32][2][W], [A][2][W]   (index 1..5)
     int64_t dw1_slab;              // [KS][A][H][D]
-    int64_t dw11_slab;             // [KS][A][D][NP]
+    int64_t dw11_slab;             // [KS][A][D][DW11_LD]
     int64_t small_slab;            // [KS][A][N_SMALL][NP*SMALL_LD]
     int64_t loss_scratch;          // small
     int64_t total;

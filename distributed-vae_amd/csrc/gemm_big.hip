@@ -509,9 +509,9 @@ int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t x
     TnDescs t1{}, t2{};
     t1.d[0] = TnDesc{c.ws + L.DZ[1], (int64_t)d.B * d.H, d.H, d.H, x, xs, d.D, d.D, 0, use_mask, nullptr, nullptr,
                    c.ws + L.dw1_slab, (int64_t)d.H * d.D, (int64_t)d.A * d.H * d.D, d.D};
-    // [dW11 | db11][j][h] = sum_b dZ11[b][j] * [d10 | 1][b][h]   -> slab [KS][A][D][NP]
+    // [dW11 | db11][j][h] = sum_b dZ11[b][j] * [d10 | 1][b][h]   -> slab [KS][A][D][DW11_LD]
     t2.d[0] = TnDesc{c.ws + L.DZ11, (int64_t)d.B * d.D, d.D, d.D, c.ws + L.Dk[4], (int64_t)d.B * d.H, d.H, d.H, 1, 0,
-                   nullptr, nullptr, c.ws + L.dw11_slab, (int64_t)d.D * NP, (int64_t)d.A * d.D * NP, NP};
+                   nullptr, nullptr, c.ws + L.dw11_slab, (int64_t)d.D * DW11_LD, (int64_t)d.A * d.D * DW11_LD, DW11_LD};
     const int vx = ((d.D & 3) == 0) && aligned16(x) && ((xs & 3) == 0) &&
                    (nd.mode != 0 || !use_mask || ((reinterpret_cast<uintptr_t>(nd.x_mask) & 3) == 0));
     {

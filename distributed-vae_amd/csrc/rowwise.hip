@@ -45,16 +45,21 @@ NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h) {
 // statistics finalisation.  part: [A][nblk][2][W] (block mean, block M2 over min(32, B-32*blk) rows)
 // kind 0: BatchNorm -> mean, rstd = 1/sqrt(M2/B + eps); running_mean/var momentum update.
 // kind 1: inv_var   -> mean, iv   = 1/sqrt(M2/(B-1) + eps)
-// grid (A), 128 threads (W <= 128).  Chan's pairwise update keeps the variance exact to rounding.
+// Chan's pairwise update keeps the variance exact to rounding.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_stats_finalize(const float* __restrict__ part, int nblk, int B, int W, int kind, float eps,
-                                 float momentum, float* __restrict__ mean_out, float* __restrict__ second_out,
-                                 float* __restrict__ run_mean, float* __restrict__ run_var, int64_t run_arm_stride,
-                                 int64_t* __restrict__ nbt, int nbt_index) {
-    const int arm = blockIdx.x, col = threadIdx.x;
+__global__ __launch_bounds__(256) void k_stats_finalize(const float* __restrict__ part, int nblk, int B, int W,
+                                                        int kind, float eps, float momentum,
+                                                        float* __restrict__ mean_out, float* __restrict__ second_out,
+                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                        int64_t run_arm_stride, int64_t* __restrict__ nbt,
+                                                        int nbt_index) {
+    // grid (A, ceil(W/32)); thread (g, c): row-block group g = tid >> 5 handles blocks g, g+8, ...
+    __shared__ float sn[8][32], sm[8][32], s2[8][32];
+    const int arm = blockIdx.x, c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int col = blockIdx.y * 32 + c;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
     if (col < W) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int b = 0; b < nblk; ++b) {
+        for (int b = g; b < nblk; b += 8) {
             const float nb = (float)min(32, B - 32 * b);
             const float* p = part + (((int64_t)arm * nblk + b) * 2) * W;
             const float mb = p[col], m2b = p[W + col];
@@ -63,6 +68,20 @@ __global__ void k_stats_finalize(const float* __restrict__ part, int nblk, int B
             mean += dl * (nb / nn);
             m2 += m2b + dl * dl * (n * nb / nn);
             n = nn;
+        }
+    }
+    sn[g][c] = n; sm[g][c] = mean; s2[g][c] = m2;
+    __syncthreads();
+    if (g == 0 && col < W) {
+        n = 0.f; mean = 0.f; m2 = 0.f;
+        for (int k = 0; k < 8; ++k) {
+            const float nb = sn[k][c];
+            if (nb > 0.f) {
+                const float nn = n + nb, dl = sm[k][c] - mean;
+                mean += dl * (nb / nn);
+                m2 += s2[k][c] + dl * dl * (n * nb / nn);
+                n = nn;
+            }
         }
         mean_out[arm * W + col] = mean;
         if (kind == 0) {
@@ -78,7 +97,7 @@ __global__ void k_stats_finalize(const float* __restrict__ part, int nblk, int B
             second_out[arm * W + col] = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
         }
     }
-    if (kind == 0 && nbt && threadIdx.x == 0) nbt[arm * MMVAE_N_BN + nbt_index] += 1;
+    if (kind == 0 && nbt && threadIdx.x == 0 && blockIdx.y == 0) nbt[arm * MMVAE_N_BN + nbt_index] += 1;
 }
 
 // eval mode: statistics come from the running buffers
@@ -406,7 +425,6 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
                                                        const float* __restrict__ fc11_part, int n11,
                                                        const float* __restrict__ lat_part, int nblk,
                                                        const float* __restrict__ couple_part,
-                                                       const float* __restrict__ T_part, float* __restrict__ T,
                                                        float* __restrict__ out) {
     __shared__ double sh[256];
     const int tid = threadIdx.x;
@@ -448,11 +466,6 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
         out[MMVAE_LOSS_CENT] = (float)(sum_c_ents / npairs);
         out[MMVAE_LOSS_CDIST] = (float)(ds / npairs);
         out[MMVAE_LOSS_CL2] = (float)(l2 / npairs);
-    }
-    for (int i = tid; i < A * C; i += 256) {
-        double t = 0.0;
-        for (int b = 0; b < nblk; ++b) t += T_part[(int64_t)b * A * C + i];
-        T[i] = (float)t;
     }
 }
 
@@ -606,13 +619,21 @@ __global__ __launch_bounds__(256) void k_lat_bwd(const LatArgs a, NoiseDev nz, c
     }
 }
 
-// sums [A][nblk][2][W] -> [A][2][W]
-__global__ void k_bnb_finalize(const float* __restrict__ part, int nblk, int W, float* __restrict__ out) {
-    const int arm = blockIdx.x;
-    for (int i = threadIdx.x; i < 2 * W; i += blockDim.x) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part[((int64_t)arm * nblk + b) * 2 * W + i];
-        out[(int64_t)arm * 2 * W + i] = (float)s;
+// out[g][i] = sum_b part[g][b][i]  (i < n): grid (G, ceil(n/32)), 256 threads = 8 block groups x 32 columns
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int nblk, int64_t group_stride,
+                                                      int64_t blk_stride, int n, float* __restrict__ out) {
+    __shared__ double sh[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.y * 32 + c;
+    const float* p = part + (int64_t)blockIdx.x * group_stride;
+    double s = 0.0;
+    if (i < n)
+        for (int b = g; b < nblk; b += 8) s += p[(int64_t)b * blk_stride + i];
+    sh[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        for (int k = 1; k < 8; ++k) s += sh[k][c];
+        out[(int64_t)blockIdx.x * n + i] = (float)s;
     }
 }
 
@@ -707,7 +728,7 @@ int launch_stats_finalize(const Ctx& c, int layer, float* bn_running, int64_t* n
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     if (layer == 5) {   // statistics of c for inv_var
-        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A), dim3(128), 0, c.stream, c.ws + L.c_part, L.nblk32, d.B, d.C, 1,
+        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A, cdiv(d.C, 32)), dim3(256), 0, c.stream, c.ws + L.c_part, L.nblk32, d.B, d.C, 1,
                            c.h.eps, 0.f, c.ws + L.c_mean, c.ws + L.c_iv, (float*)nullptr, (float*)nullptr, (int64_t)0,
                            (int64_t*)nullptr, 0);
         HIP_LAUNCH_CHECK("k_stats_finalize<c>");
@@ -717,7 +738,7 @@ int launch_stats_finalize(const Ctx& c, int layer, float* bn_running, int64_t* n
     float* rm = bn_running ? bn_running + c.po.bn_mean[layer] : nullptr;
     float* rv = bn_running ? bn_running + c.po.bn_var[layer] : nullptr;
     if (c.h.training) {
-        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A), dim3(128), 0, c.stream, c.ws + L.bn_part[layer], L.nblk32, d.B,
+        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A, cdiv(W, 32)), dim3(256), 0, c.stream, c.ws + L.bn_part[layer], L.nblk32, d.B,
                            W, 0, c.h.eps, c.h.bn_momentum, c.ws + L.bn_mean[layer], c.ws + L.bn_rstd[layer], rm, rv,
                            c.po.bn_per_arm, nbt, layer);
         HIP_LAUNCH_CHECK("k_stats_finalize");
@@ -752,8 +773,12 @@ int launch_loss_finalize(const Ctx& c, float* loss_out) {
     const Layout& L = c.lay;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C, c.h.beta, c.h.lam,
                        c.ws + L.fc11_part, L.nblk64 * L.sp.ns_fc11, c.ws + L.lat_part, L.nblk32, c.ws + L.couple_part,
-                       c.ws + L.T_part, c.ws + L.T, loss_out);
+                       loss_out);
     HIP_LAUNCH_CHECK("k_loss_finalize");
+    // T[a][k] = sum over row blocks of T_part[blk][a][k]
+    hipLaunchKernelGGL(k_sum_partials, dim3(1, cdiv(d.A * d.C, 32)), dim3(256), 0, c.stream, c.ws + L.T_part, L.nblk32,
+                       (int64_t)0, (int64_t)d.A * d.C, d.A * d.C, c.ws + L.T);
+    HIP_LAUNCH_CHECK("k_sum_partials<T>");
     return 0;
 }
 
@@ -769,9 +794,9 @@ int launch_bnb_finalize(const Ctx& c, int layer) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int W = (layer == 5) ? d.L : d.H;
-    hipLaunchKernelGGL(k_bnb_finalize, dim3(d.A), dim3(256), 0, c.stream, c.ws + L.bnb_part[layer], L.nblk32, W,
-                       c.ws + L.bnb_sum[layer]);
-    HIP_LAUNCH_CHECK("k_bnb_finalize");
+    hipLaunchKernelGGL(k_sum_partials, dim3(d.A, cdiv(2 * W, 32)), dim3(256), 0, c.stream, c.ws + L.bnb_part[layer],
+                       L.nblk32, (int64_t)L.nblk32 * 2 * W, (int64_t)2 * W, 2 * W, c.ws + L.bnb_sum[layer]);
+    HIP_LAUNCH_CHECK("k_sum_partials<bn>");
     return 0;
 }
 
@@ -784,8 +809,8 @@ int launch_reduce_grads(const Ctx& c, float* grads, float gscale) {
     const float xscale = (c.h.training && c.h.x_drop > 0.f) ? 1.f / (1.f - c.h.x_drop) : 1.f;
     // big: fc1.w, fc11.w, fc11.b
     ds.d[n++] = RedDesc{c.ws + L.dw1_slab, (int64_t)A * H * D, (int64_t)H * D, D, 0, H, D, c.po.o[0], D, gscale * xscale};
-    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * NP, (int64_t)D * NP, NP, 0, D, H, c.po.o[26], H, gscale};
-    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * NP, (int64_t)D * NP, NP, H, D, 1, c.po.o[27], 1, gscale};
+    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * DW11_LD, (int64_t)D * DW11_LD, DW11_LD, 0, D, H, c.po.o[26], H, gscale};
+    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * DW11_LD, (int64_t)D * DW11_LD, DW11_LD, H, D, 1, c.po.o[27], 1, gscale};
     const int nbig = n;
     const int64_t sks = (int64_t)A * N_SMALL * NP * SMALL_LD, sarm = (int64_t)N_SMALL * NP * SMALL_LD;
     auto small = [&](int i, int N, int K, int64_t w_off, int64_t b_off) {

@@ -190,8 +190,18 @@ int mmvae_dump_noise(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
                      uint8_t *x_mask, float *u_gumbel, float *u_state, uint8_t *s_mask,
                      void *stream);
 
+/* Launches ONE stage of the step on an already prepared workspace (mmvae_forward(need_grad=1) +
+ * mmvae_loss [+ mmvae_backward] must have run on it): for per-kernel timing with HIP events and for
+ * rocprof runs.  Stages: 0 fc1 forward (split-K GEMM + epilogue), 1 fused fc11 (x_rec GEMM + loss +
+ * dZ11 + d(d10) GEMM), 2 dW1 and dW11 GEMMs, 3 batched small-layer dW GEMM, 4 decoder chain forward,
+ * 5 decoder chain backward, 6 latent forward, 7 latent backward, 8 gradient slab reduction (grads). */
+int mmvae_debug_stage(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz, int stage,
+                      const float *params, const float *x, int64_t x_arm_stride, void *ws,
+                      size_t ws_bytes, float *grads, void *stream);
+
 /* Tuning knobs (process-wide, host side): split factors of the three large GEMMs.
- * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW split over the batch. 0 = auto. */
+ * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW1/dW11 split over the batch,
+ * 3 = small-layer dW split over the batch.  value 0 = auto.  Changes the workspace size. */
 int mmvae_set_split(int which, int value);
 
 #ifdef __cplusplus

@@ -1,0 +1,148 @@
+"""CPU (no GPU): host logic of the drop-in boundary and the C-ABI library's exported surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import distributed_vae_amd  # noqa: F401
+from distributed_vae_amd import _native as N
+from distributed_vae_amd.cpl_mixvae import FusedAdam, cpl_mixVAE
+from distributed_vae_amd.nn_model import VAEConfig, mixVAE_model, mk_vae
+from oracle import restatement as R
+from tests import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mmvae.h")).read()
+    names = sorted(set(re.findall(r"\b(mmvae_[a-z_]+)\s*\(", hdr)))
+    assert len(names) >= 13
+    L = N.lib()
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.mmvae_abi_version() == 1
+
+
+def test_param_layout_matches_state_dict_shapes():
+    d = N.Dims(2, 5000, 5000, 100, 10, 92, 2)
+    lay = N.param_layout(d)
+    h = R.Hyper()
+    shapes = h.linear_shapes()
+    total = 0
+    for t, nm in enumerate(N.PARAM_NAMES):
+        layer, kind = nm.split(".")
+        o, i = shapes[layer]
+        if kind == "weight":
+            assert (lay.rows[t], lay.cols[t]) == (o, i), nm
+            total += o * i
+        else:
+            assert (lay.rows[t], lay.cols[t]) == (o, 1), nm
+            total += o
+        assert lay.offset[t] % 4 == 0 or t in (13, 15)
+    assert total == 1070184                                 # parameters per arm at D=5000
+    assert lay.per_arm >= total and lay.per_arm % 64 == 0
+    # the state head is one [2S, L+C] matrix for the kernels
+    assert lay.offset[13] == lay.offset[12] + 2 * 102 and lay.offset[15] == lay.offset[14] + 2
+    assert N.lib().mmvae_workspace_bytes(C.byref(d)) > 200e6
+
+
+def test_constructor_matches_reference_initialisation():
+    """Same torch seed -> same parameters as the reference constructor (fixture sd0 comes from the
+    reference's mixVAE_model.__init__, nn_model.py:184-203) and the same 46-keys-per-arm layout."""
+    for name in ["tiny_a2", "tiny_a5_hard"]:
+        g = G.load(name)
+        h = G.hyper_of(g)
+        torch.manual_seed(int(g["seed"]))
+        m = mixVAE_model(input_dim=h.input_dim, fc_dim=h.fc_dim, n_categories=h.n_categories, state_dim=h.state_dim,
+                         lowD_dim=h.lowD_dim, x_drop=0.5, s_drop=h.s_drop, n_arm=h.n_arm, lam=1, lam_pc=1, tau=0.005,
+                         beta=1.0, hard=h.hard, variational=True, device="cpu", eps=1e-8, momentum=0.01,
+                         ref_prior=False, loss_mode="MSE")
+        ref = G.state_dict_of(g)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(ref.keys())
+        assert len(sd) == 46 * h.n_arm
+        for k in ref:
+            assert torch.equal(sd[k], ref[k]), k
+        # packing into the flat buffer keeps values and makes parameters views of it
+        flat = m.flat_parameters()
+        assert m._is_packed()
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, ref[k]), k
+        assert m.fc11[h.n_arm - 1].bias.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        assert [p.shape for p in m.parameters()] == [ref[k].shape for k in R.param_keys(h)]
+
+
+def test_mk_vae_and_config_defaults():
+    cfg = VAEConfig()
+    assert (cfg.n_categories, cfg.state_dim, cfg.input_dim, cfg.fc_dim, cfg.lowD_dim) == (92, 2, 5032, 100, 10)
+    assert (cfg.tau, cfg.momentum, cfg.mode) == (0.005, 0.01, "MSE")
+    m = mk_vae(10, 2, 784, "cpu", A=5)                      # the notebook call, mmidas/_mnist.ipynb cell 3
+    assert m.n_arm == 5 and m.fcc[0].bias.shape == (10,) and m.x_dp.p == 0.5 and m.s_dp.p == 0.2
+
+
+def test_forward_without_gpu_fails_loudly():
+    m = mk_vae(7, 2, 64, "cpu", fc_dim=16, latent_dim=5)
+    x = torch.zeros(8, 64)
+    with pytest.raises(N.NativeError):
+        m(x.expand(2, -1, -1), 1.0)
+    with pytest.raises(AssertionError):
+        m([x], 1.0)                                          # len(x) == n_arm, nn_model.py:317
+
+
+def test_unsupported_paths_raise():
+    m = mk_vae(7, 2, 64, "cpu", fc_dim=16, latent_dim=5, mode="ZINB")
+    with pytest.raises(AssertionError):
+        m([torch.zeros(4, 64)] * 2, 1.0)                     # ZINB rejected, nn_model.py:315
+    with pytest.raises(NotImplementedError):
+        cpl_mixVAE(aug_file="some.pth", device="cpu")
+    with pytest.raises(NotImplementedError):
+        N.Engine(2, 32, 64, 300, 5, 7, 2, "cuda:0") if False else N.check(-2, "x")
+
+
+def test_fused_adam_state_dict_is_torch_compatible():
+    m = mk_vae(7, 2, 64, "cpu", fc_dim=16, latent_dim=5)
+    opt = FusedAdam(m, lr=2e-3)
+    opt._bind()
+    opt.step_count = 4
+    opt.exp_avg.uniform_(-1, 1)
+    opt.exp_avg_sq.uniform_(0, 1)
+    sd = opt.state_dict()
+    ref = torch.optim.Adam(m.parameters(), lr=1e-3)
+    ref.load_state_dict(sd)                                  # torch accepts the format
+    ps = list(m.parameters())
+    assert ref.param_groups[0]["lr"] == 2e-3
+    for i, p in enumerate(ps):
+        assert torch.equal(ref.state[p]["exp_avg"], sd["state"][i]["exp_avg"])
+        assert ref.state[p]["exp_avg"].shape == p.shape
+    # and back: a torch.optim.Adam state loads into FusedAdam
+    opt2 = FusedAdam(m, lr=1e-3)
+    opt2.load_state_dict(ref.state_dict())
+    assert opt2.step_count == 4
+    for a, b in zip(opt2._views(opt2.exp_avg) + opt2._views(opt2.exp_avg_sq),
+                    opt._views(opt.exp_avg) + opt._views(opt.exp_avg_sq)):
+        assert torch.equal(a, b)                             # (alignment gaps of the flat buffer excluded)
+
+
+def test_philox_host_reference_vector():
+    """Philox4x32-10 known-answer vectors (Random123 kat_vectors): the device code uses the same
+    round function; this pins the constants/rounds through a pure-Python restatement and the
+    keep-threshold convention."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+    def philox(c, k):
+        c = list(c); k = list(k)
+        for _ in range(10):
+            p0, p1 = M0 * c[0], M1 * c[2]
+            c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF,
+                 p0 & 0xFFFFFFFF]
+            k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+        return c
+
+    assert philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

@@ -21,13 +21,20 @@ def rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def diag(name, h, sd, x, noise):
+def diag(name, h, sd, x, noise, ref64=False):
     print(f"==== {name}: A={h.n_arm} B={x.shape[0]} D={h.input_dim} H={h.fc_dim} L={h.lowD_dim} C={h.n_categories} "
           f"S={h.state_dim} hard={h.hard} s_drop={h.s_drop}", flush=True)
     A = h.n_arm
     sd_ref = {k: v.clone() for k, v in sd.items()}
-    out_r, lt_r, g_r, st = R.grads_manual(sd_ref, [x] * A, h, noise)
-    _, saved = R.forward({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise, keep=True, update_running=False)
+    if ref64:   # reference in fp64: shows the HIP path's own rounding error
+        sd_ref = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        n64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in noise.items()}
+        out_r, lt_r, g_r, st = R.grads_manual(sd_ref, [x.double()] * A, h, n64)
+        _, saved = R.forward({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()},
+                             [x.double()] * A, h, n64, keep=True, update_running=False)
+    else:
+        out_r, lt_r, g_r, st = R.grads_manual(sd_ref, [x] * A, h, noise)
+        _, saved = R.forward({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise, keep=True, update_running=False)
     m = U.build_model(h, sd)
     m.train()
     out, lt, grads = U.run_step(m, x.to(U.DEV), noise)
@@ -76,6 +83,13 @@ def main():
     worst = 0.0
     for name in cases:
         try:
+            if name == "full64":
+                h = R.Hyper()
+                sd = R.init_state_dict(h, 546)
+                x = R.synthetic_batch(5000, h.input_dim)
+                noise = R.draw_noise(h, 5000, seed=7)
+                worst = max(worst, diag(name, h, sd, x, noise, ref64=True))
+                continue
             if name == "mid":
                 g = G.load("mid_a2")
                 h = G.hyper_of(g)
