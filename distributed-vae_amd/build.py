@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmvae_hip.so")
-SOURCES = ["api.hip", "gemm_big.hip", "chain.hip", "rowwise.hip"]
+SOURCES = ["api.hip", "gemm_big.hip", "gemm_fast.hip", "chain.hip", "rowwise.hip"]
 HEADERS = ["common.hpp", os.path.join("..", "..", "include", "mmvae.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc"]
 

@@ -100,6 +100,7 @@ Layout make_layout(const mmvae_dims& d) {
     L.dw1_slab = take((int64_t)L.sp.ks_dw * A * H * D);
     L.dw11_slab = take((int64_t)L.sp.ks_dw * A * D * DW11_LD);
     L.small_slab = take((int64_t)L.sp.ks_small * A * N_SMALL * NP * SMALL_LD);
+    L.xbits = take(A * B * cdiv(d.D, 32));
     L.loss_scratch = take(4096);
     L.total = off;
     return L;
@@ -160,7 +161,14 @@ static int check_noise(const Ctx& c, const mmvae_noise* nz) {
 static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
                       const float* x, int64_t xs, float* x_rec, int need_grad) {
     int rc;
-    if ((rc = launch_fc1_fwd(c, nz, params, x, xs))) return rc;
+    const bool fast = fast_path_ok(c, params, x, xs);
+    if (fast) {
+        if ((rc = launch_make_xbits(c, nz))) return rc;
+        if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
+        if ((rc = launch_fc1_epi(c, params))) return rc;
+    } else if ((rc = launch_fc1_fwd(c, nz, params, x, xs))) {
+        return rc;
+    }
     if ((rc = launch_stats_finalize(c, 0, bn_running, nbt))) return rc;
     for (int layer = 2; layer <= 5; ++layer) {
         if ((rc = launch_chain_fwd_enc(c, layer, params))) return rc;
@@ -169,8 +177,8 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     if ((rc = launch_lat_fwd(c, nz, params))) return rc;
     if ((rc = launch_stats_finalize(c, 5, nullptr, nullptr))) return rc;
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
-    if ((rc = launch_fc11_fused(c, params, x, xs, x_rec, need_grad))) return rc;
-    return 0;
+    if (fast) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
+    return launch_fc11_fused(c, params, x, xs, x_rec, need_grad);
 }
 
 static int do_loss(const Ctx& c, float* loss_out) {
@@ -190,7 +198,11 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         if ((rc = launch_bnb_finalize(c, layer - 1))) return rc;
     }
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
-    if ((rc = launch_dw_big(c, nz, x, xs))) return rc;
+    if (fast_path_ok(c, params, x, xs)) {
+        if ((rc = launch_dw_big_fast(c, x, xs))) return rc;
+    } else if ((rc = launch_dw_big(c, nz, x, xs))) {
+        return rc;
+    }
     if ((rc = launch_dw_small(c))) return rc;
     return launch_reduce_grads(c, grads, grad_scale);
 }
@@ -335,9 +347,19 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
     if (!params || !x) { set_error("null params / x"); return MMVAE_E_BADARG; }
     if (int rc = check_noise(c, nz)) return rc;
     switch (stage) {
-        case 0: return launch_fc1_fwd(c, nz, params, x, x_arm_stride);
-        case 1: return launch_fc11_fused(c, params, x, x_arm_stride, nullptr, 1);
-        case 2: return launch_dw_big(c, nz, x, x_arm_stride);
+        case 0:
+            if (fast_path_ok(c, params, x, x_arm_stride)) {
+                if (int rc = launch_fc1_fwd_fast(c, params, x, x_arm_stride)) return rc;
+                return launch_fc1_epi(c, params);
+            }
+            return launch_fc1_fwd(c, nz, params, x, x_arm_stride);
+        case 1:
+            if (fast_path_ok(c, params, x, x_arm_stride)) return launch_fc11_fast(c, params, x, x_arm_stride, nullptr, 1);
+            return launch_fc11_fused(c, params, x, x_arm_stride, nullptr, 1);
+        case 2:
+            if (fast_path_ok(c, params, x, x_arm_stride)) return launch_dw_big_fast(c, x, x_arm_stride);
+            return launch_dw_big(c, nz, x, x_arm_stride);
+        case 9: return launch_make_xbits(c, nz);
         case 3: return launch_dw_small(c);
         case 4: return launch_chain_fwd_dec(c, params);
         case 5: return launch_chain_bwd_dec(c, params);

@@ -58,6 +58,7 @@ struct Layout {
     int64_t dw1_slab;              // [KS][A][H][D]
     int64_t dw11_slab;             // [KS][A][D][DW11_LD]
     int64_t small_slab;            // [KS][A][N_SMALL][NP*SMALL_LD]
+    int64_t xbits;                 // uint32 [A][B][ceil(D/32)] dropout keep-mask, bit-packed (fast path)
     int64_t loss_scratch;          // small
     int64_t total;
 };
@@ -255,6 +256,12 @@ int launch_dw_small(const Ctx& c);
 int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale);
 int launch_adam(int64_t n, float* p, const float* g, float* m, float* v, int64_t step, float lr, float b1,
                 float b2, float eps, float wd, int decoupled, hipStream_t s);
+bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs);
+int launch_make_xbits(const Ctx& c, const mmvae_noise* nz);
+int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64_t xs);
+int launch_fc1_epi(const Ctx& c, const float* params);
+int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
+int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs);
 int launch_dump_noise(const mmvae_dims& d, const mmvae_hyper& h, const mmvae_noise* nz, uint8_t* x_mask,
                       float* u_gumbel, float* u_state, uint8_t* s_mask, hipStream_t s);
 

@@ -475,7 +475,13 @@ int launch_fc1_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, con
     hipLaunchKernelGGL(k_fc1_fwd, grid, dim3(256), 0, c.stream, x, xs, params, c.po.per_arm, c.po.o[0], nd,
                        use_mask, c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS, vec_ok);
     HIP_LAUNCH_CHECK("k_fc1_fwd");
-    const float scale = use_mask ? 1.f / (1.f - c.h.x_drop) : 1.f;
+    return launch_fc1_epi(c, params);
+}
+
+int launch_fc1_epi(const Ctx& c, const float* params) {
+    const mmvae_dims& d = c.d;
+    const int KS = c.lay.sp.ks_fc1;
+    const float scale = (c.h.training && c.h.x_drop > 0.f) ? 1.f / (1.f - c.h.x_drop) : 1.f;
     hipLaunchKernelGGL(k_fc1_epi, dim3(c.lay.nblk32, d.A), dim3(256), 0, c.stream, c.ws + c.lay.fc1_slab, params,
                        c.po.per_arm, c.po.o[1], scale, c.ws + c.lay.R[0], c.ws + c.lay.bn_part[0], d.A, d.B, d.H,
                        KS);

@@ -1,0 +1,475 @@
+// Fast paths of the three MFMA-bound stages (selected when D % 4 == 0 and H % 4 == 0 and the buffers
+// are 16-byte aligned; gemm_big.hip keeps the fully general kernels).  What differs from the general
+// kernels is the instruction stream around the MFMAs, not the arithmetic:
+//   * every global load is unconditional (clamped address + select), so hipcc issues the whole
+//     tile's loads back to back and waits once -- the general loaders branch per element and wait
+//     vmcnt(0) per load, which serialises HBM latency;
+//   * the dropout keep-mask is read from a bit-packed image built once per step (k_make_xbits)
+//     instead of a Philox evaluation per float4 in both fc1 forward and dW1;
+//   * 64x64 (fc1, dW) wave tiles: 4 accumulators per wave, 1 ds_read_b128 per 4 MFMAs.
+#include "common.hpp"
+
+namespace mmvae {
+
+#define HIP_LAUNCH_CHECK(what)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            set_error("%s: %s", what, hipGetErrorString(e_));                         \
+            return MMVAE_E_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) { return ok ? v : zero4(); }
+__device__ __forceinline__ float4 mask4(float4 v, uint32_t nib) {
+    v.x = (nib & 1u) ? v.x : 0.f;
+    v.y = (nib & 2u) ? v.y : 0.f;
+    v.z = (nib & 4u) ? v.z : 0.f;
+    v.w = (nib & 8u) ? v.w : 0.f;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// keep-mask bit image: bits[(arm*B + row) * wpr + w] bit i <-> gene 32 w + i.  One thread per word.
+// Same element -> random-word mapping as the general kernels (noise_words / explicit bytes).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_make_xbits(NoiseDev nz, int A, int B, int D, int wpr, uint32_t* __restrict__ bits) {
+    const int64_t n = (int64_t)A * B * wpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % wpr);
+        const int64_t ar = i / wpr;
+        const int row = (int)(ar % B), arm = (int)(ar / B);
+        uint32_t word = 0;
+        if (nz.mode == 0) {
+            const uint8_t* m = nz.x_mask + ((int64_t)arm * B + row) * D;
+            for (int j = 0; j < 32; ++j) {
+                const int col = 32 * w + j;
+                if (col < D && m[col]) word |= (1u << j);
+            }
+        } else if ((D & 3) == 0) {
+            for (int j = 0; j < 8; ++j) {
+                const int col = 32 * w + 4 * j;
+                if (col < D) {
+                    const u32x4 r = noise_words(nz, arm, STREAM_XMASK, (uint64_t)((int64_t)row * D + col) >> 2);
+                    const uint32_t t = nz.x_keep_thr;
+                    uint32_t nib = (r.x < t ? 1u : 0u) | (r.y < t ? 2u : 0u) | (r.z < t ? 4u : 0u) | (r.w < t ? 8u : 0u);
+                    if (t == 0xFFFFFFFFu) nib = 15u;
+                    word |= nib << (4 * j);
+                }
+            }
+        } else {
+            for (int j = 0; j < 32; ++j) {
+                const int col = 32 * w + j;
+                if (col < D && noise_keep(nz, arm, STREAM_XMASK, (uint64_t)((int64_t)row * D + col), nz.x_keep_thr))
+                    word |= (1u << j);
+            }
+        }
+        bits[i] = word;
+    }
+}
+
+// =============================================================================================
+// fc1 forward, fast: block tile 128 x 128, K tile 32, wave tile 64 x 64.  grid (ceil(B/128), KS, A)
+// =============================================================================================
+constexpr int V2_LD = 36;
+
+template <bool USE_MASK>
+__global__ __launch_bounds__(256) void k_fc1_fwd_v2(const float* __restrict__ x, int64_t x_arm_stride,
+                                                    const float* __restrict__ params, int64_t per_arm, int64_t w_off,
+                                                    const uint32_t* __restrict__ bits, int wpr,
+                                                    float* __restrict__ slab, int A, int B, int D, int H, int KS) {
+    __shared__ __attribute__((aligned(16))) float As[128 * V2_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[128 * V2_LD];
+    const int arm = blockIdx.z, ks = blockIdx.y, b0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float* xa = x + (int64_t)arm * x_arm_stride;
+    const float* W = params + (int64_t)arm * per_arm + w_off;
+    const int nkt = cdiv(D, 32);
+    const int kt0 = (int)(((int64_t)ks * nkt) / KS), kt1 = (int)(((int64_t)(ks + 1) * nkt) / KS);
+    const int r0 = tid >> 3, c4 = tid & 7;
+
+    const float* pa[4];
+    const float* pb[4];
+    const uint32_t* pm[4];
+    bool okb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = min(b0 + r0 + 32 * i, B - 1);      // rows past B recompute row B-1; never stored
+        pa[i] = xa + (int64_t)ra * D + c4 * 4;
+        pm[i] = bits + ((int64_t)arm * B + ra) * wpr;
+        const int rb = r0 + 32 * i;
+        okb[i] = rb < H;
+        pb[i] = W + (int64_t)min(rb, H - 1) * D + c4 * 4;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+
+    float4 ra4[4], rb4[4];
+    auto load_tiles = [&](int kt) {
+        const bool colok = kt * 32 + c4 * 4 < D;
+        const int koff = colok ? kt * 32 : 0;
+        uint32_t wd[4];
+        if (USE_MASK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wd[i] = pm[i][kt];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra4[i] = *reinterpret_cast<const float4*>(pa[i] + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb4[i] = *reinterpret_cast<const float4*>(pb[i] + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = sel4(colok, ra4[i]);
+            if (USE_MASK) v = mask4(v, wd[i] >> (c4 * 4));
+            ra4[i] = v;
+            rb4[i] = sel4(colok && okb[i], rb4[i]);
+        }
+    };
+    if (kt0 < kt1) load_tiles(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * V2_LD + c4 * 4]) = ra4[i];
+            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * V2_LD + c4 * 4]) = rb4[i];
+        }
+        __syncthreads();
+        if (kt + 1 < kt1) load_tiles(kt + 1);
+        const float* la = As + (wm * 64 + l31) * V2_LD + 4 * hh;
+        const float* lb = Bs + (wn * 64 + l31) * V2_LD + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4*>(la + 8 * g);
+            const float4 a1 = *reinterpret_cast<const float4*>(la + 32 * V2_LD + 8 * g);
+            const float4 q0 = *reinterpret_cast<const float4*>(lb + 8 * g);
+            const float4 q1 = *reinterpret_cast<const float4*>(lb + 32 * V2_LD + 8 * g);
+            acc[0][0] = mfma32(a0.x, q0.x, acc[0][0]); acc[0][1] = mfma32(a0.x, q1.x, acc[0][1]);
+            acc[1][0] = mfma32(a1.x, q0.x, acc[1][0]); acc[1][1] = mfma32(a1.x, q1.x, acc[1][1]);
+            acc[0][0] = mfma32(a0.y, q0.y, acc[0][0]); acc[0][1] = mfma32(a0.y, q1.y, acc[0][1]);
+            acc[1][0] = mfma32(a1.y, q0.y, acc[1][0]); acc[1][1] = mfma32(a1.y, q1.y, acc[1][1]);
+            acc[0][0] = mfma32(a0.z, q0.z, acc[0][0]); acc[0][1] = mfma32(a0.z, q1.z, acc[0][1]);
+            acc[1][0] = mfma32(a1.z, q0.z, acc[1][0]); acc[1][1] = mfma32(a1.z, q1.z, acc[1][1]);
+            acc[0][0] = mfma32(a0.w, q0.w, acc[0][0]); acc[0][1] = mfma32(a0.w, q1.w, acc[0][1]);
+            acc[1][0] = mfma32(a1.w, q0.w, acc[1][0]); acc[1][1] = mfma32(a1.w, q1.w, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    float* out = slab + (((int64_t)ks * A + arm) * B) * NP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = b0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (row < B) out[(int64_t)row * NP + wn * 64 + j * 32 + l31] = acc[i][j][r];
+            }
+}
+
+// =============================================================================================
+// TN over the batch, fast: out[m][n] = sum_b P[b][m] Q[b][n]; tile 128 x 128, 32 batch rows per step,
+// wave tile 64 x 64.  grid (tiles_m * tiles_n, KS, A).  Q may carry the keep-mask (x) or a trailing
+// ones column (bias gradient).
+// =============================================================================================
+constexpr int TN_LD = 132;
+
+template <bool QMASK, bool QONES>
+__global__ __launch_bounds__(256) void k_tn_v2(const float* __restrict__ P, int64_t p_arm, int ldp, int Mv,
+                                               const float* __restrict__ Q, int64_t q_arm, int ldq, int Nv,
+                                               const uint32_t* __restrict__ bits, int wpr, float* __restrict__ out,
+                                               int64_t out_arm, int64_t out_ks, int ldo, int B, int KS, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float Ps[32 * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Qs[32 * TN_LD];
+    const int arm = blockIdx.z, ks = blockIdx.y;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float* Pa = P + (int64_t)arm * p_arm;
+    const float* Qa = Q + (int64_t)arm * q_arm;
+    const int nbt = cdiv(B, 32);
+    const int bt0 = (int)(((int64_t)ks * nbt) / KS), bt1 = (int)(((int64_t)(ks + 1) * nbt) / KS);
+    const int rr = tid >> 5, c4 = tid & 31;
+    const int pc = m0 + c4 * 4, qc = n0 + c4 * 4;
+    const bool pok = pc < Mv, qok = qc < Nv;
+    const bool qone = QONES && (qc == Nv);
+    const int pcc = pok ? pc : 0, qcc = qok ? qc : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+    float4 rp[4], rq[4];
+    auto load_tiles = [&](int bt) {
+        uint32_t wd[4];
+        int rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = bt * 32 + rr + 8 * i;
+        if (QMASK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wd[i] = bits[((int64_t)arm * B + min(rows[i], B - 1)) * wpr + (qcc >> 5)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rp[i] = *reinterpret_cast<const float4*>(Pa + (int64_t)min(rows[i], B - 1) * ldp + pcc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rq[i] = *reinterpret_cast<const float4*>(Qa + (int64_t)min(rows[i], B - 1) * ldq + qcc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rp[i] = sel4(pok && rows[i] < B, rp[i]);      // zero P rows past the batch: their products vanish
+            float4 v = sel4(qok, rq[i]);
+            if (QMASK) v = mask4(v, wd[i] >> (qcc & 31));
+            if (qone) v.x = 1.f;
+            rq[i] = v;
+        }
+    };
+    if (bt0 < bt1) load_tiles(bt0);
+    for (int bt = bt0; bt < bt1; ++bt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&Ps[(rr + 8 * i) * TN_LD + c4 * 4]) = rp[i];
+            *reinterpret_cast<float4*>(&Qs[(rr + 8 * i) * TN_LD + c4 * 4]) = rq[i];
+        }
+        __syncthreads();
+        if (bt + 1 < bt1) load_tiles(bt + 1);
+        const float* la = Ps + hh * TN_LD + wm * 64 + l31;
+        const float* lb = Qs + hh * TN_LD + wn * 64 + l31;
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float a0 = la[2 * s * TN_LD], a1 = la[2 * s * TN_LD + 32];
+            const float q0 = lb[2 * s * TN_LD], q1 = lb[2 * s * TN_LD + 32];
+            acc[0][0] = mfma32(a0, q0, acc[0][0]);
+            acc[0][1] = mfma32(a0, q1, acc[0][1]);
+            acc[1][0] = mfma32(a1, q0, acc[1][0]);
+            acc[1][1] = mfma32(a1, q1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    float* o = out + (int64_t)ks * out_ks + (int64_t)arm * out_arm;
+    const int ncols = Nv + (QONES ? 1 : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (m < Mv && n < ncols) o[(int64_t)m * ldo + n] = acc[i][j][r];
+            }
+}
+
+// =============================================================================================
+// fused fc11, fast.  Same tiling as k_fc11_fused (64 cells x 64 genes per step, waves 2 x 2), with the
+// next weight tile prefetched into registers and this tile's x values requested before the first
+// GEMM, so HBM / L2 latency hides under the MFMAs.
+// =============================================================================================
+constexpr int F11_LDZ2 = 68;
+
+__global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d10, const float* __restrict__ params,
+                                                 int64_t per_arm, int64_t w_off, int64_t b_off,
+                                                 const float* __restrict__ x, int64_t x_arm_stride,
+                                                 float* __restrict__ x_rec, float* __restrict__ dz11,
+                                                 float* __restrict__ gd10_slab, float* __restrict__ part, float coef,
+                                                 int need_grad, int A, int B, int D, int H, int NS, int ldk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ds = smem;                 // [64][ldk]
+    float* Ws = Ds + 64 * ldk;        // [64][ldk]
+    float* Zs = Ws + 64 * ldk;        // [64][68]
+    float* red = Zs + 64 * F11_LDZ2;  // [8]
+    const int arm = blockIdx.z, ns = blockIdx.y, b0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31;
+    const int KP = rup(H, 8), nc4 = KP / 4, hc4 = H / 4;
+    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
+    const float* bias = params + (int64_t)arm * per_arm + b_off;
+    const float* xa = x + (int64_t)arm * x_arm_stride;
+    const float* d10a = d10 + (int64_t)arm * B * H;
+    const int srow = tid >> 2, spart = tid & 3;     // staging: 4 threads per row, float4 chunks spart + 4 i
+
+    {   // d10 tile (rows past B: zero)
+        const int row = b0 + srow;
+        const float* p = d10a + (int64_t)min(row, B - 1) * H;
+        for (int c = spart; c < nc4; c += 4) {
+            const bool ok = (row < B) && (c < hc4);
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? c * 4 : 0));
+            *reinterpret_cast<float4*>(&Ds[srow * ldk + c * 4]) = sel4(ok, v);
+        }
+    }
+    const int ntile = cdiv(D, 64);
+    const int t0 = (int)(((int64_t)ns * ntile) / NS), t1 = (int)(((int64_t)(ns + 1) * ntile) / NS);
+    constexpr int WR = 8;                        // up to 32 float4 chunks per row: H <= 128
+    float4 wreg[WR];
+    auto prefetch_w = [&](int t) {
+        const int j = t * 64 + srow;
+        const float* p = W + (int64_t)min(j, D - 1) * H;
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int c = spart + 4 * i;
+            const bool ok = (j < D) && (c < hc4);
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? c * 4 : 0));
+            wreg[i] = sel4(ok, v);
+        }
+    };
+    f32x16 g0 = zero16(), g1 = zero16();
+    float se = 0.f, mism = 0.f;
+    if (t0 < t1) prefetch_w(t0);
+    for (int t = t0; t < t1; ++t) {
+        const int j0 = t * 64;
+        __syncthreads();                           // previous step's readers of Ws / Zs are done
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int c = spart + 4 * i;
+            if (c < nc4) *reinterpret_cast<float4*>(&Ws[srow * ldk + c * 4]) = wreg[i];
+        }
+        __syncthreads();
+        // request this step's x values (C layout of the 32x32 tile of this wave) and the next W tile
+        const int col = j0 + wn * 32 + l31;
+        const int colc = min(col, D - 1);
+        float xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(b0 + wm * 32 + acc_row(r, lane), B - 1);
+            xv[r] = xa[(int64_t)row * D + colc];
+        }
+        const float bj = bias[colc];
+        if (t + 1 < t1) prefetch_w(t + 1);
+        f32x16 z = zero16();
+        mma_nt(z, Ds, ldk, wm * 32, Ws, ldk, wn * 32, KP / 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = wm * 32 + acc_row(r, lane);
+            const int row = b0 + lrow;
+            const bool ok = (row < B) && (col < D);
+            const float xr = fmaxf(z[r] + bj, 0.f);
+            const float e = xr - xv[r];
+            const float dzv = (ok && xr > 0.f) ? coef * e : 0.f;
+            if (ok) {
+                se += e * e;
+                mism += ((xr > 0.1f) != (xv[r] > 0.1f)) ? 1.f : 0.f;
+                if (x_rec) x_rec[((int64_t)arm * B + row) * D + col] = xr;
+                if (need_grad) dz11[((int64_t)arm * B + row) * D + col] = dzv;
+            }
+            Zs[lrow * F11_LDZ2 + wn * 32 + l31] = dzv;
+        }
+        if (need_grad) {
+            __syncthreads();
+            mma_nn(g0, Zs, F11_LDZ2, wm * 32, Ws, ldk, wn * 64, 8);
+            if (wn * 64 + 32 < H) mma_nn(g1, Zs, F11_LDZ2, wm * 32, Ws, ldk, wn * 64 + 32, 8);
+        }
+    }
+    if (need_grad) {
+        float* o = gd10_slab + (((int64_t)ns * A + arm) * B) * H;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = b0 + wm * 32 + acc_row(r, lane);
+            const int c0 = wn * 64 + l31;
+            if (row < B) {
+                if (c0 < H) o[(int64_t)row * H + c0] = g0[r];
+                if (c0 + 32 < H) o[(int64_t)row * H + c0 + 32] = g1[r];
+            }
+        }
+    }
+    se = wave_sum(se);
+    mism = wave_sum(mism);
+    __syncthreads();
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mism; }
+    __syncthreads();
+    if (tid == 0) {
+        float* p = part + (((int64_t)arm * gridDim.x + blockIdx.x) * NS + ns) * 2;
+        p[0] = red[0] + red[2] + red[4] + red[6];
+        p[1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs) {
+    const mmvae_dims& d = c.d;
+    return (d.D & 3) == 0 && (d.H & 3) == 0 && al16(params) && al16(x) && (xs & 3) == 0 && d.H >= 4;
+}
+
+int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
+    if (!(c.h.training && c.h.x_drop > 0.f)) return 0;
+    const mmvae_dims& d = c.d;
+    NoiseDev nd = make_noise_dev(nz, c.h);
+    const int wpr = cdiv(d.D, 32);
+    const int64_t n = (int64_t)d.A * d.B * wpr;
+    const int blocks = (int)imin64(4096, cdiv64(n, 256));
+    hipLaunchKernelGGL(k_make_xbits, dim3(blocks), dim3(256), 0, c.stream, nd, d.A, d.B, d.D, wpr,
+                       reinterpret_cast<uint32_t*>(c.ws + c.lay.xbits));
+    HIP_LAUNCH_CHECK("k_make_xbits");
+    return 0;
+}
+
+int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64_t xs) {
+    const mmvae_dims& d = c.d;
+    const bool use_mask = c.h.training && c.h.x_drop > 0.f;
+    const int KS = c.lay.sp.ks_fc1;
+    dim3 grid(cdiv(d.B, 128), KS, d.A);
+    const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits);
+    if (use_mask)
+        hipLaunchKernelGGL((k_fc1_fwd_v2<true>), grid, dim3(256), 0, c.stream, x, xs, params, c.po.per_arm, c.po.o[0],
+                           bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS);
+    else
+        hipLaunchKernelGGL((k_fc1_fwd_v2<false>), grid, dim3(256), 0, c.stream, x, xs, params, c.po.per_arm,
+                           c.po.o[0], bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS);
+    HIP_LAUNCH_CHECK("k_fc1_fwd_v2");
+    return 0;
+}
+
+int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad) {
+    const mmvae_dims& d = c.d;
+    const int ldk = rup(d.H, 8) + 4;
+    const size_t shm = (size_t)(64 * ldk * 2 + 64 * F11_LDZ2 + 8) * sizeof(float);
+    const float coef = (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B;
+    const int NS = c.lay.sp.ns_fc11;
+    hipLaunchKernelGGL(k_fc11_v2, dim3(c.lay.nblk64, NS, d.A), dim3(256), shm, c.stream, c.ws + c.lay.Dk[4], params,
+                       c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + c.lay.DZ11, c.ws + c.lay.GD10_slab,
+                       c.ws + c.lay.fc11_part, coef, need_grad, d.A, d.B, d.D, d.H, NS, ldk);
+    HIP_LAUNCH_CHECK("k_fc11_v2");
+    return 0;
+}
+
+int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    const bool use_mask = c.h.training && c.h.x_drop > 0.f;
+    const int KS = L.sp.ks_dw;
+    const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + L.xbits);
+    const int wpr = cdiv(d.D, 32);
+    {   // dW1[h][d] = sum_b dZ1[b][h] x~[b][d]   -> slab [KS][A][H][D]
+        const int tiles_n = cdiv(d.D, 128);
+        dim3 grid(cdiv(d.H, 128) * tiles_n, KS, d.A);
+        if (use_mask)
+            hipLaunchKernelGGL((k_tn_v2<true, false>), grid, dim3(256), 0, c.stream, c.ws + L.DZ[1],
+                               (int64_t)d.B * d.H, d.H, d.H, x, xs, d.D, d.D, bits, wpr, c.ws + L.dw1_slab,
+                               (int64_t)d.H * d.D, (int64_t)d.A * d.H * d.D, d.D, d.B, KS, tiles_n);
+        else
+            hipLaunchKernelGGL((k_tn_v2<false, false>), grid, dim3(256), 0, c.stream, c.ws + L.DZ[1],
+                               (int64_t)d.B * d.H, d.H, d.H, x, xs, d.D, d.D, bits, wpr, c.ws + L.dw1_slab,
+                               (int64_t)d.H * d.D, (int64_t)d.A * d.H * d.D, d.D, d.B, KS, tiles_n);
+        HIP_LAUNCH_CHECK("k_tn_v2<dW1>");
+    }
+    {   // [dW11 | db11][j][h] = sum_b dZ11[b][j] [d10 | 1][b][h]   -> slab [KS][A][D][DW11_LD]
+        const int tiles_n = cdiv(d.H + 1, 128);
+        dim3 grid(cdiv(d.D, 128) * tiles_n, KS, d.A);
+        hipLaunchKernelGGL((k_tn_v2<false, true>), grid, dim3(256), 0, c.stream, c.ws + L.DZ11, (int64_t)d.B * d.D,
+                           d.D, d.D, c.ws + L.Dk[4], (int64_t)d.B * d.H, d.H, d.H, bits, wpr, c.ws + L.dw11_slab,
+                           (int64_t)d.D * DW11_LD, (int64_t)d.A * d.D * DW11_LD, DW11_LD, d.B, KS, tiles_n);
+        HIP_LAUNCH_CHECK("k_tn_v2<dW11>");
+    }
+    return 0;
+}
+
+}  // namespace mmvae
