@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmmvae_hip.so")
+LIB_PATH = os.environ.get("MMVAE_LIB") or os.path.join(HERE, "libmmvae_hip.so")   # env override: A/B timing of builds
 
 N_PARAM_TENSORS = 28
 N_BN = 6

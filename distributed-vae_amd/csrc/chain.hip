@@ -35,26 +35,30 @@ struct ChainFwdArgs {
     int64_t per_arm;
 };
 
-// stage W [N][K] (global, row-major) into LDS rows [0, rows_pad) x cols [0, cols_pad), zero padded
+// stage W [N][K] (global, row-major) into LDS rows [0, rows_pad) x cols [0, cols_pad), zero padded.
+// 8 threads per row (128-B segments), two rows x four chunks in flight per thread, no per-element
+// branches: all loads of a pass issue before the first LDS store waits.
 __device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restrict__ W, int N, int K,
                                         int rows_pad, int cols_pad) {
-    const int c4n = cols_pad / 4;
+    const int c4n = cols_pad >> 2;
     const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
-    for (int idx = threadIdx.x; idx < rows_pad * c4n; idx += blockDim.x) {
-        const int row = idx / c4n, col = (idx % c4n) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < N) {
-            const float* p = W + (int64_t)row * K + col;
-            if (vec && col + 3 < K) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                if (col < K) v.x = p[0];
-                if (col + 1 < K) v.y = p[1];
-                if (col + 2 < K) v.z = p[2];
-                if (col + 3 < K) v.w = p[3];
-            }
+    const int part = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    for (int cb = 0; cb < c4n; cb += 32) {
+        for (int row = r0; row < rows_pad; row += 64) {
+            float4 v[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[u][j] = ldg4_bf(W, K, row + 32 * u, (cb + part + 8 * j) * 4, N, K, vec);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = cb + part + 8 * j, rr = row + 32 * u;
+                    if (c < c4n && rr < rows_pad) *reinterpret_cast<float4*>(&Ws[rr * ld + c * 4]) = v[u][j];
+                }
         }
-        *reinterpret_cast<float4*>(&Ws[row * ld + col]) = v;
     }
 }
 
@@ -72,17 +76,34 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const f
     // ---- input tile (optionally BatchNorm-normalised), zero padded to a multiple of 8 columns
     {
         const float* X = ws + a.x_off + (int64_t)arm * B * a.K0;
-        const float* mu = a.bn_mean_off >= 0 ? ws + a.bn_mean_off + (int64_t)arm * a.K0 : nullptr;
-        const float* rs = a.bn_rstd_off >= 0 ? ws + a.bn_rstd_off + (int64_t)arm * a.K0 : nullptr;
-        const int kp = rup(a.K0, 8);
-        for (int idx = tid; idx < 32 * kp; idx += 256) {
-            const int row = idx / kp, col = idx % kp;
-            float v = 0.f;
-            if (row < nvalid && col < a.K0) {
-                v = X[(int64_t)(b0 + row) * a.K0 + col];
-                if (mu) v = (v - mu[col]) * rs[col];
+        const bool bn = a.bn_mean_off >= 0;
+        const float* mu = bn ? ws + a.bn_mean_off + (int64_t)arm * a.K0 : X;
+        const float* rs = bn ? ws + a.bn_rstd_off + (int64_t)arm * a.K0 : X;
+        const int c4n = rup(a.K0, 8) >> 2;
+        const bool vec = (a.K0 & 3) == 0;    // workspace regions are 256-B aligned, widths multiples of 4
+        const int part = tid & 7, row = tid >> 3;
+        for (int cb = 0; cb < c4n; cb += 32) {
+            float4 v[4], m4[4], r4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = (cb + part + 8 * j) * 4;
+                v[j] = ldg4_bf(X, a.K0, b0 + row, col, B, a.K0, vec);
+                m4[j] = ldg4_bf(mu, 0, 0, col, 1, a.K0, vec);
+                r4[j] = ldg4_bf(rs, 0, 0, col, 1, a.K0, vec);
             }
-            Xs[row * ld + col] = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = cb + part + 8 * j;
+                float4 o = v[j];
+                if (bn) {   // padded columns: (0 - 0) * 0 = 0; rows past the batch must stay zero
+                    const bool rok = b0 + row < B;
+                    o.x = rok ? (o.x - m4[j].x) * r4[j].x : 0.f;
+                    o.y = rok ? (o.y - m4[j].y) * r4[j].y : 0.f;
+                    o.z = rok ? (o.z - m4[j].z) * r4[j].z : 0.f;
+                    o.w = rok ? (o.w - m4[j].w) * r4[j].w : 0.f;
+                }
+                if (c < c4n) *reinterpret_cast<float4*>(&Xs[row * ld + c * 4]) = o;
+            }
         }
     }
     for (int l = 0; l < a.nlayers; ++l) {
@@ -176,29 +197,55 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const f
     // ---- prologue: dZ of the first (= last forward) layer
     {
         const BwdLayer& L0 = a.L[0];
-        const int N = L0.N, np = rup(N, 8);
-        const float* act = L0.act_off >= 0 ? ws + L0.act_off + (int64_t)arm * B * N : nullptr;
+        const int N = L0.N, c4n = rup(N, 8) >> 2;
+        const bool has_act = L0.act_off >= 0, bnb = a.bnb_sum_off >= 0;
+        const float* G = ws + a.g_off + (int64_t)arm * B * N;
+        const float* act = has_act ? ws + L0.act_off + (int64_t)arm * B * N : G;
         float* dz = ws + L0.dz_off + (int64_t)arm * B * N;
-        const float* s1 = a.bnb_sum_off >= 0 ? ws + a.bnb_sum_off + (int64_t)arm * 2 * N : nullptr;
-        const float* mu = a.bnb_sum_off >= 0 ? ws + a.bn_mean_off + (int64_t)arm * N : nullptr;
-        const float* rs = a.bnb_sum_off >= 0 ? ws + a.bn_rstd_off + (int64_t)arm * N : nullptr;
+        const float* s1 = bnb ? ws + a.bnb_sum_off + (int64_t)arm * 2 * N : G;
+        const float* mu = bnb ? ws + a.bn_mean_off + (int64_t)arm * N : G;
+        const float* rs = bnb ? ws + a.bn_rstd_off + (int64_t)arm * N : G;
         const float invB = 1.f / (float)B;
-        for (int idx = tid; idx < 32 * np; idx += 256) {
-            const int row = idx / np, col = idx % np;
-            float v = 0.f;
-            if (row < nvalid && col < N) {
-                const int64_t e = (int64_t)(b0 + row) * N + col;
-                float g = 0.f;
-                for (int s = 0; s < a.nslab; ++s) g += ws[a.g_off + (int64_t)s * a.slab_stride + (int64_t)arm * B * N + e];
-                const float av = act ? act[e] : 1.f;
-                if (s1) {
-                    const float xh = (av - mu[col]) * rs[col];
-                    g = rs[col] * (g - s1[col] * invB - xh * (s1[N + col] * invB));
+        const bool vec = (N & 3) == 0;
+        const int part = tid & 7, row = tid >> 3;
+        const bool rok = row < nvalid;
+        for (int cb = 0; cb < c4n; cb += 32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = cb + part + 8 * j, col = c * 4;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int sl = 0; sl < a.nslab; ++sl) {
+                    const float4 t = ldg4_bf(G + (int64_t)sl * a.slab_stride, N, b0 + row, col, B, N, vec);
+                    g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
                 }
-                v = (!act || av > 0.f) ? g : 0.f;
-                dz[e] = v;
+                const float4 av = ldg4_bf(act, N, b0 + row, col, B, N, vec);
+                if (bnb) {
+                    const float4 m1 = ldg4_bf(s1, 0, 0, col, 1, N, vec), m2 = ldg4_bf(s1 + N, 0, 0, col, 1, N, vec);
+                    const float4 mm = ldg4_bf(mu, 0, 0, col, 1, N, vec), rr = ldg4_bf(rs, 0, 0, col, 1, N, vec);
+                    g.x = rr.x * (g.x - m1.x * invB - ((av.x - mm.x) * rr.x) * (m2.x * invB));
+                    g.y = rr.y * (g.y - m1.y * invB - ((av.y - mm.y) * rr.y) * (m2.y * invB));
+                    g.z = rr.z * (g.z - m1.z * invB - ((av.z - mm.z) * rr.z) * (m2.z * invB));
+                    g.w = rr.w * (g.w - m1.w * invB - ((av.w - mm.w) * rr.w) * (m2.w * invB));
+                }
+                float4 v;
+                v.x = (rok && col < N && (!has_act || av.x > 0.f)) ? g.x : 0.f;
+                v.y = (rok && col + 1 < N && (!has_act || av.y > 0.f)) ? g.y : 0.f;
+                v.z = (rok && col + 2 < N && (!has_act || av.z > 0.f)) ? g.z : 0.f;
+                v.w = (rok && col + 3 < N && (!has_act || av.w > 0.f)) ? g.w : 0.f;
+                if (c < c4n) {
+                    *reinterpret_cast<float4*>(&Gs[row * ld + col]) = v;
+                    if (rok) {
+                        float* o = dz + (int64_t)(b0 + row) * N + col;
+                        if (vec && col + 3 < N) *reinterpret_cast<float4*>(o) = v;
+                        else {
+                            if (col < N) o[0] = v.x;
+                            if (col + 1 < N) o[1] = v.y;
+                            if (col + 2 < N) o[2] = v.z;
+                            if (col + 3 < N) o[3] = v.w;
+                        }
+                    }
+                }
             }
-            Gs[row * ld + col] = v;
         }
     }
     for (int l = 0; l < a.nlayers; ++l) {
@@ -225,15 +272,19 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const f
                 const BwdLayer& Ln = a.L[l + 1];   // its N == this K
                 const float* act = Ln.act_off >= 0 ? ws + Ln.act_off + (int64_t)arm * B * K : nullptr;
                 float* dz = ws + Ln.dz_off + (int64_t)arm * B * K;
+                float av[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = acc_row(r, lane);
-                    float v = 0.f;
-                    if (col < K && row < nvalid) {
-                        const int64_t e = (int64_t)(b0 + row) * K + col;
-                        v = (!act || act[e] > 0.f) ? acc[r] : 0.f;
-                        dz[e] = v;
-                    }
+                    const bool ok = col < K && row < nvalid;
+                    av[r] = (act && ok) ? act[(int64_t)(b0 + row) * K + col] : 1.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lane);
+                    const bool ok = col < K && row < nvalid;
+                    const float v = (ok && av[r] > 0.f) ? acc[r] : 0.f;
+                    if (ok) dz[(int64_t)(b0 + row) * K + col] = v;
                     Gs[row * ld + col] = v;
                 }
             } else {
@@ -246,16 +297,20 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const f
                     mu = ws[a.rprev_mean_off + (int64_t)arm * K + col];
                     rs = ws[a.rprev_rstd_off + (int64_t)arm * K + col];
                 }
+                float rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lane);
+                    const bool ok = col < K && row < nvalid;
+                    rv[r] = (want && ok) ? rp[(int64_t)(b0 + row) * K + col] : 0.f;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = acc_row(r, lane);
                     if (col < K && row < nvalid) {
-                        const int64_t e = (int64_t)(b0 + row) * K + col;
-                        go[e] = acc[r];
-                        if (want) {
-                            s1 += acc[r];
-                            s2 += acc[r] * ((rp[e] - mu) * rs);
-                        }
+                        go[(int64_t)(b0 + row) * K + col] = acc[r];
+                        s1 += acc[r];
+                        s2 += acc[r] * ((rv[r] - mu) * rs);
                     }
                 }
                 if (want) {

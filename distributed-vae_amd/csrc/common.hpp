@@ -107,13 +107,19 @@ __device__ __forceinline__ void mma_nt(f32x16& acc, const float* At, int lda, in
     const int lane = lane_id();
     const float* pa = At + (a_row0 + (lane & 31)) * lda + 4 * (lane >> 5);
     const float* pb = Bt + (b_row0 + (lane & 31)) * ldb + 4 * (lane >> 5);
+    // fragments of group g+1 are requested before the MFMAs of group g: LDS latency hides under them
+    float4 a = *reinterpret_cast<const float4*>(pa);
+    float4 b = *reinterpret_cast<const float4*>(pb);
     for (int g = 0; g < kgroups; ++g) {
-        const float4 a = *reinterpret_cast<const float4*>(pa + 8 * g);
-        const float4 b = *reinterpret_cast<const float4*>(pb + 8 * g);
+        const int gn = (g + 1 < kgroups) ? g + 1 : g;
+        const float4 an = *reinterpret_cast<const float4*>(pa + 8 * gn);
+        const float4 bn = *reinterpret_cast<const float4*>(pb + 8 * gn);
         acc = mfma32(a.x, b.x, acc);
         acc = mfma32(a.y, b.y, acc);
         acc = mfma32(a.z, b.z, acc);
         acc = mfma32(a.w, b.w, acc);
+        a = an;
+        b = bn;
     }
 }
 
@@ -124,13 +130,49 @@ __device__ __forceinline__ void mma_nn(f32x16& acc, const float* At, int lda, in
     const int lane = lane_id();
     const float* pa = At + (a_row0 + (lane & 31)) * lda + 4 * (lane >> 5);
     const float* pb = Bk + (4 * (lane >> 5)) * ldb + n0 + (lane & 31);
+    float4 a = *reinterpret_cast<const float4*>(pa);
+    float b0 = pb[0], b1 = pb[ldb], b2 = pb[2 * ldb], b3 = pb[3 * ldb];
     for (int g = 0; g < kgroups; ++g) {
-        const float4 a = *reinterpret_cast<const float4*>(pa + 8 * g);
-        const float* q = pb + (8 * g) * ldb;
-        acc = mfma32(a.x, q[0], acc);
-        acc = mfma32(a.y, q[ldb], acc);
-        acc = mfma32(a.z, q[2 * ldb], acc);
-        acc = mfma32(a.w, q[3 * ldb], acc);
+        const int gn = (g + 1 < kgroups) ? g + 1 : g;
+        const float4 an = *reinterpret_cast<const float4*>(pa + 8 * gn);
+        const float* q = pb + (8 * gn) * ldb;
+        const float n0_ = q[0], n1_ = q[ldb], n2_ = q[2 * ldb], n3_ = q[3 * ldb];
+        acc = mfma32(a.x, b0, acc);
+        acc = mfma32(a.y, b1, acc);
+        acc = mfma32(a.z, b2, acc);
+        acc = mfma32(a.w, b3, acc);
+        a = an;
+        b0 = n0_; b1 = n1_; b2 = n2_; b3 = n3_;
+    }
+}
+
+// two adjacent 32-column tiles sharing the A fragments (n0 and n0 + 32); second tile optional
+__device__ __forceinline__ void mma_nn2(f32x16& acc0, f32x16& acc1, bool second, const float* At, int lda,
+                                        int a_row0, const float* Bk, int ldb, int n0, int kgroups) {
+    const int lane = lane_id();
+    const float* pa = At + (a_row0 + (lane & 31)) * lda + 4 * (lane >> 5);
+    const float* pb = Bk + (4 * (lane >> 5)) * ldb + n0 + (lane & 31);
+    const int o1 = second ? 32 : 0;
+    float4 a = *reinterpret_cast<const float4*>(pa);
+    float b0 = pb[0], b1 = pb[ldb], b2 = pb[2 * ldb], b3 = pb[3 * ldb];
+    float c0 = pb[o1], c1 = pb[ldb + o1], c2 = pb[2 * ldb + o1], c3 = pb[3 * ldb + o1];
+    for (int g = 0; g < kgroups; ++g) {
+        const int gn = (g + 1 < kgroups) ? g + 1 : g;
+        const float4 an = *reinterpret_cast<const float4*>(pa + 8 * gn);
+        const float* q = pb + (8 * gn) * ldb;
+        const float n0_ = q[0], n1_ = q[ldb], n2_ = q[2 * ldb], n3_ = q[3 * ldb];
+        const float m0_ = q[o1], m1_ = q[ldb + o1], m2_ = q[2 * ldb + o1], m3_ = q[3 * ldb + o1];
+        acc0 = mfma32(a.x, b0, acc0);
+        if (second) acc1 = mfma32(a.x, c0, acc1);
+        acc0 = mfma32(a.y, b1, acc0);
+        if (second) acc1 = mfma32(a.y, c1, acc1);
+        acc0 = mfma32(a.z, b2, acc0);
+        if (second) acc1 = mfma32(a.z, c2, acc1);
+        acc0 = mfma32(a.w, b3, acc0);
+        if (second) acc1 = mfma32(a.w, c3, acc1);
+        a = an;
+        b0 = n0_; b1 = n1_; b2 = n2_; b3 = n3_;
+        c0 = m0_; c1 = m1_; c2 = m2_; c3 = m3_;
     }
 }
 
@@ -145,6 +187,26 @@ __device__ __forceinline__ void mma_tn(f32x16& acc, const float* Pk, int ldp, in
     for (int s = 0; s < ksteps; ++s) {
         acc = mfma32(pa[2 * s * ldp], pb[2 * s * ldq], acc);
     }
+}
+
+// Branch-free [1 x 4] load of a row-major matrix, zero outside [R, Cn].  Addresses are clamped and the
+// result selected, so a tile's loads issue back to back (a per-element `if` makes hipcc wait
+// vmcnt(0) per load).  `vec` must be block-uniform: ld % 4 == 0, Cn % 4 == 0, col % 4 == 0, base aligned.
+__device__ __forceinline__ float4 ldg4_bf(const float* __restrict__ m, int64_t ld, int row, int col, int R, int Cn,
+                                          bool vec) {
+    const bool rok = row < R;
+    const float* p = m + (int64_t)(rok ? row : 0) * ld;
+    float4 v;
+    if (vec) {
+        const bool ok = rok && (col < Cn);
+        v = *reinterpret_cast<const float4*>(p + (ok ? col : 0));
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+        return v;
+    }
+    const bool o0 = rok && (col < Cn), o1 = rok && (col + 1 < Cn), o2 = rok && (col + 2 < Cn), o3 = rok && (col + 3 < Cn);
+    v.x = p[o0 ? col : 0]; v.y = p[o1 ? col + 1 : 0]; v.z = p[o2 ? col + 2 : 0]; v.w = p[o3 ? col + 3 : 0];
+    v.x = o0 ? v.x : 0.f; v.y = o1 ? v.y : 0.f; v.z = o2 ? v.z : 0.f; v.w = o3 ? v.w : 0.f;
+    return v;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -366,34 +366,41 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
 
     constexpr int PA4 = BK * TA / 4 / 256, QB4 = BK * TB / 4 / 256;   // float4 per thread
     float4 rp[PA4], rq[QB4];
+    const bool pv = pvec && ((d.Mv & 3) == 0);
+    const bool qv = qvec && ((d.Nv & 3) == 0);
     auto load_tiles = [&](int bt) {
         const int r0 = bt * BK;
 #pragma unroll
         for (int i = 0; i < PA4; ++i) {
             const int idx = tid + i * 256, row = idx / (TA / 4), c4 = idx % (TA / 4);
-            rp[i] = load_m4(P, d.ldp, r0 + row, m0 + c4 * 4, B, d.Mv, pvec);
+            rp[i] = ldg4_bf(P, d.ldp, r0 + row, m0 + c4 * 4, B, d.Mv, pv);
         }
 #pragma unroll
         for (int i = 0; i < QB4; ++i) {
             const int idx = tid + i * 256, row = idx / (TB / 4), c4 = idx % (TB / 4);
             const int gr = r0 + row, gc = n0 + c4 * 4;
-            float4 v = load_m4(Q, d.ldq, gr, gc, B, d.Nv, qvec);
+            float4 v = ldg4_bf(Q, d.ldq, gr, gc, B, d.Nv, qv);
             if (d.q_xmask) v = apply_xmask(v, nz, 1, arm, gr, gc, B, d.Nv, qvec);
-            if (d.q_mean) {
+            if (d.q_mean) {   // uniform branch; clamped, unconditional loads inside
                 const float* mu = d.q_mean + (int64_t)arm * d.Nv;
                 const float* rs = d.q_rstd + (int64_t)arm * d.Nv;
-                if (gr < B) {
-                    if (gc < d.Nv) v.x = (v.x - mu[gc]) * rs[gc];
-                    if (gc + 1 < d.Nv) v.y = (v.y - mu[gc + 1]) * rs[gc + 1];
-                    if (gc + 2 < d.Nv) v.z = (v.z - mu[gc + 2]) * rs[gc + 2];
-                    if (gc + 3 < d.Nv) v.w = (v.w - mu[gc + 3]) * rs[gc + 3];
-                }
+                const bool rok = gr < B;
+                const bool o0 = rok && gc < d.Nv, o1 = rok && gc + 1 < d.Nv, o2 = rok && gc + 2 < d.Nv,
+                           o3 = rok && gc + 3 < d.Nv;
+                const int i0 = o0 ? gc : 0, i1 = o1 ? gc + 1 : 0, i2 = o2 ? gc + 2 : 0, i3 = o3 ? gc + 3 : 0;
+                const float m0_ = mu[i0], m1_ = mu[i1], m2_ = mu[i2], m3_ = mu[i3];
+                const float s0_ = rs[i0], s1_ = rs[i1], s2_ = rs[i2], s3_ = rs[i3];
+                v.x = o0 ? (v.x - m0_) * s0_ : 0.f;
+                v.y = o1 ? (v.y - m1_) * s1_ : 0.f;
+                v.z = o2 ? (v.z - m2_) * s2_ : 0.f;
+                v.w = o3 ? (v.w - m3_) * s3_ : 0.f;
             }
-            if (d.q_ones && gr < B) {
-                if (gc == d.Nv) v.x = 1.f;
-                if (gc + 1 == d.Nv) v.y = 1.f;
-                if (gc + 2 == d.Nv) v.z = 1.f;
-                if (gc + 3 == d.Nv) v.w = 1.f;
+            if (d.q_ones) {
+                const bool rok = gr < B;
+                v.x = (rok && gc == d.Nv) ? 1.f : v.x;
+                v.y = (rok && gc + 1 == d.Nv) ? 1.f : v.y;
+                v.z = (rok && gc + 2 == d.Nv) ? 1.f : v.z;
+                v.w = (rok && gc + 3 == d.Nv) ? 1.f : v.w;
             }
             rq[i] = v;
         }

@@ -8,6 +8,7 @@
 //     instead of a Philox evaluation per float4 in both fc1 forward and dW1;
 //   * 64x64 (fc1, dW) wave tiles: 4 accumulators per wave, 1 ds_read_b128 per 4 MFMAs.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace mmvae {
 
@@ -78,7 +79,8 @@ template <bool USE_MASK>
 __global__ __launch_bounds__(256) void k_fc1_fwd_v2(const float* __restrict__ x, int64_t x_arm_stride,
                                                     const float* __restrict__ params, int64_t per_arm, int64_t w_off,
                                                     const uint32_t* __restrict__ bits, int wpr,
-                                                    float* __restrict__ slab, int A, int B, int D, int H, int KS) {
+                                                    float* __restrict__ slab, int A, int B, int D, int H, int KS,
+                                                    int ablate) {
     __shared__ __attribute__((aligned(16))) float As[128 * V2_LD];
     __shared__ __attribute__((aligned(16))) float Bs[128 * V2_LD];
     const int arm = blockIdx.z, ks = blockIdx.y, b0 = blockIdx.x * 128;
@@ -138,9 +140,10 @@ __global__ __launch_bounds__(256) void k_fc1_fwd_v2(const float* __restrict__ x,
             *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * V2_LD + c4 * 4]) = rb4[i];
         }
         __syncthreads();
-        if (kt + 1 < kt1) load_tiles(kt + 1);
+        if (kt + 1 < kt1 && !(ablate & 2)) load_tiles(kt + 1);
         const float* la = As + (wm * 64 + l31) * V2_LD + 4 * hh;
         const float* lb = Bs + (wn * 64 + l31) * V2_LD + 4 * hh;
+        if (!(ablate & 1))
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 a0 = *reinterpret_cast<const float4*>(la + 8 * g);
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d1
                                                  const float* __restrict__ x, int64_t x_arm_stride,
                                                  float* __restrict__ x_rec, float* __restrict__ dz11,
                                                  float* __restrict__ gd10_slab, float* __restrict__ part, float coef,
-                                                 int need_grad, int A, int B, int D, int H, int NS, int ldk) {
+                                                 int need_grad, int A, int B, int D, int H, int NS, int ldk,
+                                                 int ablate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                 // [64][ldk]
     float* Ws = Ds + 64 * ldk;        // [64][ldk]
@@ -320,6 +324,10 @@ __global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d1
     };
     f32x16 g0 = zero16(), g1 = zero16();
     float se = 0.f, mism = 0.f;
+    // per-lane bases of this wave's 32x32 tile (row of register 0, column of this lane)
+    const uint32_t lane_off = (uint32_t)(b0 + wm * 32 + 4 * (lane >> 5)) * (uint32_t)D + (uint32_t)(wn * 32 + l31);
+    float* dza = dz11 + (int64_t)arm * B * D;
+    float* xra = x_rec ? x_rec + (int64_t)arm * B * D : nullptr;
     if (t0 < t1) prefetch_w(t0);
     for (int t = t0; t < t1; ++t) {
         const int j0 = t * 64;
@@ -330,39 +338,51 @@ __global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d1
             if (c < nc4) *reinterpret_cast<float4*>(&Ws[srow * ldk + c * 4]) = wreg[i];
         }
         __syncthreads();
-        // request this step's x values (C layout of the 32x32 tile of this wave) and the next W tile
+        // request this step's x values (C layout of the 32x32 tile of this wave) and the next W tile.
+        // Interior tiles (all 64 rows and 64 genes valid) use per-lane base pointers + wave-uniform
+        // offsets (no clamps, no predicates: few address registers); edge tiles take the guarded path.
+        const bool edge = (b0 + 64 > B) || (j0 + 64 > D);
         const int col = j0 + wn * 32 + l31;
-        const int colc = min(col, D - 1);
         float xv[16];
+        float bj;
+        // 32-bit element offsets from wave-uniform bases (B*D < 2^30 checked by the launcher): one
+        // address VGPR per access instead of hoisted 64-bit pointers per register row
+        uint32_t off[16];
+        if (!edge) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = min(b0 + wm * 32 + acc_row(r, lane), B - 1);
-            xv[r] = xa[(int64_t)row * D + colc];
+            for (int r = 0; r < 16; ++r) off[r] = lane_off + (uint32_t)(((r & 3) + 8 * (r >> 2)) * D + j0);
+            bj = bias[col];
+        } else {
+            const int colc = min(col, D - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                off[r] = (uint32_t)min(b0 + wm * 32 + acc_row(r, lane), B - 1) * (uint32_t)D + (uint32_t)colc;
+            bj = bias[colc];
         }
-        const float bj = bias[colc];
-        if (t + 1 < t1) prefetch_w(t + 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xv[r] = (ablate & 1) ? 0.f : xa[off[r]];
         f32x16 z = zero16();
-        mma_nt(z, Ds, ldk, wm * 32, Ws, ldk, wn * 32, KP / 8);
+        if (!(ablate & 4)) mma_nt(z, Ds, ldk, wm * 32, Ws, ldk, wn * 32, KP / 8);
+        float* zs = Zs + (wm * 32 + 4 * (lane >> 5)) * F11_LDZ2 + wn * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int lrow = wm * 32 + acc_row(r, lane);
-            const int row = b0 + lrow;
-            const bool ok = (row < B) && (col < D);
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const bool ok = !edge || ((b0 + wm * 32 + acc_row(r, lane) < B) && (col < D));
             const float xr = fmaxf(z[r] + bj, 0.f);
             const float e = xr - xv[r];
             const float dzv = (ok && xr > 0.f) ? coef * e : 0.f;
             if (ok) {
                 se += e * e;
                 mism += ((xr > 0.1f) != (xv[r] > 0.1f)) ? 1.f : 0.f;
-                if (x_rec) x_rec[((int64_t)arm * B + row) * D + col] = xr;
-                if (need_grad) dz11[((int64_t)arm * B + row) * D + col] = dzv;
+                if (x_rec) xra[off[r]] = xr;
+                if (need_grad && !(ablate & 2)) dza[off[r]] = dzv;
             }
-            Zs[lrow * F11_LDZ2 + wn * 32 + l31] = dzv;
+            zs[rr * F11_LDZ2] = dzv;
         }
-        if (need_grad) {
+        if (t + 1 < t1 && !(ablate & 16)) prefetch_w(t + 1);     // in flight during the second GEMM
+        if (need_grad && !(ablate & 8)) {
             __syncthreads();
-            mma_nn(g0, Zs, F11_LDZ2, wm * 32, Ws, ldk, wn * 64, 8);
-            if (wn * 64 + 32 < H) mma_nn(g1, Zs, F11_LDZ2, wm * 32, Ws, ldk, wn * 64 + 32, 8);
+            mma_nn2(g0, g1, wn * 64 + 32 < H, Zs, F11_LDZ2, wm * 32, Ws, ldk, wn * 64, 8);
         }
     }
     if (need_grad) {
@@ -396,7 +416,8 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs) {
     const mmvae_dims& d = c.d;
-    return (d.D & 3) == 0 && (d.H & 3) == 0 && al16(params) && al16(x) && (xs & 3) == 0 && d.H >= 4;
+    return (d.D & 3) == 0 && (d.H & 3) == 0 && al16(params) && al16(x) && (xs & 3) == 0 && d.H >= 4 &&
+           (int64_t)d.B * d.D < ((int64_t)1 << 30);
 }
 
 int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
@@ -416,14 +437,16 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
     const mmvae_dims& d = c.d;
     const bool use_mask = c.h.training && c.h.x_drop > 0.f;
     const int KS = c.lay.sp.ks_fc1;
+    static const int ablate = getenv("MMVAE_ABLATE") ? atoi(getenv("MMVAE_ABLATE")) : 0;   // timing experiments only
+    static const int padlds = getenv("MMVAE_PADLDS") ? atoi(getenv("MMVAE_PADLDS")) : 0;   // occupancy experiments
     dim3 grid(cdiv(d.B, 128), KS, d.A);
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits);
     if (use_mask)
-        hipLaunchKernelGGL((k_fc1_fwd_v2<true>), grid, dim3(256), 0, c.stream, x, xs, params, c.po.per_arm, c.po.o[0],
-                           bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS);
+        hipLaunchKernelGGL((k_fc1_fwd_v2<true>), grid, dim3(256), padlds, c.stream, x, xs, params, c.po.per_arm, c.po.o[0],
+                           bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS, ablate);
     else
         hipLaunchKernelGGL((k_fc1_fwd_v2<false>), grid, dim3(256), 0, c.stream, x, xs, params, c.po.per_arm,
-                           c.po.o[0], bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS);
+                           c.po.o[0], bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS, ablate);
     HIP_LAUNCH_CHECK("k_fc1_fwd_v2");
     return 0;
 }
@@ -434,9 +457,10 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
     const size_t shm = (size_t)(64 * ldk * 2 + 64 * F11_LDZ2 + 8) * sizeof(float);
     const float coef = (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B;
     const int NS = c.lay.sp.ns_fc11;
+    static const int ablate = getenv("MMVAE_ABLATE") ? atoi(getenv("MMVAE_ABLATE")) : 0;   // timing experiments only
     hipLaunchKernelGGL(k_fc11_v2, dim3(c.lay.nblk64, NS, d.A), dim3(256), shm, c.stream, c.ws + c.lay.Dk[4], params,
                        c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + c.lay.DZ11, c.ws + c.lay.GD10_slab,
-                       c.ws + c.lay.fc11_part, coef, need_grad, d.A, d.B, d.D, d.H, NS, ldk);
+                       c.ws + c.lay.fc11_part, coef, need_grad, d.A, d.B, d.D, d.H, NS, ldk, ablate);
     HIP_LAUNCH_CHECK("k_fc11_v2");
     return 0;
 }

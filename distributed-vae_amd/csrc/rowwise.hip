@@ -137,17 +137,31 @@ __device__ __forceinline__ bool state_keep(const NoiseDev& nz, int arm, int B, i
     return noise_keep(nz, arm, STREAM_SMASK, (uint64_t)b * S + s, nz.s_keep_thr);
 }
 
-// grid (ceil(B/32), A), 256 threads; wave w handles rows b0 + w, b0 + w + 4, ...
-__global__ __launch_bounds__(256) void k_lat_fwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
-                                                 float* __restrict__ ws) {
-    __shared__ float sh_mean[4][CPL * 64], sh_m2[4][CPL * 64], sh_cnt[4], sh_red[4][2];
+// Stages fcc (transposed to [L][C]) and the state-head weights in LDS once per workgroup.
+constexpr int LAT_NW = 16;   // waves per workgroup: 2 rows of the 32-row block each
+__device__ __forceinline__ void lat_stage_weights(float* WcT, float* Wm, const float* __restrict__ Wc,
+                                                  const float* __restrict__ Wms, int L, int C, int S) {
+    for (int i = threadIdx.x; i < C * L; i += blockDim.x) {
+        const int col = i / L, k = i % L;
+        WcT[k * C + col] = Wc[i];
+    }
+    for (int i = threadIdx.x; i < 2 * S * (L + C); i += blockDim.x) Wm[i] = Wms[i];
+    __syncthreads();
+}
+
+// grid (ceil(B/32), A), 1024 threads; wave w handles rows b0 + w, b0 + w + 16
+__global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
+                                                  float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float lat_smem[];
+    __shared__ float sh_mean[LAT_NW][CPL * 64], sh_m2[LAT_NW][CPL * 64], sh_cnt[LAT_NW], sh_red[LAT_NW][2];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int B = a.B, L = a.L, C = a.C, S = a.S;
     const float* P = params + (int64_t)arm * a.per_arm;
-    const float* Wc = P + a.o_wc;     // [C][L]
+    float* WcT = lat_smem;            // [L][C]
+    float* Wms = lat_smem + C * L;    // [2S][L+C]
+    lat_stage_weights(WcT, Wms, P + a.o_wc, P + a.o_wms, L, C, S);
     const float* bc = P + a.o_bc;
-    const float* Wms = P + a.o_wms;   // [2S][L+C]
     const float* bms = P + a.o_bms;   // [2S]
     const int64_t ab = (int64_t)arm * B;
     const float eps = a.eps;
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(256) void k_lat_fwd(const LatArgs a, NoiseDev nz, c
     const float mu5 = lane < L ? ws[a.mean5 + arm * L + lane] : 0.f;
     const float rs5 = lane < L ? ws[a.rstd5 + arm * L + lane] : 0.f;
 
-    for (int row = wv; row < 32; row += 4) {
+    for (int row = wv; row < 32; row += LAT_NW) {
         const int b = b0 + row;
         if (b >= B) break;   // wave-uniform
         // ---- x_low = BN5(R5)
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(256) void k_lat_fwd(const LatArgs a, NoiseDev nz, c
         for (int k = 0; k < L; ++k) {
             const float xk = __shfl(xl, k, 64);
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) z[t] += xk * Wc[col * L + k]; }
+            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) z[t] += xk * WcT[k * C + col]; }
         }
         float m = -INFINITY;
 #pragma unroll
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(256) void k_lat_fwd(const LatArgs a, NoiseDev nz, c
     const int col = threadIdx.x;
     if (col < C) {
         float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < LAT_NW; ++w) {
             const float nb = sh_cnt[w];
             if (nb > 0.f) {
                 const float nn = n + nb, dl = sh_mean[w][col] - mean;
@@ -317,8 +331,10 @@ __global__ __launch_bounds__(256) void k_lat_fwd(const LatArgs a, NoiseDev nz, c
     }
     if (threadIdx.x == 0) {
         float* p = ws + a.lat_part + ((int64_t)arm * gridDim.x + blk) * 2;
-        p[0] = sh_red[0][0] + sh_red[1][0] + sh_red[2][0] + sh_red[3][0];
-        p[1] = sh_red[0][1] + sh_red[1][1] + sh_red[2][1] + sh_red[3][1];
+        float k0 = 0.f, k1 = 0.f;
+        for (int w = 0; w < LAT_NW; ++w) { k0 += sh_red[w][0]; k1 += sh_red[w][1]; }
+        p[0] = k0;
+        p[1] = k1;
     }
 }
 
@@ -472,15 +488,17 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
 // ---------------------------------------------------------------------------------------------
 // backward of the latent block.  grid (ceil(B/32), A), 256 threads, one wave per cell.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lat_bwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
-                                                 float* __restrict__ ws) {
-    __shared__ float sh_s[4][2][64];
+__global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
+                                                  float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float lat_smem[];
+    __shared__ float sh_s[LAT_NW][2][64];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int A = a.A, B = a.B, L = a.L, C = a.C, S = a.S;
     const float* P = params + (int64_t)arm * a.per_arm;
-    const float* Wc = P + a.o_wc;
-    const float* Wms = P + a.o_wms;
+    float* WcT = lat_smem;            // [L][C]
+    float* Wms = lat_smem + C * L;    // [2S][L+C]
+    lat_stage_weights(WcT, Wms, P + a.o_wc, P + a.o_wms, L, C, S);
     const int64_t ab = (int64_t)arm * B;
     const float eps = a.eps, invB = 1.f / (float)B;
     const float coefG = 2.f * a.lam * invB;
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(256) void k_lat_bwd(const LatArgs a, NoiseDev nz, c
     }
     float s1 = 0.f, s2 = 0.f;   // BN5 backward sums for column `lane` (< L)
 
-    for (int row = wv; row < 32; row += 4) {
+    for (int row = wv; row < 32; row += LAT_NW) {
         const int b = b0 + row;
         if (b >= B) break;
         // ---- state head backward (lanes < S)
@@ -598,7 +616,7 @@ __global__ __launch_bounds__(256) void k_lat_bwd(const LatArgs a, NoiseDev nz, c
         for (int k = 0; k < L; ++k) {
             float p = 0.f;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) p += gzc[t] * Wc[col * L + k]; }
+            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) p += gzc[t] * WcT[k * C + col]; }
             p = wave_sum(p);
             if (lane == k) g5 = gxl + p;
         }
@@ -614,8 +632,10 @@ __global__ __launch_bounds__(256) void k_lat_bwd(const LatArgs a, NoiseDev nz, c
     if (threadIdx.x < L) {
         const int k = threadIdx.x;
         float* p = ws + a.bnb_part5 + (((int64_t)arm * gridDim.x + blk) * 2) * L;
-        p[k] = sh_s[0][0][k] + sh_s[1][0][k] + sh_s[2][0][k] + sh_s[3][0][k];
-        p[L + k] = sh_s[0][1][k] + sh_s[1][1][k] + sh_s[2][1][k] + sh_s[3][1][k];
+        float k0 = 0.f, k1 = 0.f;
+        for (int w = 0; w < LAT_NW; ++w) { k0 += sh_s[w][0][k]; k1 += sh_s[w][1][k]; }
+        p[k] = k0;
+        p[L + k] = k1;
     }
 }
 
@@ -754,7 +774,8 @@ int launch_stats_finalize(const Ctx& c, int layer, float* bn_running, int64_t* n
 int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
-    hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblk32, c.d.A), dim3(256), 0, c.stream, a, nd, params, c.ws);
+    const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
+    hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblk32, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws);
     HIP_LAUNCH_CHECK("k_lat_fwd");
     return 0;
 }
@@ -785,7 +806,8 @@ int launch_loss_finalize(const Ctx& c, float* loss_out) {
 int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
-    hipLaunchKernelGGL(k_lat_bwd, dim3(c.lay.nblk32, c.d.A), dim3(256), 0, c.stream, a, nd, params, c.ws);
+    const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
+    hipLaunchKernelGGL(k_lat_bwd, dim3(c.lay.nblk32, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws);
     HIP_LAUNCH_CHECK("k_lat_bwd");
     return 0;
 }

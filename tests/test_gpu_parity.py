@@ -366,7 +366,7 @@ def test_full_size_against_oracle(full):
         e_cpu = ((g_r[k].double() - ref).abs() / sc).flatten()
         assert p90(e_gpu) < max(3.0 * p90(e_cpu), 1e-4), (k, p90(e_gpu), p90(e_cpu))
         assert float(e_gpu.max()) < 5 * GRAD_TOL, (k, float(e_gpu.max()))
-        assert float((e_gpu > 1e-4).float().mean()) < 1e-2, k            # isolated flips only
+        assert int((e_gpu > 1e-4).sum()) <= max(3, e_gpu.numel() // 100), k   # isolated flips only
 
 
 def test_full_size_properties(full):

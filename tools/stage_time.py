@@ -1,0 +1,26 @@
+"""GPU tuning aid: time given stages once (HIP events), honouring MMVAE_ABLATE / split env."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import distributed_vae_amd  # noqa
+from distributed_vae_amd import _native as N
+from distributed_vae_amd.nn_model import mixVAE_model
+A, B, D, H, L, C, S = 2, 5000, 5000, 100, 10, 92, 2
+dev = torch.device("cuda", 0)
+for w in range(4):
+    v = os.environ.get(f"MMVAE_SPLIT{w}")
+    if v: N.lib().mmvae_set_split(w, int(v))
+g = torch.Generator(device=dev).manual_seed(1)
+x = (torch.rand(B, D, generator=g, device=dev) < 0.2).float() * torch.randn(B, D, generator=g, device=dev).abs() * 3
+torch.manual_seed(546)
+m = mixVAE_model(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev, eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE").to(dev)
+m.train(); eng = m._ensure(B); hyper = m._hyper(1.0, False); noise = N.make_noise(None, 99, 1)
+eng.forward(hyper, noise, m._flat, m._bn_flat, None, x, 0, None, True); eng.loss(hyper); eng.backward(hyper, noise, m._flat, x, 0, m._flat_grad)
+torch.cuda.synchronize()
+for sid in [int(s) for s in sys.argv[1:]]:
+    for _ in range(2): eng.debug_stage(sid, hyper, noise, m._flat, x, 0, m._flat_grad)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): eng.debug_stage(sid, hyper, noise, m._flat, x, 0, m._flat_grad)
+    e1.record(); e1.synchronize()
+    print(f"ABLATE={os.environ.get('MMVAE_ABLATE','0')} splits={[os.environ.get(f'MMVAE_SPLIT{w}') for w in range(4)]} stage {sid}: {e0.elapsed_time(e1)/10*1e3:.1f} us", flush=True)
