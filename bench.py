@@ -213,18 +213,21 @@ def main():
 
 
 STAGES = {
-    # id: (kernel(s), algorithmic FLOPs per launch as a function of (A,B,D,H), algorithmic HBM bytes)
-    0: ("k_fc1_fwd+k_fc1_epi", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D),
-    1: ("k_fc11_fused", lambda A, B, D, H: A * 2 * 2.0 * B * D * H, lambda A, B, D, H: A * 2 * 4.0 * B * D),
-    2: ("k_gemm_tn<dW1>+<dW11>", lambda A, B, D, H: A * 2 * 2.0 * B * D * H, lambda A, B, D, H: A * 2 * 4.0 * B * D),
+    # debug-stage id: (kernel, algorithmic FLOPs per launch, algorithmic HBM bytes per launch) as functions of (A,B,D,H)
+    14: ("k_fc1_fwd_v2", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D),
+    10: ("k_fc11_z", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 2 * 4.0 * B * D),
+    11: ("k_gd10_v2", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D),
+    12: ("k_tn_v2<dW1>", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D),
+    13: ("k_tn_v2<dW11>", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D),
 }
 
 
 def measure_stages(model, x, A, B, D, H):
-    """Per-launch duration of the MFMA-bound stages, measured live with HIP events on the stream the
-    kernels are launched on (torch's current stream), each stage replayed alone on a workspace that a
-    full forward+loss+backward has prepared (mmvae_debug_stage).  The dominant one is reported as the
-    roofline object; FLOPs are the algorithmic ones of SURVEY.md 8(d) (padding H->104/128 not counted)."""
+    """Per-launch duration of the five MFMA-bound kernels (the five D x H GEMMs of SURVEY.md 8d), measured
+    live with HIP events on the stream the kernels are launched on (torch's current stream), each kernel
+    replayed alone on a workspace that a full forward+loss+backward has prepared (mmvae_debug_stage).
+    The one with the longest launch is reported as the roofline object; FLOPs are algorithmic
+    (2*B*D*H per arm and GEMM; padding H -> 104/128 is not counted)."""
     from distributed_vae_amd import _native as N
 
     eng = model._engine

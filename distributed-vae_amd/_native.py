@@ -86,6 +86,8 @@ def lib():
     L.mmvae_ws_offset.argtypes = [C.POINTER(Dims), C.c_int]
     L.mmvae_ws_offset.restype = i64
     L.mmvae_set_split.argtypes = [C.c_int, C.c_int]
+    L.mmvae_set_side_stream.argtypes = [vp]
+    L.mmvae_set_side_stream.restype = C.c_int
     L.mmvae_forward.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp, i32,
                                 vp, C.c_size_t, vp]
     L.mmvae_loss.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, C.c_size_t, vp, vp]
@@ -158,6 +160,13 @@ class Engine:
         self.ws = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
         assert self.ws.data_ptr() % 256 == 0
         self.loss_buf = torch.zeros(5 + 3 * A, dtype=torch.float32, device=self.device)
+        # side stream: the dW11 GEMM overlaps the latency-bound backward chain (MMVAE_SIDE_STREAM=0 disables)
+        self.side = None
+        if os.environ.get("MMVAE_SIDE_STREAM", "1") != "0":
+            self.side = torch.cuda.Stream(device=self.device)
+
+    def _bind_side(self):
+        lib().mmvae_set_side_stream(C.c_void_p(self.side.cuda_stream) if self.side is not None else None)
 
     def ws_view(self, name: str, width: int) -> torch.Tensor:
         off = int(lib().mmvae_ws_offset(C.byref(self.dims), WS_IDS[name]))
@@ -181,12 +190,14 @@ class Engine:
         return self.loss_buf
 
     def backward(self, hyper: Hyper, noise: Noise, params, x, x_arm_stride, grads, grad_scale=1.0):
+        self._bind_side()
         check(lib().mmvae_backward(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params), _ptr(x),
                                    x_arm_stride, float(grad_scale), _ptr(self.ws), self.ws_bytes, _ptr(grads),
                                    _stream()), "mmvae_backward")
 
     def train_step(self, hyper, noise, params, bn_running, nbt, x, x_arm_stride, grads, do_adam, exp_avg,
                    exp_avg_sq, step, lr, b1=0.9, b2=0.999, adam_eps=1e-8, wd=0.0, decoupled=False):
+        self._bind_side()
         check(lib().mmvae_train_step(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params),
                                      _ptr(bn_running), _ptr(nbt), _ptr(x), x_arm_stride, _ptr(self.ws), self.ws_bytes,
                                      _ptr(grads), _ptr(self.loss_buf), int(do_adam), _ptr(exp_avg), _ptr(exp_avg_sq),

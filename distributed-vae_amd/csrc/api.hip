@@ -14,25 +14,35 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static int g_split[4] = {0, 0, 0, 0};
+static int g_split[5] = {0, 0, 0, 0, 0};
 
+// Split factors are chosen so that each large kernel's grid fills the chip's resident-workgroup
+// slots once (256 CUs x workgroups per CU that its registers / LDS admit) without spilling into a
+// second, mostly empty round: e.g. 624 workgroups on 512 slots take two rounds, 468 take one.
 Splits default_splits(const mmvae_dims& d) {
-    auto pick = [](int base_blocks, int target, int cap) {
-        int k = cdiv(target, base_blocks > 0 ? base_blocks : 1);
+    constexpr int CUS = 256;
+    auto fit = [](int base_blocks, int slots, int cap) {
+        int k = slots / (base_blocks > 0 ? base_blocks : 1);
         if (k > cap) k = cap;
         if (k < 1) k = 1;
         return k;
     };
     Splits s;
-    const int nb64 = cdiv(d.B, 64);
-    s.ks_fc1 = g_split[0] > 0 ? g_split[0] : pick(nb64 * d.A, 1024, 16);
+    const int nb128 = cdiv(d.B, 128), nb64 = cdiv(d.B, 64);
+    const bool fastdims = (d.D & 3) == 0 && (d.H & 3) == 0;
+    // fc1 forward: fast kernel 128-row blocks, 3 workgroups / CU; general kernel 64-row blocks
+    s.ks_fc1 = g_split[0] > 0 ? g_split[0] : (fastdims ? fit(nb128 * d.A, 3 * CUS, 16) : fit(nb64 * d.A, 4 * CUS, 16));
     s.ks_fc1 = min(s.ks_fc1, max(1, cdiv(d.D, 32)));
-    s.ns_fc11 = g_split[1] > 0 ? g_split[1] : pick(nb64 * d.A, 1024, 16);
+    // fc11 x_rec/loss/dZ11 kernel: 128-row blocks, 2 workgroups / CU (general fused kernel: 64-row blocks)
+    s.ns_fc11 = g_split[1] > 0 ? g_split[1] : (fastdims ? fit(max(1, d.B / 128) * d.A, 2 * CUS, 16) : fit(nb64 * d.A, 2 * CUS, 16));
     s.ns_fc11 = min(s.ns_fc11, max(1, cdiv(d.D, 64)));
-    s.ks_dw = g_split[2] > 0 ? g_split[2] : pick(cdiv(d.D, 64) * d.A, 1024, 16);
+    // dW1 / dW11: 128-gene tiles, 4 workgroups / CU
+    s.ks_dw = g_split[2] > 0 ? g_split[2] : fit(cdiv(d.D, fastdims ? 128 : 64) * d.A, 4 * CUS, 16);
     s.ks_dw = min(s.ks_dw, max(1, cdiv(d.B, 32)));
-    s.ks_small = g_split[3] > 0 ? g_split[3] : pick(N_SMALL * d.A, 512, 32);
+    s.ks_small = g_split[3] > 0 ? g_split[3] : fit(N_SMALL * d.A, 2 * CUS, 32);
     s.ks_small = min(s.ks_small, max(1, cdiv(d.B, 32)));
+    s.ks_gd10 = g_split[4] > 0 ? g_split[4] : fit(nb128 * d.A, 3 * CUS, 16);
+    s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, 32)));
     return s;
 }
 
@@ -84,8 +94,9 @@ Layout make_layout(const mmvae_dims& d) {
     L.c_part = take(A * nb * 2 * C); L.c_mean = take(A * C); L.c_iv = take(A * C);
     L.lat_part = take(A * nb * 2);
     L.fc1_slab = take((int64_t)L.sp.ks_fc1 * A * B * NP);
-    L.fc11_part = take(A * L.nblk64 * L.sp.ns_fc11 * 2);
-    L.GD10_slab = take((int64_t)L.sp.ns_fc11 * A * B * H);
+    L.n11 = (L.nblk64 + 2) * (L.sp.ns_fc11 + 1) + cdiv(d.D, 64);
+    L.fc11_part = take(A * (int64_t)L.n11 * 2 + 64);   // + diagnostic stamp counters
+    L.GD10_slab = take((int64_t)max(L.sp.ns_fc11, L.sp.ks_gd10) * A * B * H);
     L.DZ11 = take(A * B * D);
     L.couple_part = take(nb * 2);
     L.T_part = take(nb * A * C); L.T = take(A * C);
@@ -187,10 +198,35 @@ static int do_loss(const Ctx& c, float* loss_out) {
     return launch_loss_finalize(c, loss_out);
 }
 
+static thread_local hipStream_t g_side = nullptr;
+static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+
 static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs,
                        float grad_scale, float* grads) {
     int rc;
-    if ((rc = launch_chain_bwd_dec(c, params))) return rc;
+    const bool fast = fast_path_ok(c, params, x, xs);
+    // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain
+    bool forked = false;
+    if (fast && g_side) {
+        if (!g_ev_fork) {
+            if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
+                set_error("event creation failed");
+                return MMVAE_E_LAUNCH;
+            }
+        }
+        Ctx cs = c;
+        cs.stream = g_side;
+        if (hipEventRecord(g_ev_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess) {
+            set_error("stream fork failed");
+            return MMVAE_E_LAUNCH;
+        }
+        if ((rc = launch_dw_big_fast(cs, x, xs, 2))) return rc;
+        if (hipEventRecord(g_ev_join, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+        forked = true;
+    }
+    const int nslab = fc11_split_path(c, params, x, xs) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11;
+    if ((rc = launch_chain_bwd_dec(c, params, nslab))) return rc;
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
     if ((rc = launch_bnb_finalize(c, 5))) return rc;
     for (int layer = 5; layer >= 2; --layer) {
@@ -198,12 +234,13 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         if ((rc = launch_bnb_finalize(c, layer - 1))) return rc;
     }
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
-    if (fast_path_ok(c, params, x, xs)) {
-        if ((rc = launch_dw_big_fast(c, x, xs))) return rc;
+    if (fast) {
+        if ((rc = launch_dw_big_fast(c, x, xs, forked ? 1 : 3))) return rc;
     } else if ((rc = launch_dw_big(c, nz, x, xs))) {
         return rc;
     }
     if ((rc = launch_dw_small(c))) return rc;
+    if (forked && hipStreamWaitEvent(c.stream, g_ev_join, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
     return launch_reduce_grads(c, grads, grad_scale);
 }
 
@@ -217,8 +254,13 @@ int mmvae_abi_version(void) { return 1; }
 const char* mmvae_last_error_string(void) { return g_err; }
 int mmvae_check_dims(const mmvae_dims* d) { return check_dims(d); }
 
+int mmvae_set_side_stream(void* side_stream) {
+    g_side = reinterpret_cast<hipStream_t>(side_stream);
+    return 0;
+}
+
 int mmvae_set_split(int which, int value) {
-    if (which < 0 || which > 3 || value < 0 || value > 64) { set_error("bad split"); return MMVAE_E_BADARG; }
+    if (which < 0 || which > 4 || value < 0 || value > 64) { set_error("bad split"); return MMVAE_E_BADARG; }
     g_split[which] = value;
     return 0;
 }
@@ -357,12 +399,20 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
             if (fast_path_ok(c, params, x, x_arm_stride)) return launch_fc11_fast(c, params, x, x_arm_stride, nullptr, 1);
             return launch_fc11_fused(c, params, x, x_arm_stride, nullptr, 1);
         case 2:
-            if (fast_path_ok(c, params, x, x_arm_stride)) return launch_dw_big_fast(c, x, x_arm_stride);
+            if (fast_path_ok(c, params, x, x_arm_stride)) return launch_dw_big_fast(c, x, x_arm_stride, 3);
             return launch_dw_big(c, nz, x, x_arm_stride);
         case 9: return launch_make_xbits(c, nz);
+        // single kernels of the fast path (per-kernel roofline timing)
+        case 10: case 11: case 12: case 13: case 14:
+            if (!fast_path_ok(c, params, x, x_arm_stride)) { set_error("stage %d needs the fast path", stage); return MMVAE_E_UNSUPPORTED; }
+            if (stage == 10) return launch_fc11_fast(c, params, x, x_arm_stride, nullptr, 1, 1);
+            if (stage == 11) return launch_fc11_fast(c, params, x, x_arm_stride, nullptr, 1, 2);
+            if (stage == 12) return launch_dw_big_fast(c, x, x_arm_stride, 1);
+            if (stage == 13) return launch_dw_big_fast(c, x, x_arm_stride, 2);
+            return launch_fc1_fwd_fast(c, params, x, x_arm_stride);
         case 3: return launch_dw_small(c);
         case 4: return launch_chain_fwd_dec(c, params);
-        case 5: return launch_chain_bwd_dec(c, params);
+        case 5: return launch_chain_bwd_dec(c, params, fc11_split_path(c, params, x, x_arm_stride) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11);
         case 6: return launch_lat_fwd(c, nz, params);
         case 7: return launch_lat_bwd(c, nz, params);
         case 8: if (!grads) { set_error("grads is null"); return MMVAE_E_BADARG; } return launch_reduce_grads(c, grads, 1.f);

@@ -7,6 +7,7 @@
 //   k_chain_bwd   their autograd: dZ = G .* relu'(out); G_prev = dZ W; with the BatchNorm backward
 //                 folded into the prologue and its batch sums emitted by the epilogue
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace mmvae {
 
@@ -33,6 +34,7 @@ struct ChainFwdArgs {
     int64_t stats_part_off;             // [A][nblk][2][N_last] or -1
     int B, ld, wrows;
     int64_t per_arm;
+    int ablate;   // timing experiments only (MMVAE_ABLATE_C)
 };
 
 // stage W [N][K] (global, row-major) into LDS rows [0, rows_pad) x cols [0, cols_pad), zero padded.
@@ -109,11 +111,11 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const f
     for (int l = 0; l < a.nlayers; ++l) {
         const FwdLayer& Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
-        stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
+        if (!(a.ablate & 2) || l == 0) stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
         __syncthreads();
         f32x16 acc = zero16();
         const bool active = wv * 32 < NPad;
-        if (active) mma_nt(acc, Xs, ld, 0, Ws, ld, wv * 32, KP / 8);
+        if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, 0, Ws, ld, wv * 32, KP / 8);
         __syncthreads();   // every wave has finished reading Xs / Ws
         const int col = wv * 32 + (lane & 31);
         const bool last = (l + 1 == a.nlayers);
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const f
                 if (col < N && row < nvalid) {
                     v = acc[r] + bias;
                     if (Lr.act) v = fmaxf(v, 0.f);
-                    out[(int64_t)(b0 + row) * N + col] = v;
+                    if (!(a.ablate & 4)) out[(int64_t)(b0 + row) * N + col] = v;
                 }
                 vals[r] = v;
                 // next layer's input: zero beyond N (up to the next multiple of 8) and beyond nvalid
@@ -397,13 +399,14 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.ld = fwd_ld(max(max(d.H, d.L), d.C + d.S));
     a.wrows = rup(max(d.H, d.L), 32);
     a.per_arm = c.po.per_arm;
+    a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws);
     HIP_LAUNCH_CHECK("k_chain_fwd<dec>");
     return 0;
 }
 
-int launch_chain_bwd_dec(const Ctx& c, const float* params) {
+int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     ChainBwdArgs a{};
@@ -414,7 +417,7 @@ int launch_chain_bwd_dec(const Ctx& c, const float* params) {
     a.L[3] = BwdLayer{c.po.o[18], L.DZ[7], L.Dk[1], d.L, d.H};           // fc7: K = L
     a.L[4] = BwdLayer{c.po.o[16], L.DZ[6], L.Dk[0], d.C + d.S, d.L};     // fc6: K = C+S
     a.g_off = L.GD10_slab;
-    a.nslab = L.sp.ns_fc11;
+    a.nslab = nslab;
     a.slab_stride = (int64_t)d.A * d.B * d.H;
     a.bnb_sum_off = -1;
     a.bn_mean_off = a.bn_rstd_off = -1;

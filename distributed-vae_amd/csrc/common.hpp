@@ -29,6 +29,7 @@ struct Splits {
     int ns_fc11;  // column splits of the fused fc11 kernel
     int ks_dw;    // batch splits of the dW1 / dW11 GEMMs
     int ks_small; // batch splits of the batched small-layer dW GEMM
+    int ks_gd10;  // gene splits of the d(d10) = dZ11 W11 GEMM (fast path; the fused general kernel uses ns_fc11)
 };
 
 constexpr int N_SMALL = 12;  // fc2 fc3 fc4 fc5 fcc musig fc6 fc7 fc8 fc9 fc10 + fc1.bias
@@ -46,8 +47,9 @@ struct Layout {
     int64_t c_part, c_mean, c_iv;  // [A][nblk32][2][C], [A,C], [A,C]
     int64_t lat_part;              // [A][nblk32][2]  (kl sum, entropy sum)
     int64_t fc1_slab;              // [KS][A][B][NP]
-    int64_t fc11_part;             // [A][nblk64*NS][2] (squared error sum, mismatch count)
-    int64_t GD10_slab;             // [NS][A][B][H]
+    int n11;                       // loss partial slots per arm (zero-filled, a subset is written)
+    int64_t fc11_part;             // [A][n11][2] (squared error sum, mismatch count)
+    int64_t GD10_slab;             // [max(ns_fc11, ks_gd10)][A][B][H]
     int64_t DZ11;                  // [A][B][D]
     int64_t couple_part;           // [nblk32][2]  (pair distance sum, pair l2 sum)
     int64_t T_part, T;             // [nblk32][A][C], [A][C]
@@ -308,7 +310,8 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params);
 int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
 int launch_couple(const Ctx& c);
 int launch_loss_finalize(const Ctx& c, float* loss_out);
-int launch_chain_bwd_dec(const Ctx& c, const float* params);
+int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab);
+bool fc11_split_path(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params);
 int launch_bnb_finalize(const Ctx& c, int layer /*1..5*/);
 int launch_chain_bwd_enc(const Ctx& c, int layer /*5..2*/, const float* params);
@@ -322,8 +325,9 @@ bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs)
 int launch_make_xbits(const Ctx& c, const mmvae_noise* nz);
 int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc1_epi(const Ctx& c, const float* params);
-int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
-int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs);
+int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad,
+                     int which = 3);
+int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit0 dW1, bit1 dW11*/);
 int launch_dump_noise(const mmvae_dims& d, const mmvae_hyper& h, const mmvae_noise* nz, uint8_t* x_mask,
                       float* u_gumbel, float* u_state, uint8_t* s_mask, hipStream_t s);
 

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_fc11_fused(const float* __restrict__ d1
                                                     float* __restrict__ x_rec, float* __restrict__ dz11,
                                                     float* __restrict__ gd10_slab, float* __restrict__ part,
                                                     float coef, int need_grad, int A, int B, int D, int H, int NS,
-                                                    int ldk, int vec_ok) {
+                                                    int ldk, int vec_ok, int n11) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                       // [64][ldk]
     float* Ws = Ds + F11_BM * ldk;          // [64][ldk]
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_fc11_fused(const float* __restrict__ d1
     if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mism; }
     __syncthreads();
     if (tid == 0) {
-        float* p = part + (((int64_t)arm * gridDim.x + blockIdx.x) * NS + ns) * 2;
+        float* p = part + ((int64_t)arm * n11 + (int64_t)blockIdx.x * NS + ns) * 2;
         p[0] = red[0] + red[2] + red[4] + red[6];
         p[1] = red[1] + red[3] + red[5] + red[7];
     }
@@ -504,10 +504,12 @@ int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t
     const float coef = am1 / (float)d.B;
     const int NS = c.lay.sp.ns_fc11;
     dim3 grid(c.lay.nblk64, NS, d.A);
+    hipError_t e = hipMemsetAsync(c.ws + c.lay.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * c.lay.n11, c.stream);
+    if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
     hipLaunchKernelGGL(k_fc11_fused, grid, dim3(256), shm, c.stream, c.ws + c.lay.Dk[4], params, c.po.per_arm,
                        c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + c.lay.DZ11, c.ws + c.lay.GD10_slab,
                        c.ws + c.lay.fc11_part, coef, need_grad, d.A, d.B, d.D, d.H, NS, ldk,
-                       (int)(aligned16(params)));
+                       (int)(aligned16(params)), c.lay.n11);
     HIP_LAUNCH_CHECK("k_fc11_fused");
     return 0;
 }

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d1
                                                  float* __restrict__ x_rec, float* __restrict__ dz11,
                                                  float* __restrict__ gd10_slab, float* __restrict__ part, float coef,
                                                  int need_grad, int A, int B, int D, int H, int NS, int ldk,
-                                                 int ablate) {
+                                                 int ablate, int n11) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                 // [64][ldk]
     float* Ws = Ds + 64 * ldk;        // [64][ldk]
@@ -403,10 +403,284 @@ __global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d1
     if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mism; }
     __syncthreads();
     if (tid == 0) {
-        float* p = part + (((int64_t)arm * gridDim.x + blockIdx.x) * NS + ns) * 2;
+        float* p = part + ((int64_t)arm * n11 + (int64_t)blockIdx.x * NS + ns) * 2;
         p[0] = red[0] + red[2] + red[4] + red[6];
         p[1] = red[1] + red[3] + red[5] + red[7];
     }
+}
+
+// =============================================================================================
+// fc11 forward + reconstruction loss + dZ11, fast ("A-stationary"): every wave keeps the d10 rows of
+// its 32 cells in registers for the whole kernel (13 float4 at H = 100) and only the W11 tile moves
+// through LDS (double buffered, one barrier per 64-gene step).  grid (ceil(B/128), NS, A).
+// HBM-shaped: per step a wave reads 32x64 x values and writes 32x64 dZ11 values.
+// =============================================================================================
+// FZ_KG: K groups of 8 held in registers.  EXACT: rup(H,8)/8 == FZ_KG, so the MFMA stream has no
+// per-group branch (a runtime bound splits it into 8-MFMA pieces each waiting on its own LDS reads).
+template <int FZ_KG, bool EXACT, bool EDGE>
+__global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10, const float* __restrict__ params,
+                                                   int64_t per_arm, int64_t w_off, int64_t b_off,
+                                                   const float* __restrict__ x, int64_t x_arm_stride,
+                                                   float* __restrict__ x_rec, float* __restrict__ dz11,
+                                                   float* __restrict__ part, int n11, int slot_base, float coef,
+                                                   int need_grad, int A, int B, int D, int H, int ldk, int rb0, int tbeg,
+                                                   int tend, int ablate) {
+    // grid (row blocks, column splits, A).  EDGE = false: every cell row and gene column touched is
+    // in range (no clamps, no predicates, wave-uniform address bases); EDGE = true: guarded strips.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wbuf = smem;                     // [2][64][ldk]
+    float* red = smem + 2 * 64 * ldk;       // [8]
+    const int arm = blockIdx.z, ns = blockIdx.y, NS = gridDim.y, b0 = (rb0 + blockIdx.x) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int KP = rup(H, 8), kg = KP / 8, nc4 = KP / 4, hc4 = H / 4;
+    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
+    const float* bias = params + (int64_t)arm * per_arm + b_off;
+    const float* xa = x + (int64_t)arm * x_arm_stride;
+    float* dza = dz11 + (int64_t)arm * B * D;
+    float* xra = x_rec ? x_rec + (int64_t)arm * B * D : nullptr;
+    const int srow = tid >> 2, spart = tid & 3;
+
+    // ---- A fragments: row b0 + 32 wv + l31 of d10, k = 8 g + 4 hh .. + 3
+    float4 afr[FZ_KG];
+    {
+        const int row = b0 + wv * 32 + l31;
+        const float* p = d10 + ((int64_t)arm * B + min(row, B - 1)) * H + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < FZ_KG; ++g) {
+            const bool ok = (g < kg) && (row < B) && (8 * g + 4 * hh < H);
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? 8 * g : 0));
+            afr[g] = sel4(ok, v);
+        }
+    }
+    const int ntile = tend - tbeg;
+    const int t0 = tbeg + (int)(((int64_t)ns * ntile) / NS), t1 = tbeg + (int)(((int64_t)(ns + 1) * ntile) / NS);
+    float4 wreg[8];
+    auto prefetch_w = [&](int t) {
+        const int j = t * 64 + srow;
+        const float* p = W + (int64_t)min(j, D - 1) * H;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = spart + 4 * i;
+            const bool ok = (j < D) && (c < hc4);
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? c * 4 : 0));
+            wreg[i] = sel4(ok, v);
+        }
+    };
+    auto store_w = [&](float* Ws) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = spart + 4 * i;
+            if (c < nc4) *reinterpret_cast<float4*>(&Ws[srow * ldk + c * 4]) = wreg[i];
+        }
+    };
+    float se = 0.f, mism = 0.f;
+    const int rbase = b0 + wv * 32 + 4 * hh;                      // row of accumulator register 0
+    const uint32_t lane_off = (uint32_t)rbase * (uint32_t)D + (uint32_t)l31;
+    if (t0 < t1) {
+        prefetch_w(t0);
+        store_w(Wbuf);
+    }
+    __syncthreads();
+    int cur = 0;
+    // diagnostic stamps (ablate bit 3): shader-clock cycles per phase, summed over all waves, added to
+    // a counter block that nothing else reads (tail of the loss scratch region)
+    const bool stamps = (ablate & 8) != 0;
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int i) {
+        if (stamps) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            ph[i] += now - tprev;
+            tprev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+    for (int t = t0; t < t1; ++t) {
+        const int j0 = t * 64;
+        const float* Ws = Wbuf + cur * 64 * ldk;
+        // ---- request x for both 32-gene halves (C layout: lane = gene, register = cell)
+        float xv[2][16];
+        float bj[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = j0 + 32 * c + l31;
+            const int colc = EDGE ? min(col, D - 1) : col;
+            bj[c] = bias[colc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                if (!EDGE) {
+                    const float* xr = xa + ((int64_t)rr * D + j0 + 32 * c);     // wave-uniform base
+                    xv[c][r] = (ablate & 2) ? 0.f : xr[lane_off];
+                } else {
+                    xv[c][r] = xa[(uint32_t)min(rbase + rr, B - 1) * (uint32_t)D + (uint32_t)colc];
+                }
+            }
+        }
+        stamp(0);
+        // ---- z = d10 W^T for 32 cells x 64 genes
+        f32x16 z0 = zero16(), z1 = zero16();
+        {
+            const float* pb = Ws + l31 * ldk + 4 * hh;
+            float4 q0 = *reinterpret_cast<const float4*>(pb);
+            float4 q1 = *reinterpret_cast<const float4*>(pb + 32 * ldk);
+            if (!(ablate & 1))
+#pragma unroll
+            for (int g = 0; g < FZ_KG; ++g) {
+                if (EXACT || g < kg) {
+                    const int gn = EXACT ? ((g + 1 < FZ_KG) ? g + 1 : g) : ((g + 1 < kg) ? g + 1 : g);
+                    const float4 n0 = *reinterpret_cast<const float4*>(pb + 8 * gn);
+                    const float4 n1 = *reinterpret_cast<const float4*>(pb + 32 * ldk + 8 * gn);
+                    const float4 a = afr[g];
+                    z0 = mfma32(a.x, q0.x, z0); z1 = mfma32(a.x, q1.x, z1);
+                    z0 = mfma32(a.y, q0.y, z0); z1 = mfma32(a.y, q1.y, z1);
+                    z0 = mfma32(a.z, q0.z, z0); z1 = mfma32(a.z, q1.z, z1);
+                    z0 = mfma32(a.w, q0.w, z0); z1 = mfma32(a.w, q1.w, z1);
+                    q0 = n0; q1 = n1;
+                }
+            }
+        }
+        if (stamps) { asm volatile("" :: "v"(z0[0]), "v"(z1[15])); }
+        stamp(1);
+        // ---- next weight tile: requested now, lands while the epilogue runs
+        if (t + 1 < t1) prefetch_w(t + 1);
+        stamp(2);
+        // ---- epilogue
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = j0 + 32 * c + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                const bool ok = !EDGE || ((rbase + rr < B) && (col < D));
+                const float zz = c == 0 ? z0[r] : z1[r];
+                const float xr = fmaxf(zz + bj[c], 0.f);
+                const float e = xr - xv[c][r];
+                const float dzv = (xr > 0.f) ? coef * e : 0.f;
+                if (ok) {
+                    se += e * e;
+                    mism += ((xr > 0.1f) != (xv[c][r] > 0.1f)) ? 1.f : 0.f;
+                    if (!EDGE) {
+                        const int64_t uo = (int64_t)rr * D + j0 + 32 * c;       // wave-uniform
+                        if (xra) (xra + uo)[lane_off] = xr;
+                        if (need_grad && !(ablate & 4)) (dza + uo)[lane_off] = dzv;
+                    } else {
+                        const uint32_t off = (uint32_t)(rbase + rr) * (uint32_t)D + (uint32_t)col;
+                        if (xra) xra[off] = xr;
+                        if (need_grad) dza[off] = dzv;
+                    }
+                }
+            }
+        }
+        stamp(3);
+        if (t + 1 < t1) store_w(Wbuf + (cur ^ 1) * 64 * ldk);
+        __syncthreads();
+        stamp(4);
+        cur ^= 1;
+    }
+    if (stamps && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(part + 2 * (size_t)A * n11) ;
+        for (int i = 0; i < 5; ++i) atomicAdd(dbg + i, ph[i]);
+        atomicAdd(dbg + 5, 1ull);
+    }
+    se = wave_sum(se);
+    mism = wave_sum(mism);
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mism; }
+    __syncthreads();
+    if (tid == 0) {
+        float* p = part + ((int64_t)arm * n11 + slot_base + (int64_t)blockIdx.x * NS + ns) * 2;
+        p[0] = red[0] + red[2] + red[4] + red[6];
+        p[1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// =============================================================================================
+// d(d10) = dZ11 W11: M = cells, N = H, K = genes.  Tile 128 x 128, K tile 32, wave tile 64 x 64.
+// A = dZ11 (K contiguous, b128 fragment reads), B = W11 rows (h contiguous, b32 reads).
+// grid (ceil(B/128), KS, A) -> slabs [KS][A][B][H]
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_gd10_v2(const float* __restrict__ dz11, const float* __restrict__ params,
+                                                 int64_t per_arm, int64_t w_off, float* __restrict__ slab, int A, int B,
+                                                 int D, int H, int KS) {
+    __shared__ __attribute__((aligned(16))) float As[128 * V2_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * TN_LD];
+    const int arm = blockIdx.z, ks = blockIdx.y, b0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float* Z = dz11 + (int64_t)arm * B * D;
+    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
+    const int nkt = cdiv(D, 32);
+    const int kt0 = (int)(((int64_t)ks * nkt) / KS), kt1 = (int)(((int64_t)(ks + 1) * nkt) / KS);
+    const int r0 = tid >> 3, c4 = tid & 7;      // A staging
+    const int rr = tid >> 5, bc4 = tid & 31;    // B staging
+    const bool bok = bc4 * 4 < H;
+    const float* pa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa[i] = Z + (int64_t)min(b0 + r0 + 32 * i, B - 1) * D + c4 * 4;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+    float4 ra4[4], rb4[4];
+    auto load_tiles = [&](int kt) {
+        const bool colok = kt * 32 + c4 * 4 < D;
+        const int koff = colok ? kt * 32 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra4[i] = *reinterpret_cast<const float4*>(pa[i] + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = kt * 32 + rr + 8 * i;
+            const bool ok = bok && (j < D);
+            rb4[i] = *reinterpret_cast<const float4*>(W + (int64_t)(ok ? j : 0) * H + (ok ? bc4 * 4 : 0));
+            rb4[i] = sel4(ok, rb4[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra4[i] = sel4(colok, ra4[i]);
+    };
+    if (kt0 < kt1) load_tiles(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * V2_LD + c4 * 4]) = ra4[i];
+            *reinterpret_cast<float4*>(&Bs[(rr + 8 * i) * TN_LD + bc4 * 4]) = rb4[i];
+        }
+        __syncthreads();
+        if (kt + 1 < kt1) load_tiles(kt + 1);
+        const float* la = As + (wm * 64 + l31) * V2_LD + 4 * hh;
+        const float* lb = Bs + (4 * hh) * TN_LD + wn * 64 + l31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4*>(la + 8 * g);
+            const float4 a1 = *reinterpret_cast<const float4*>(la + 32 * V2_LD + 8 * g);
+            const float* q = lb + (8 * g) * TN_LD;
+            const float q00 = q[0], q01 = q[32], q10 = q[TN_LD], q11 = q[TN_LD + 32];
+            const float q20 = q[2 * TN_LD], q21 = q[2 * TN_LD + 32], q30 = q[3 * TN_LD], q31 = q[3 * TN_LD + 32];
+            acc[0][0] = mfma32(a0.x, q00, acc[0][0]); acc[0][1] = mfma32(a0.x, q01, acc[0][1]);
+            acc[1][0] = mfma32(a1.x, q00, acc[1][0]); acc[1][1] = mfma32(a1.x, q01, acc[1][1]);
+            acc[0][0] = mfma32(a0.y, q10, acc[0][0]); acc[0][1] = mfma32(a0.y, q11, acc[0][1]);
+            acc[1][0] = mfma32(a1.y, q10, acc[1][0]); acc[1][1] = mfma32(a1.y, q11, acc[1][1]);
+            acc[0][0] = mfma32(a0.z, q20, acc[0][0]); acc[0][1] = mfma32(a0.z, q21, acc[0][1]);
+            acc[1][0] = mfma32(a1.z, q20, acc[1][0]); acc[1][1] = mfma32(a1.z, q21, acc[1][1]);
+            acc[0][0] = mfma32(a0.w, q30, acc[0][0]); acc[0][1] = mfma32(a0.w, q31, acc[0][1]);
+            acc[1][0] = mfma32(a1.w, q30, acc[1][0]); acc[1][1] = mfma32(a1.w, q31, acc[1][1]);
+        }
+        __syncthreads();
+    }
+    float* out = slab + (((int64_t)ks * A + arm) * B) * H;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = b0 + wm * 64 + i * 32 + acc_row(r, lane);
+                const int col = wn * 64 + j * 32 + l31;
+                if (row < B && col < H) out[(int64_t)row * H + col] = acc[i][j][r];
+            }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,6 +692,12 @@ bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs)
     const mmvae_dims& d = c.d;
     return (d.D & 3) == 0 && (d.H & 3) == 0 && al16(params) && al16(x) && (xs & 3) == 0 && d.H >= 4 &&
            (int64_t)d.B * d.D < ((int64_t)1 << 30);
+}
+
+// true when forward used k_fc11_z + k_gd10_v2 (slab count ks_gd10) rather than a fused kernel (ns_fc11)
+bool fc11_split_path(const Ctx& c, const float* params, const float* x, int64_t xs) {
+    static const int fused = getenv("MMVAE_FC11_FUSED") ? atoi(getenv("MMVAE_FC11_FUSED")) : 0;
+    return fast_path_ok(c, params, x, xs) && !fused;
 }
 
 int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
@@ -451,28 +731,71 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
     return 0;
 }
 
-int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad) {
+int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad,
+                     int which /*bit0: x_rec/loss/dZ11 kernel, bit1: d(d10) GEMM*/) {
     const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
     const int ldk = rup(d.H, 8) + 4;
-    const size_t shm = (size_t)(64 * ldk * 2 + 64 * F11_LDZ2 + 8) * sizeof(float);
     const float coef = (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B;
-    const int NS = c.lay.sp.ns_fc11;
-    static const int ablate = getenv("MMVAE_ABLATE") ? atoi(getenv("MMVAE_ABLATE")) : 0;   // timing experiments only
-    hipLaunchKernelGGL(k_fc11_v2, dim3(c.lay.nblk64, NS, d.A), dim3(256), shm, c.stream, c.ws + c.lay.Dk[4], params,
-                       c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + c.lay.DZ11, c.ws + c.lay.GD10_slab,
-                       c.ws + c.lay.fc11_part, coef, need_grad, d.A, d.B, d.D, d.H, NS, ldk, ablate);
-    HIP_LAUNCH_CHECK("k_fc11_v2");
+    const int NS = L.sp.ns_fc11;
+    static const int fused = getenv("MMVAE_FC11_FUSED") ? atoi(getenv("MMVAE_FC11_FUSED")) : 0;   // A/B timing
+    if (fused) {
+        hipError_t e0 = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        if (e0 != hipSuccess) { set_error("memset: %s", hipGetErrorString(e0)); return MMVAE_E_LAUNCH; }
+        const size_t shm = (size_t)(64 * ldk * 2 + 64 * F11_LDZ2 + 8) * sizeof(float);
+        static const int ablate = getenv("MMVAE_ABLATE") ? atoi(getenv("MMVAE_ABLATE")) : 0;
+        hipLaunchKernelGGL(k_fc11_v2, dim3(L.nblk64, NS, d.A), dim3(256), shm, c.stream, c.ws + L.Dk[4], params,
+                           c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11, c.ws + L.GD10_slab,
+                           c.ws + L.fc11_part, coef, need_grad, d.A, d.B, d.D, d.H, NS, ldk, ablate, L.n11);
+        HIP_LAUNCH_CHECK("k_fc11_v2");
+        return 0;
+    }
+    if (which & 1) {
+    // loss partials: the launches below fill a subset of the reserved slots
+    hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+    if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
+    {
+        const size_t shm = (size_t)(2 * 64 * ldk + 8) * sizeof(float);
+        const int nbi = d.B / 128, nball = cdiv(d.B, 128);        // interior / all row blocks
+        const int nti = d.D / 64, ntall = cdiv(d.D, 64);          // interior / all 64-gene tiles
+        const int kgv = rup(d.H, 8) / 8;
+        static const int ablz = getenv("MMVAE_ABLATE_Z") ? atoi(getenv("MMVAE_ABLATE_Z")) : 0;   // timing experiments
+        auto launch = [&](bool edge, int nrb, int nsplit, int rb0, int tbeg, int tend, int slot_base) {
+            if (nrb <= 0 || tend <= tbeg) return;
+            nsplit = max(1, min(nsplit, tend - tbeg));
+            dim3 grid(nrb, nsplit, d.A);
+#define FZ_ARGS c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,        \
+                c.ws + L.fc11_part, L.n11, slot_base, coef, need_grad, d.A, d.B, d.D, d.H, ldk, rb0, tbeg, tend, ablz
+            if (kgv == 13 && !edge) hipLaunchKernelGGL((k_fc11_z<13, true, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            else if (kgv == 13) hipLaunchKernelGGL((k_fc11_z<13, true, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            else if (kgv == 16 && !edge) hipLaunchKernelGGL((k_fc11_z<16, true, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            else if (kgv == 16) hipLaunchKernelGGL((k_fc11_z<16, true, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            else if (!edge) hipLaunchKernelGGL((k_fc11_z<16, false, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            else hipLaunchKernelGGL((k_fc11_z<16, false, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+#undef FZ_ARGS
+        };
+        launch(false, nbi, NS, 0, 0, nti, 0);                                  // interior
+        launch(true, nball, 1, 0, nti, ntall, nbi * NS);                       // right strip (D % 64 genes)
+        launch(true, nball - nbi, nti, nbi, 0, nti, nbi * NS + nball);         // bottom strip (B % 128 cells)
+        HIP_LAUNCH_CHECK("k_fc11_z");
+    }
+    }
+    if (need_grad && (which & 2)) {
+        hipLaunchKernelGGL(k_gd10_v2, dim3(cdiv(d.B, 128), L.sp.ks_gd10, d.A), dim3(256), 0, c.stream, c.ws + L.DZ11,
+                           params, c.po.per_arm, c.po.o[26], c.ws + L.GD10_slab, d.A, d.B, d.D, d.H, L.sp.ks_gd10);
+        HIP_LAUNCH_CHECK("k_gd10_v2");
+    }
     return 0;
 }
 
-int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs) {
+int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const bool use_mask = c.h.training && c.h.x_drop > 0.f;
     const int KS = L.sp.ks_dw;
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + L.xbits);
     const int wpr = cdiv(d.D, 32);
-    {   // dW1[h][d] = sum_b dZ1[b][h] x~[b][d]   -> slab [KS][A][H][D]
+    if (which & 1) {   // dW1[h][d] = sum_b dZ1[b][h] x~[b][d]   -> slab [KS][A][H][D]
         const int tiles_n = cdiv(d.D, 128);
         dim3 grid(cdiv(d.H, 128) * tiles_n, KS, d.A);
         if (use_mask)
@@ -485,7 +808,7 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs) {
                                (int64_t)d.H * d.D, (int64_t)d.A * d.H * d.D, d.D, d.B, KS, tiles_n);
         HIP_LAUNCH_CHECK("k_tn_v2<dW1>");
     }
-    {   // [dW11 | db11][j][h] = sum_b dZ11[b][j] [d10 | 1][b][h]   -> slab [KS][A][D][DW11_LD]
+    if (which & 2) {   // [dW11 | db11][j][h] = sum_b dZ11[b][j] [d10 | 1][b][h]   -> slab [KS][A][D][DW11_LD]
         const int tiles_n = cdiv(d.H + 1, 128);
         dim3 grid(cdiv(d.D, 128) * tiles_n, KS, d.A);
         hipLaunchKernelGGL((k_tn_v2<false, true>), grid, dim3(256), 0, c.stream, c.ws + L.DZ11, (int64_t)d.B * d.D,

@@ -793,7 +793,7 @@ int launch_loss_finalize(const Ctx& c, float* loss_out) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C, c.h.beta, c.h.lam,
-                       c.ws + L.fc11_part, L.nblk64 * L.sp.ns_fc11, c.ws + L.lat_part, L.nblk32, c.ws + L.couple_part,
+                       c.ws + L.fc11_part, L.n11, c.ws + L.lat_part, L.nblk32, c.ws + L.couple_part,
                        loss_out);
     HIP_LAUNCH_CHECK("k_loss_finalize");
     // T[a][k] = sum over row blocks of T_part[blk][a][k]

@@ -194,14 +194,23 @@ int mmvae_dump_noise(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
  * mmvae_loss [+ mmvae_backward] must have run on it): for per-kernel timing with HIP events and for
  * rocprof runs.  Stages: 0 fc1 forward (split-K GEMM + epilogue), 1 fused fc11 (x_rec GEMM + loss +
  * dZ11 + d(d10) GEMM), 2 dW1 and dW11 GEMMs, 3 batched small-layer dW GEMM, 4 decoder chain forward,
- * 5 decoder chain backward, 6 latent forward, 7 latent backward, 8 gradient slab reduction (grads). */
+ * 5 decoder chain backward, 6 latent forward, 7 latent backward, 8 gradient slab reduction (grads),
+ * 9 dropout keep-mask bit image; single kernels of the fast path: 10 fc11 x_rec/loss/dZ11, 11 d(d10) GEMM,
+ * 12 dW1 GEMM, 13 [dW11|db11] GEMM, 14 fc1 GEMM without its epilogue. */
 int mmvae_debug_stage(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz, int stage,
                       const float *params, const float *x, int64_t x_arm_stride, void *ws,
                       size_t ws_bytes, float *grads, void *stream);
 
+/* Optional side stream (per host thread).  When set (non-NULL), mmvae_backward / mmvae_train_step run
+ * the [dW11 | db11] GEMM on it, concurrently with the latency-bound decoder/encoder backward chain on
+ * the main stream, fork/join by events (created lazily, one pair per host thread).  The caller owns the
+ * stream and must keep it alive; pass NULL to return to single-stream operation. */
+int mmvae_set_side_stream(void *side_stream);
+
 /* Tuning knobs (process-wide, host side): split factors of the three large GEMMs.
  * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW1/dW11 split over the batch,
- * 3 = small-layer dW split over the batch.  value 0 = auto.  Changes the workspace size. */
+ * 3 = small-layer dW split over the batch, 4 = d(d10) GEMM split over the genes.  value 0 = auto.
+ * Changes the workspace size. */
 int mmvae_set_split(int which, int value);
 
 #ifdef __cplusplus
