@@ -27,6 +27,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (before HIP init)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

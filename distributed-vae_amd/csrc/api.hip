@@ -318,6 +318,11 @@ int64_t mmvae_ws_offset(const mmvae_dims* d, int id) {
     }
 }
 
+int64_t mmvae_ws_debug_offset(const mmvae_dims* d) {
+    if (check_dims(d)) return -1;
+    return make_layout(*d).loss_scratch + 2048;
+}
+
 int mmvae_forward(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, const float* params,
                   float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride, float* x_rec, int need_grad,
                   void* ws, size_t ws_bytes, void* stream) {
@@ -402,6 +407,8 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
             if (fast_path_ok(c, params, x, x_arm_stride)) return launch_dw_big_fast(c, x, x_arm_stride, 3);
             return launch_dw_big(c, nz, x, x_arm_stride);
         case 9: return launch_make_xbits(c, nz);
+        case 20: return launch_chain_fwd_enc(c, 3, params);   // one encoder layer (fc3)
+        case 21: return launch_chain_bwd_enc(c, 3, params);
         // single kernels of the fast path (per-kernel roofline timing)
         case 10: case 11: case 12: case 13: case 14:
             if (!fast_path_ok(c, params, x, x_arm_stride)) { set_error("stage %d needs the fast path", stage); return MMVAE_E_UNSUPPORTED; }

@@ -35,15 +35,16 @@ struct ChainFwdArgs {
     int B, ld, wrows;
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
+    int64_t dbg_off;   // >= 0: workspace offset of a diagnostic stamp-counter block (bit 3 of ablate)
 };
 
 // stage W [N][K] (global, row-major) into LDS rows [0, rows_pad) x cols [0, cols_pad), zero padded.
 // 8 threads per row (128-B segments), two rows x four chunks in flight per thread, no per-element
 // branches: all loads of a pass issue before the first LDS store waits.
-__device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restrict__ W, int N, int K,
-                                        int rows_pad, int cols_pad) {
+template <bool VEC>
+__device__ __forceinline__ void stage_w_t(float* Ws, int ld, const float* __restrict__ W, int N, int K,
+                                          int rows_pad, int cols_pad) {
     const int c4n = cols_pad >> 2;
-    const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
     const int part = threadIdx.x & 7, r0 = threadIdx.x >> 3;
     for (int cb = 0; cb < c4n; cb += 32) {
         for (int row = r0; row < rows_pad; row += 64) {
@@ -52,7 +53,7 @@ __device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restri
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    v[u][j] = ldg4_bf(W, K, row + 32 * u, (cb + part + 8 * j) * 4, N, K, vec);
+                    v[u][j] = ldg4_t<VEC>(W, K, row + 32 * u, (cb + part + 8 * j) * 4, N, K);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -63,9 +64,19 @@ __device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restri
         }
     }
 }
+__device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restrict__ W, int N, int K,
+                                        int rows_pad, int cols_pad) {
+    const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+    if (vec) stage_w_t<true>(Ws, ld, W, N, K, rows_pad, cols_pad);
+    else stage_w_t<false>(Ws, ld, W, N, K, rows_pad, cols_pad);
+}
 
-__global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const float* __restrict__ params,
+__global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
                                                    float* __restrict__ ws) {
+    // Copy the argument block into registers once.  Read in place, the kernarg segment may alias the
+    // stores below as far as hipcc knows: it then re-loads fields after every store and waits vmcnt(0)
+    // before each re-load, which serialises the epilogue's stores (measured: 47 % of the kernel).
+    const ChainFwdArgs a = a_in;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                 // [32][ld]
     float* Ws = smem + 32 * a.ld;     // [wrows][ld]
@@ -74,6 +85,19 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const f
     const int B = a.B, ld = a.ld;
     const int nvalid = min(32, B - b0);
     const float* P = params + (int64_t)arm * a.per_arm;
+    const bool stamps = (a.ablate & 8) != 0 && a.dbg_off >= 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int i) {
+        if (stamps) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            ph[i] += now - tprev;
+            tprev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 
     // ---- input tile (optionally BatchNorm-normalised), zero padded to a multiple of 8 columns
     {
@@ -84,39 +108,50 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const f
         const int c4n = rup(a.K0, 8) >> 2;
         const bool vec = (a.K0 & 3) == 0;    // workspace regions are 256-B aligned, widths multiples of 4
         const int part = tid & 7, row = tid >> 3;
-        for (int cb = 0; cb < c4n; cb += 32) {
-            float4 v[4], m4[4], r4[4];
+        auto stage_x = [&](auto tag) __attribute__((always_inline)) {
+            constexpr bool V = decltype(tag)::value;
+            for (int cb = 0; cb < c4n; cb += 32) {
+                float4 v[4], m4[4], r4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = (cb + part + 8 * j) * 4;
-                v[j] = ldg4_bf(X, a.K0, b0 + row, col, B, a.K0, vec);
-                m4[j] = ldg4_bf(mu, 0, 0, col, 1, a.K0, vec);
-                r4[j] = ldg4_bf(rs, 0, 0, col, 1, a.K0, vec);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = cb + part + 8 * j;
-                float4 o = v[j];
-                if (bn) {   // padded columns: (0 - 0) * 0 = 0; rows past the batch must stay zero
-                    const bool rok = b0 + row < B;
-                    o.x = rok ? (o.x - m4[j].x) * r4[j].x : 0.f;
-                    o.y = rok ? (o.y - m4[j].y) * r4[j].y : 0.f;
-                    o.z = rok ? (o.z - m4[j].z) * r4[j].z : 0.f;
-                    o.w = rok ? (o.w - m4[j].w) * r4[j].w : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int col = (cb + part + 8 * j) * 4;
+                    v[j] = ldg4_t<V>(X, a.K0, b0 + row, col, B, a.K0);
+                    m4[j] = ldg4_t<V>(mu, 0, 0, col, 1, a.K0);
+                    r4[j] = ldg4_t<V>(rs, 0, 0, col, 1, a.K0);
                 }
-                if (c < c4n) *reinterpret_cast<float4*>(&Xs[row * ld + c * 4]) = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = cb + part + 8 * j;
+                    float4 o = v[j];
+                    if (bn) {   // padded columns: (0 - 0) * 0 = 0; rows past the batch must stay zero
+                        const bool rok = b0 + row < B;
+                        o.x = rok ? (o.x - m4[j].x) * r4[j].x : 0.f;
+                        o.y = rok ? (o.y - m4[j].y) * r4[j].y : 0.f;
+                        o.z = rok ? (o.z - m4[j].z) * r4[j].z : 0.f;
+                        o.w = rok ? (o.w - m4[j].w) * r4[j].w : 0.f;
+                    }
+                    if (c < c4n) *reinterpret_cast<float4*>(&Xs[row * ld + c * 4]) = o;
+                }
             }
-        }
+        };
+        if (vec) stage_x(VecTag{});
+        else stage_x(ScalarTag{});
     }
+    stamp(0);
     for (int l = 0; l < a.nlayers; ++l) {
-        const FwdLayer& Lr = a.L[l];
+        const FwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
         if (!(a.ablate & 2) || l == 0) stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
+        stamp(1);
         __syncthreads();
+        stamp(2);
         f32x16 acc = zero16();
         const bool active = wv * 32 < NPad;
         if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, 0, Ws, ld, wv * 32, KP / 8);
+        if (stamps) asm volatile("" :: "v"(acc[0]));
+        stamp(3);
         __syncthreads();   // every wave has finished reading Xs / Ws
+        stamp(2);
         const int col = wv * 32 + (lane & 31);
         const bool last = (l + 1 == a.nlayers);
         float vals[16];
@@ -159,7 +194,14 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a, const f
                 }
             }
         }
+        stamp(4);
         __syncthreads();
+        stamp(2);
+    }
+    if (stamps && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);
+        for (int i = 0; i < 5; ++i) atomicAdd(dbg + i, ph[i]);
+        atomicAdd(dbg + 5, 1ull);
     }
 }
 
@@ -185,8 +227,9 @@ struct ChainBwdArgs {
     int64_t per_arm;
 };
 
-__global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const float* __restrict__ params,
+__global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, const float* __restrict__ params,
                                                    float* __restrict__ ws) {
+    const ChainBwdArgs a = a_in;   // see k_chain_fwd: keep the argument block out of memory
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Gs = smem;                // [32][ld]
     float* Ws = smem + 32 * a.ld;    // [128][ld]  rows = n (output features), cols = k (input features)
@@ -198,7 +241,7 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const f
 
     // ---- prologue: dZ of the first (= last forward) layer
     {
-        const BwdLayer& L0 = a.L[0];
+        const BwdLayer L0 = a.L[0];
         const int N = L0.N, c4n = rup(N, 8) >> 2;
         const bool has_act = L0.act_off >= 0, bnb = a.bnb_sum_off >= 0;
         const float* G = ws + a.g_off + (int64_t)arm * B * N;
@@ -211,47 +254,63 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const f
         const bool vec = (N & 3) == 0;
         const int part = tid & 7, row = tid >> 3;
         const bool rok = row < nvalid;
-        for (int cb = 0; cb < c4n; cb += 32) {
+        auto stage_g = [&](auto tag) __attribute__((always_inline)) {
+            constexpr bool V = decltype(tag)::value;
+            for (int cb = 0; cb < c4n; cb += 32) {
+                float4 gq[4], avq[4], m1q[4], m2q[4], mmq[4], rrq[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = cb + part + 8 * j, col = c * 4;
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int sl = 0; sl < a.nslab; ++sl) {
-                    const float4 t = ldg4_bf(G + (int64_t)sl * a.slab_stride, N, b0 + row, col, B, N, vec);
-                    g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                for (int j = 0; j < 4; ++j) {
+                    const int col = (cb + part + 8 * j) * 4;
+                    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int sl = 0; sl < a.nslab; ++sl) {
+                        const float4 t = ldg4_t<V>(G + (int64_t)sl * a.slab_stride, N, b0 + row, col, B, N);
+                        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                    }
+                    gq[j] = g;
+                    avq[j] = ldg4_t<V>(act, N, b0 + row, col, B, N);
+                    m1q[j] = ldg4_t<V>(s1, 0, 0, col, 1, N);
+                    m2q[j] = ldg4_t<V>(s1 + (bnb ? N : 0), 0, 0, col, 1, N);
+                    mmq[j] = ldg4_t<V>(mu, 0, 0, col, 1, N);
+                    rrq[j] = ldg4_t<V>(rs, 0, 0, col, 1, N);
                 }
-                const float4 av = ldg4_bf(act, N, b0 + row, col, B, N, vec);
-                if (bnb) {
-                    const float4 m1 = ldg4_bf(s1, 0, 0, col, 1, N, vec), m2 = ldg4_bf(s1 + N, 0, 0, col, 1, N, vec);
-                    const float4 mm = ldg4_bf(mu, 0, 0, col, 1, N, vec), rr = ldg4_bf(rs, 0, 0, col, 1, N, vec);
-                    g.x = rr.x * (g.x - m1.x * invB - ((av.x - mm.x) * rr.x) * (m2.x * invB));
-                    g.y = rr.y * (g.y - m1.y * invB - ((av.y - mm.y) * rr.y) * (m2.y * invB));
-                    g.z = rr.z * (g.z - m1.z * invB - ((av.z - mm.z) * rr.z) * (m2.z * invB));
-                    g.w = rr.w * (g.w - m1.w * invB - ((av.w - mm.w) * rr.w) * (m2.w * invB));
-                }
-                float4 v;
-                v.x = (rok && col < N && (!has_act || av.x > 0.f)) ? g.x : 0.f;
-                v.y = (rok && col + 1 < N && (!has_act || av.y > 0.f)) ? g.y : 0.f;
-                v.z = (rok && col + 2 < N && (!has_act || av.z > 0.f)) ? g.z : 0.f;
-                v.w = (rok && col + 3 < N && (!has_act || av.w > 0.f)) ? g.w : 0.f;
-                if (c < c4n) {
-                    *reinterpret_cast<float4*>(&Gs[row * ld + col]) = v;
-                    if (rok) {
-                        float* o = dz + (int64_t)(b0 + row) * N + col;
-                        if (vec && col + 3 < N) *reinterpret_cast<float4*>(o) = v;
-                        else {
-                            if (col < N) o[0] = v.x;
-                            if (col + 1 < N) o[1] = v.y;
-                            if (col + 2 < N) o[2] = v.z;
-                            if (col + 3 < N) o[3] = v.w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = cb + part + 8 * j, col = c * 4;
+                    float4 g = gq[j];
+                    const float4 av = avq[j];
+                    if (bnb) {
+                        const float4 m1 = m1q[j], m2 = m2q[j], mm = mmq[j], rr = rrq[j];
+                        g.x = rr.x * (g.x - m1.x * invB - ((av.x - mm.x) * rr.x) * (m2.x * invB));
+                        g.y = rr.y * (g.y - m1.y * invB - ((av.y - mm.y) * rr.y) * (m2.y * invB));
+                        g.z = rr.z * (g.z - m1.z * invB - ((av.z - mm.z) * rr.z) * (m2.z * invB));
+                        g.w = rr.w * (g.w - m1.w * invB - ((av.w - mm.w) * rr.w) * (m2.w * invB));
+                    }
+                    float4 v;
+                    v.x = (rok && col < N && (!has_act || av.x > 0.f)) ? g.x : 0.f;
+                    v.y = (rok && col + 1 < N && (!has_act || av.y > 0.f)) ? g.y : 0.f;
+                    v.z = (rok && col + 2 < N && (!has_act || av.z > 0.f)) ? g.z : 0.f;
+                    v.w = (rok && col + 3 < N && (!has_act || av.w > 0.f)) ? g.w : 0.f;
+                    if (c < c4n) {
+                        *reinterpret_cast<float4*>(&Gs[row * ld + col]) = v;
+                        if (rok) {
+                            float* o = dz + (int64_t)(b0 + row) * N + col;
+                            if (V && col + 3 < N) *reinterpret_cast<float4*>(o) = v;
+                            else {
+                                if (col < N) o[0] = v.x;
+                                if (col + 1 < N) o[1] = v.y;
+                                if (col + 2 < N) o[2] = v.z;
+                                if (col + 3 < N) o[3] = v.w;
+                            }
                         }
                     }
                 }
             }
-        }
+        };
+        if (vec) stage_g(VecTag{});
+        else stage_g(ScalarTag{});
     }
     for (int l = 0; l < a.nlayers; ++l) {
-        const BwdLayer& Lr = a.L[l];
+        const BwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, NP8 = rup(N, 8), KPad = rup(K, 32);
         stage_w(Ws, ld, P + Lr.w_off, N, K, NP8, KPad);
         __syncthreads();
@@ -271,7 +330,7 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a, const f
             const f32x16 acc = accs[ti];
             const int col = ct * 32 + (lane & 31);
             if (!last) {
-                const BwdLayer& Ln = a.L[l + 1];   // its N == this K
+                const BwdLayer Ln = a.L[l + 1];   // its N == this K
                 const float* act = Ln.act_off >= 0 ? ws + Ln.act_off + (int64_t)arm * B * K : nullptr;
                 float* dz = ws + Ln.dz_off + (int64_t)arm * B * K;
                 float av[16];
@@ -372,9 +431,11 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params) {
     a.bn_rstd_off = L.bn_rstd[i - 1];
     a.stats_part_off = L.bn_part[i];
     a.B = d.B;
-    a.ld = fwd_ld(d.H);
+    a.ld = fwd_ld(max(d.H, N));
     a.wrows = rup(N, 32);
     a.per_arm = c.po.per_arm;
+    a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
+    a.dbg_off = L.loss_scratch + 2048;
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws);
     HIP_LAUNCH_CHECK("k_chain_fwd<enc>");
@@ -400,6 +461,7 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.wrows = rup(max(d.H, d.L), 32);
     a.per_arm = c.po.per_arm;
     a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
+    a.dbg_off = L.loss_scratch + 2048;
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws);
     HIP_LAUNCH_CHECK("k_chain_fwd<dec>");

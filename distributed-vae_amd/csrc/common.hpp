@@ -192,14 +192,15 @@ __device__ __forceinline__ void mma_tn(f32x16& acc, const float* Pk, int ldp, in
 }
 
 // Branch-free [1 x 4] load of a row-major matrix, zero outside [R, Cn].  Addresses are clamped and the
-// result selected, so a tile's loads issue back to back (a per-element `if` makes hipcc wait
-// vmcnt(0) per load).  `vec` must be block-uniform: ld % 4 == 0, Cn % 4 == 0, col % 4 == 0, base aligned.
-__device__ __forceinline__ float4 ldg4_bf(const float* __restrict__ m, int64_t ld, int row, int col, int R, int Cn,
-                                          bool vec) {
+// result selected, so a tile's loads issue back to back (a per-element `if`, or even a uniform
+// vec/scalar `if` around each load, makes hipcc wait vmcnt(0) per load).  VEC: ld % 4 == 0,
+// Cn % 4 == 0, col % 4 == 0, base 16-byte aligned -- decide it once per tile, outside the loads.
+template <bool VEC>
+__device__ __forceinline__ float4 ldg4_t(const float* __restrict__ m, int64_t ld, int row, int col, int R, int Cn) {
     const bool rok = row < R;
     const float* p = m + (int64_t)(rok ? row : 0) * ld;
     float4 v;
-    if (vec) {
+    if (VEC) {
         const bool ok = rok && (col < Cn);
         v = *reinterpret_cast<const float4*>(p + (ok ? col : 0));
         v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
@@ -210,6 +211,8 @@ __device__ __forceinline__ float4 ldg4_bf(const float* __restrict__ m, int64_t l
     v.x = o0 ? v.x : 0.f; v.y = o1 ? v.y : 0.f; v.z = o2 ? v.z : 0.f; v.w = o3 ? v.w : 0.f;
     return v;
 }
+struct VecTag { static constexpr bool value = true; };
+struct ScalarTag { static constexpr bool value = false; };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

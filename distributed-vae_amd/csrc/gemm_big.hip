@@ -345,7 +345,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
     __shared__ __attribute__((aligned(16))) float Ps[BK * LDA];
     __shared__ __attribute__((aligned(16))) float Qs[BK * LDB];
     const int di = blockIdx.z % ndesc, arm = blockIdx.z / ndesc, ks = blockIdx.y;
-    const TnDesc& d = descs.d[di];
+    // field-by-field into registers: read in place, the kernarg block is re-loaded after every store
+    // (hipcc cannot rule out aliasing); copied as a whole with a runtime index it lands in scratch
+    const TnDesc& dr = descs.d[di];
+    const TnDesc d = {dr.P, dr.p_arm_stride, dr.ldp, dr.Mv, dr.Q, dr.q_arm_stride, dr.ldq, dr.Nv, dr.q_ones, dr.q_xmask,
+                      dr.q_mean, dr.q_rstd, dr.out, dr.out_arm_stride, dr.out_ks_stride, dr.ldo};
     const int tiles_n = cdiv(d.Nv + d.q_ones, TB);
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
     if (tm * TA >= d.Mv) return;
@@ -368,18 +372,24 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
     float4 rp[PA4], rq[QB4];
     const bool pv = pvec && ((d.Mv & 3) == 0);
     const bool qv = qvec && ((d.Nv & 3) == 0);
-    auto load_tiles = [&](int bt) {
+    auto load_tiles_t = [&](int bt, auto ptag, auto qtag) __attribute__((always_inline)) {
+        constexpr bool PV = decltype(ptag)::value, QV = decltype(qtag)::value;
         const int r0 = bt * BK;
 #pragma unroll
         for (int i = 0; i < PA4; ++i) {
             const int idx = tid + i * 256, row = idx / (TA / 4), c4 = idx % (TA / 4);
-            rp[i] = ldg4_bf(P, d.ldp, r0 + row, m0 + c4 * 4, B, d.Mv, pv);
+            rp[i] = ldg4_t<PV>(P, d.ldp, r0 + row, m0 + c4 * 4, B, d.Mv);
+        }
+#pragma unroll
+        for (int i = 0; i < QB4; ++i) {
+            const int idx = tid + i * 256, row = idx / (TB / 4), c4 = idx % (TB / 4);
+            rq[i] = ldg4_t<QV>(Q, d.ldq, r0 + row, n0 + c4 * 4, B, d.Nv);
         }
 #pragma unroll
         for (int i = 0; i < QB4; ++i) {
             const int idx = tid + i * 256, row = idx / (TB / 4), c4 = idx % (TB / 4);
             const int gr = r0 + row, gc = n0 + c4 * 4;
-            float4 v = ldg4_bf(Q, d.ldq, gr, gc, B, d.Nv, qv);
+            float4 v = rq[i];
             if (d.q_xmask) v = apply_xmask(v, nz, 1, arm, gr, gc, B, d.Nv, qvec);
             if (d.q_mean) {   // uniform branch; clamped, unconditional loads inside
                 const float* mu = d.q_mean + (int64_t)arm * d.Nv;
@@ -404,6 +414,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
             }
             rq[i] = v;
         }
+    };
+    auto load_tiles = [&](int bt) __attribute__((always_inline)) {
+        if (pv && qv) load_tiles_t(bt, VecTag{}, VecTag{});
+        else if (pv) load_tiles_t(bt, VecTag{}, ScalarTag{});
+        else if (qv) load_tiles_t(bt, ScalarTag{}, VecTag{});
+        else load_tiles_t(bt, ScalarTag{}, ScalarTag{});
     };
     auto store_tiles = [&]() {
 #pragma unroll

@@ -150,8 +150,10 @@ __device__ __forceinline__ void lat_stage_weights(float* WcT, float* Wm, const f
 }
 
 // grid (ceil(B/32), A), 1024 threads; wave w handles rows b0 + w, b0 + w + 16
-__global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
-                                                  float* __restrict__ ws) {
+__global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const NoiseDev nz_in,
+                                                  const float* __restrict__ params, float* __restrict__ ws) {
+    const LatArgs a = a_in;      // argument blocks into registers once (see k_chain_fwd)
+    const NoiseDev nz = nz_in;
     extern __shared__ __attribute__((aligned(16))) float lat_smem[];
     __shared__ float sh_mean[LAT_NW][CPL * 64], sh_m2[LAT_NW][CPL * 64], sh_cnt[LAT_NW], sh_red[LAT_NW][2];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
@@ -488,8 +490,10 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
 // ---------------------------------------------------------------------------------------------
 // backward of the latent block.  grid (ceil(B/32), A), 256 threads, one wave per cell.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a, NoiseDev nz, const float* __restrict__ params,
-                                                  float* __restrict__ ws) {
+__global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const NoiseDev nz_in,
+                                                  const float* __restrict__ params, float* __restrict__ ws) {
+    const LatArgs a = a_in;
+    const NoiseDev nz = nz_in;
     extern __shared__ __attribute__((aligned(16))) float lat_smem[];
     __shared__ float sh_s[LAT_NW][2][64];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
@@ -672,7 +676,8 @@ struct RedDescs { RedDesc d[MAX_RED]; };
 __global__ void k_reduce(const RedDescs ds, int KSbig, int KSsmall, int nbig, float* __restrict__ grads,
                          int64_t per_arm) {
     const int di = blockIdx.y, arm = blockIdx.z;
-    const RedDesc& d = ds.d[di];
+    const RedDesc& dr = ds.d[di];
+    const RedDesc d = {dr.slab, dr.ks_stride, dr.arm_stride, dr.ld, dr.col0, dr.rows, dr.cols, dr.dst_off, dr.dst_ld, dr.scale};
     const int KS = di < nbig ? KSbig : KSsmall;
     const int64_t n = (int64_t)d.rows * d.cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

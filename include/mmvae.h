@@ -143,6 +143,9 @@ int mmvae_param_layout(const mmvae_dims *d, mmvae_param_layout_t *out);
 size_t mmvae_workspace_bytes(const mmvae_dims *d);
 /* offset (in floats) of a named region inside the workspace, or -1 */
 int64_t mmvae_ws_offset(const mmvae_dims *d, int ws_id);
+/* offset (in floats) of a 1024-float block inside the workspace that only diagnostic builds write
+ * (in-kernel cycle stamps, enabled by environment switches; never read by any kernel) */
+int64_t mmvae_ws_debug_offset(const mmvae_dims *d);
 
 /* ---- compute (device pointers, asynchronous on stream) ----------------------------------- */
 
