@@ -34,7 +34,7 @@ Splits default_splits(const mmvae_dims& d) {
     s.ks_fc1 = g_split[0] > 0 ? g_split[0] : (fastdims ? fit(nb128 * d.A, 3 * CUS, 16) : fit(nb64 * d.A, 4 * CUS, 16));
     s.ks_fc1 = min(s.ks_fc1, max(1, cdiv(d.D, 32)));
     // fc11 x_rec/loss/dZ11 kernel: 128-row blocks, 2 workgroups / CU (general fused kernel: 64-row blocks)
-    s.ns_fc11 = g_split[1] > 0 ? g_split[1] : (fastdims ? fit(max(1, d.B / 128) * d.A, 2 * CUS, 16) : fit(nb64 * d.A, 2 * CUS, 16));
+    s.ns_fc11 = g_split[1] > 0 ? g_split[1] : (fastdims ? fit(nb128 * d.A, 2 * CUS, 16) : fit(nb64 * d.A, 2 * CUS, 16));
     s.ns_fc11 = min(s.ns_fc11, max(1, cdiv(d.D, 64)));
     // dW1 / dW11: 128-gene tiles, 4 workgroups / CU
     s.ks_dw = g_split[2] > 0 ? g_split[2] : fit(cdiv(d.D, fastdims ? 128 : 64) * d.A, 4 * CUS, 16);
@@ -202,7 +202,7 @@ static thread_local hipStream_t g_side = nullptr;
 static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
 
 static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs,
-                       float grad_scale, float* grads) {
+                       float grad_scale, float* grads, const AdamHost* adam = nullptr) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
     // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain
@@ -241,7 +241,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     }
     if ((rc = launch_dw_small(c))) return rc;
     if (forked && hipStreamWaitEvent(c.stream, g_ev_join, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
-    return launch_reduce_grads(c, grads, grad_scale);
+    return launch_reduce_grads(c, grads, grad_scale, adam);
 }
 
 }  // namespace mmvae
@@ -376,14 +376,14 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
     int rc;
     if ((rc = do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, nullptr, 1))) return rc;
     if ((rc = do_loss(c, loss_out))) return rc;
-    if ((rc = do_backward(c, nz, params, x, x_arm_stride, 1.f, grads))) return rc;
     if (do_adam) {
+        // the Adam update rides on the slab reduction (alignment gaps of the flat buffers hold zeros and
+        // need no update)
         if (!exp_avg || !exp_avg_sq || step < 1) { set_error("adam state missing"); return MMVAE_E_BADARG; }
-        const int64_t n = c.po.per_arm * d->A;
-        return launch_adam(n, params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, adam_eps, weight_decay,
-                           decoupled, c.stream);
+        const AdamHost ah{params, exp_avg, exp_avg_sq, step, lr, beta1, beta2, adam_eps, weight_decay, decoupled};
+        return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, &ah);
     }
-    return 0;
+    return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads);
 }
 
 int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, int stage,

@@ -321,7 +321,9 @@ int launch_chain_bwd_enc(const Ctx& c, int layer /*5..2*/, const float* params);
 int launch_bn_bwd_apply1(const Ctx& c);
 int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t xs);
 int launch_dw_small(const Ctx& c);
-int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale);
+struct AdamHost { float* p; float* m; float* v; int64_t step; float lr, b1, b2, eps, wd; int decoupled; };
+// slabs -> grads; with `adam` (p != null) the Adam update is fused into the same pass
+int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale, const AdamHost* adam = nullptr);
 int launch_adam(int64_t n, float* p, const float* g, float* m, float* v, int64_t step, float lr, float b1,
                 float b2, float eps, float wd, int decoupled, hipStream_t s);
 bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs);

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d1
 // =============================================================================================
 // FZ_KG: K groups of 8 held in registers.  EXACT: rup(H,8)/8 == FZ_KG, so the MFMA stream has no
 // per-group branch (a runtime bound splits it into 8-MFMA pieces each waiting on its own LDS reads).
-template <int FZ_KG, bool EXACT, bool EDGE>
+template <int FZ_KG, bool EXACT>
 __global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10, const float* __restrict__ params,
                                                    int64_t per_arm, int64_t w_off, int64_t b_off,
                                                    const float* __restrict__ x, int64_t x_arm_stride,
@@ -425,8 +425,9 @@ __global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10
                                                    float* __restrict__ part, int n11, int slot_base, float coef,
                                                    int need_grad, int A, int B, int D, int H, int ldk, int rb0, int tbeg,
                                                    int tend, int ablate) {
-    // grid (row blocks, column splits, A).  EDGE = false: every cell row and gene column touched is
-    // in range (no clamps, no predicates, wave-uniform address bases); EDGE = true: guarded strips.
+    // grid (row blocks, column splits, A).  Each 64-gene step runs one of two bodies: interior (every
+    // cell row and gene column in range: no clamps, no predicates, wave-uniform address bases) or edge
+    // (last row block / last partial gene tile: guarded).
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wbuf = smem;                     // [2][64][ldk]
     float* red = smem + 2 * 64 * ldk;       // [8]
@@ -498,7 +499,8 @@ __global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10
         }
     };
     if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-    for (int t = t0; t < t1; ++t) {
+    auto tile_step = [&](int t, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         const int j0 = t * 64;
         const float* Ws = Wbuf + cur * 64 * ldk;
         // ---- request x for both 32-gene halves (C layout: lane = gene, register = cell)
@@ -580,7 +582,11 @@ __global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10
         __syncthreads();
         stamp(4);
         cur ^= 1;
-    }
+    };
+    // interior steps first, then the guarded ones (two loops: the bodies' live ranges do not overlap)
+    const int t_mid = (b0 + 128 > B) ? t0 : max(t0, min(t1, D / 64));
+    for (int t = t0; t < t_mid; ++t) tile_step(t, ScalarTag{});      // ScalarTag::value == false: interior body
+    for (int t = t_mid; t < t1; ++t) tile_step(t, VecTag{});         // VecTag::value == true: edge body
     if (stamps && lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(part + 2 * (size_t)A * n11) ;
         for (int i = 0; i < 5; ++i) atomicAdd(dbg + i, ph[i]);
@@ -756,27 +762,17 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
     if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
     {
         const size_t shm = (size_t)(2 * 64 * ldk + 8) * sizeof(float);
-        const int nbi = d.B / 128, nball = cdiv(d.B, 128);        // interior / all row blocks
-        const int nti = d.D / 64, ntall = cdiv(d.D, 64);          // interior / all 64-gene tiles
+        const int nball = cdiv(d.B, 128), ntall = cdiv(d.D, 64);
         const int kgv = rup(d.H, 8) / 8;
         static const int ablz = getenv("MMVAE_ABLATE_Z") ? atoi(getenv("MMVAE_ABLATE_Z")) : 0;   // timing experiments
-        auto launch = [&](bool edge, int nrb, int nsplit, int rb0, int tbeg, int tend, int slot_base) {
-            if (nrb <= 0 || tend <= tbeg) return;
-            nsplit = max(1, min(nsplit, tend - tbeg));
-            dim3 grid(nrb, nsplit, d.A);
+        const int nsplit = max(1, min(NS, ntall));
+        dim3 grid(nball, nsplit, d.A);
 #define FZ_ARGS c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,        \
-                c.ws + L.fc11_part, L.n11, slot_base, coef, need_grad, d.A, d.B, d.D, d.H, ldk, rb0, tbeg, tend, ablz
-            if (kgv == 13 && !edge) hipLaunchKernelGGL((k_fc11_z<13, true, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-            else if (kgv == 13) hipLaunchKernelGGL((k_fc11_z<13, true, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-            else if (kgv == 16 && !edge) hipLaunchKernelGGL((k_fc11_z<16, true, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-            else if (kgv == 16) hipLaunchKernelGGL((k_fc11_z<16, true, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-            else if (!edge) hipLaunchKernelGGL((k_fc11_z<16, false, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-            else hipLaunchKernelGGL((k_fc11_z<16, false, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+                c.ws + L.fc11_part, L.n11, 0, coef, need_grad, d.A, d.B, d.D, d.H, ldk, 0, 0, ntall, ablz
+        if (kgv == 13) hipLaunchKernelGGL((k_fc11_z<13, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+        else if (kgv == 16) hipLaunchKernelGGL((k_fc11_z<16, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+        else hipLaunchKernelGGL((k_fc11_z<16, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
 #undef FZ_ARGS
-        };
-        launch(false, nbi, NS, 0, 0, nti, 0);                                  // interior
-        launch(true, nball, 1, 0, nti, ntall, nbi * NS);                       // right strip (D % 64 genes)
-        launch(true, nball - nbi, nti, nbi, 0, nti, nbi * NS + nball);         // bottom strip (B % 128 cells)
         HIP_LAUNCH_CHECK("k_fc11_z");
     }
     }

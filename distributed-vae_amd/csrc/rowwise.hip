@@ -443,9 +443,24 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
                                                        const float* __restrict__ fc11_part, int n11,
                                                        const float* __restrict__ lat_part, int nblk,
                                                        const float* __restrict__ couple_part,
+                                                       const float* __restrict__ T_part, float* __restrict__ T,
                                                        float* __restrict__ out) {
     __shared__ double sh[256];
     const int tid = threadIdx.x;
+    if (blockIdx.x > 0) {
+        // blocks 1.. : T[a][k] = sum over row blocks of T_part[blk][a][k]  (8 block groups x 32 columns)
+        const int c = tid & 31, g = tid >> 5, i = (blockIdx.x - 1) * 32 + c, n = A * C;
+        double s = 0.0;
+        if (i < n)
+            for (int b = g; b < nblk; b += 8) s += T_part[(int64_t)b * n + i];
+        sh[g * 32 + c] = s;
+        __syncthreads();
+        if (g == 0 && i < n) {
+            for (int k = 1; k < 8; ++k) s += sh[k * 32 + c];
+            T[i] = (float)s;
+        }
+        return;
+    }
     const double PI2 = 6.283185307179586;
     double sum_ind = 0.0, sum_ent = 0.0;
     for (int a = 0; a < A; ++a) {
@@ -673,8 +688,16 @@ struct RedDesc {
 constexpr int MAX_RED = 28;
 struct RedDescs { RedDesc d[MAX_RED]; };
 
+struct AdamArgs {
+    float* p; float* m; float* v;        // null p: gradients only
+    float lr_bc1, inv_sqrt_bc2, b1, b2, eps, wd, lr;
+    int decoupled;
+};
+
+// grid (blocks, ndesc, A): descriptor y, arm z; the first `nbig` descriptors use KSbig slabs.  With
+// adam.p != null the Adam/AdamW update of the element is applied in the same pass (single-GPU step).
 __global__ void k_reduce(const RedDescs ds, int KSbig, int KSsmall, int nbig, float* __restrict__ grads,
-                         int64_t per_arm) {
+                         int64_t per_arm, const AdamArgs adam) {
     const int di = blockIdx.y, arm = blockIdx.z;
     const RedDesc& dr = ds.d[di];
     const RedDesc d = {dr.slab, dr.ks_stride, dr.arm_stride, dr.ld, dr.col0, dr.rows, dr.cols, dr.dst_off, dr.dst_ld, dr.scale};
@@ -685,7 +708,21 @@ __global__ void k_reduce(const RedDescs ds, int KSbig, int KSsmall, int nbig, fl
         const float* p = d.slab + (int64_t)arm * d.arm_stride + (int64_t)r * d.ld + d.col0 + cidx;
         float s = 0.f;
         for (int k = 0; k < KS; ++k) s += p[(int64_t)k * d.ks_stride];
-        grads[(int64_t)arm * per_arm + d.dst_off + (int64_t)r * d.dst_ld + cidx] = s * d.scale;
+        const int64_t o = (int64_t)arm * per_arm + d.dst_off + (int64_t)r * d.dst_ld + cidx;
+        float gi = s * d.scale;
+        grads[o] = gi;
+        if (adam.p) {
+            float pi = adam.p[o];
+            if (adam.wd != 0.f) {
+                if (adam.decoupled) pi *= (1.f - adam.lr * adam.wd);
+                else gi += adam.wd * pi;
+            }
+            const float mi = adam.b1 * adam.m[o] + (1.f - adam.b1) * gi;
+            const float vi = adam.b2 * adam.v[o] + (1.f - adam.b2) * gi * gi;
+            adam.m[o] = mi;
+            adam.v[o] = vi;
+            adam.p[o] = pi - adam.lr_bc1 * (mi / (sqrtf(vi) * adam.inv_sqrt_bc2 + adam.eps));
+        }
     }
 }
 
@@ -797,14 +834,10 @@ int launch_couple(const Ctx& c) {
 int launch_loss_finalize(const Ctx& c, float* loss_out) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C, c.h.beta, c.h.lam,
-                       c.ws + L.fc11_part, L.n11, c.ws + L.lat_part, L.nblk32, c.ws + L.couple_part,
-                       loss_out);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1 + cdiv(d.A * d.C, 32)), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C,
+                       c.h.beta, c.h.lam, c.ws + L.fc11_part, L.n11, c.ws + L.lat_part, L.nblk32, c.ws + L.couple_part,
+                       c.ws + L.T_part, c.ws + L.T, loss_out);
     HIP_LAUNCH_CHECK("k_loss_finalize");
-    // T[a][k] = sum over row blocks of T_part[blk][a][k]
-    hipLaunchKernelGGL(k_sum_partials, dim3(1, cdiv(d.A * d.C, 32)), dim3(256), 0, c.stream, c.ws + L.T_part, L.nblk32,
-                       (int64_t)0, (int64_t)d.A * d.C, d.A * d.C, c.ws + L.T);
-    HIP_LAUNCH_CHECK("k_sum_partials<T>");
     return 0;
 }
 
@@ -827,7 +860,7 @@ int launch_bnb_finalize(const Ctx& c, int layer) {
     return 0;
 }
 
-int launch_reduce_grads(const Ctx& c, float* grads, float gscale) {
+int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost* ah) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int A = d.A, H = d.H, D = d.D, Ld = d.L, C = d.C, S = d.S;
@@ -857,16 +890,19 @@ int launch_reduce_grads(const Ctx& c, float* grads, float gscale) {
     small(9, H, H, c.po.o[22], c.po.o[23]);
     small(10, H, H, c.po.o[24], c.po.o[25]);
     small(11, H, 0, 0, c.po.o[1]);                     // fc1.b = column sums of dZ1
+    AdamArgs aa{};
+    if (ah && ah->p) {
+        const double bc1 = 1.0 - pow((double)ah->b1, (double)ah->step);
+        const double bc2 = 1.0 - pow((double)ah->b2, (double)ah->step);
+        aa = AdamArgs{ah->p, ah->m, ah->v, (float)(ah->lr / bc1), (float)(1.0 / sqrt(bc2)), ah->b1, ah->b2, ah->eps,
+                      ah->wd, ah->lr, ah->decoupled};
+    }
+    // one launch: grid.x sized for the large tensors (small ones leave most of their blocks idle at once)
     const int64_t big_elems = (int64_t)max(H, 1) * D;
-    const int gx = (int)imin64(1024, cdiv64(big_elems, 256));
-    hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, L.sp.ks_dw, L.sp.ks_small, nbig, grads,
-                       c.po.per_arm);
-    HIP_LAUNCH_CHECK("k_reduce<big>");
-    RedDescs ds2{};
-    for (int i = nbig; i < n; ++i) ds2.d[i - nbig] = ds.d[i];
-    hipLaunchKernelGGL(k_reduce, dim3(64, n - nbig, A), dim3(256), 0, c.stream, ds2, L.sp.ks_dw, L.sp.ks_small, 0, grads,
-                       c.po.per_arm);
-    HIP_LAUNCH_CHECK("k_reduce<small>");
+    const int gx = (int)imin64(256, cdiv64(big_elems, 1024));
+    hipLaunchKernelGGL(k_reduce, dim3(gx, n, A), dim3(256), 0, c.stream, ds, L.sp.ks_dw, L.sp.ks_small, nbig, grads,
+                       c.po.per_arm, aa);
+    HIP_LAUNCH_CHECK("k_reduce");
     return 0;
 }
 
