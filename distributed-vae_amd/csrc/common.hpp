@@ -256,13 +256,20 @@ struct NoiseDev {
     const uint8_t* s_mask;
     uint32_t k0, k1;       // seed
     uint32_t step_lo, step_hi;
-    uint32_t x_keep_thr;   // keep iff u32 < thr  (thr = (1-p) * 2^32, saturated)
-    uint32_t s_keep_thr;
+    uint32_t x_keep_thr;   // input dropout: keep iff u16 < thr, thr = round((1-p) * 65536) in [0, 65536]
+    uint32_t s_keep_thr;   // state dropout: keep iff u32 < thr (thr = (1-p) * 2^32, saturated)
 };
 
 __host__ __device__ inline uint32_t keep_threshold(float p_drop) {
     double k = (1.0 - (double)p_drop) * 4294967296.0;
     if (k >= 4294967295.0) return 0xFFFFFFFFu;
+    if (k <= 0.0) return 0u;
+    return (uint32_t)k;
+}
+
+__host__ __device__ inline uint32_t keep_threshold16(float p_drop) {
+    double k = (1.0 - (double)p_drop) * 65536.0 + 0.5;
+    if (k >= 65536.0) return 65536u;
     if (k <= 0.0) return 0u;
     return (uint32_t)k;
 }
@@ -285,6 +292,26 @@ __device__ __forceinline__ bool noise_keep(const NoiseDev& nz, int arm, int kind
     const u32x4 w = noise_words(nz, arm, kind, idx >> 2);
     const uint32_t v = pick(w, (int)(idx & 3));
     return thr == 0xFFFFFFFFu ? true : (v < thr);
+}
+// Input-dropout keep decision for element e of an arm's [B, D] stream: 16 random bits per element, 8
+// elements per Philox call (the B x D mask is the only noise large enough for the generator to cost
+// time: 25 M elements per arm per step).  Resolution of the keep probability: 2^-16.
+__device__ __forceinline__ bool xmask_keep16(const NoiseDev& nz, int arm, uint64_t e) {
+    const u32x4 w = noise_words(nz, arm, STREAM_XMASK, e >> 3);
+    const uint32_t word = pick(w, (int)((e >> 1) & 3));
+    const uint32_t u16 = (e & 1) ? (word >> 16) : (word & 0xFFFFu);
+    return u16 < nz.x_keep_thr;
+}
+// keep bits of the 8 elements of one Philox group (bit i <-> element 8 g + i)
+__device__ __forceinline__ uint32_t xmask_keep8(const NoiseDev& nz, int arm, uint64_t group) {
+    const u32x4 w = noise_words(nz, arm, STREAM_XMASK, group);
+    const uint32_t t = nz.x_keep_thr;
+    uint32_t b = 0;
+    b |= ((w.x & 0xFFFFu) < t) ? 1u : 0u;   b |= ((w.x >> 16) < t) ? 2u : 0u;
+    b |= ((w.y & 0xFFFFu) < t) ? 4u : 0u;   b |= ((w.y >> 16) < t) ? 8u : 0u;
+    b |= ((w.z & 0xFFFFu) < t) ? 16u : 0u;  b |= ((w.z >> 16) < t) ? 32u : 0u;
+    b |= ((w.w & 0xFFFFu) < t) ? 64u : 0u;  b |= ((w.w >> 16) < t) ? 128u : 0u;
+    return b;
 }
 #endif  // __HIPCC__
 

@@ -52,20 +52,11 @@ __device__ __forceinline__ float4 apply_xmask(float4 v, const NoiseDev& nz, int 
             if (col + 3 < D) v.w = m[3] ? v.w : 0.f;
         }
     } else {
-        const uint32_t thr = nz.x_keep_thr;
         const int64_t e = (int64_t)row * D + col;   // element index inside this arm's stream
-        if ((e & 3) == 0) {
-            const u32x4 w = noise_words(nz, arm, STREAM_XMASK, (uint64_t)e >> 2);
-            v.x = (w.x < thr) ? v.x : 0.f;
-            v.y = (w.y < thr) ? v.y : 0.f;
-            v.z = (w.z < thr) ? v.z : 0.f;
-            v.w = (w.w < thr) ? v.w : 0.f;
-        } else {
-            v.x = noise_keep(nz, arm, STREAM_XMASK, (uint64_t)e, thr) ? v.x : 0.f;
-            v.y = noise_keep(nz, arm, STREAM_XMASK, (uint64_t)e + 1, thr) ? v.y : 0.f;
-            v.z = noise_keep(nz, arm, STREAM_XMASK, (uint64_t)e + 2, thr) ? v.z : 0.f;
-            v.w = noise_keep(nz, arm, STREAM_XMASK, (uint64_t)e + 3, thr) ? v.w : 0.f;
-        }
+        v.x = xmask_keep16(nz, arm, (uint64_t)e) ? v.x : 0.f;
+        if (col + 1 < D) v.y = xmask_keep16(nz, arm, (uint64_t)e + 1) ? v.y : 0.f;
+        if (col + 2 < D) v.z = xmask_keep16(nz, arm, (uint64_t)e + 2) ? v.z : 0.f;
+        if (col + 3 < D) v.w = xmask_keep16(nz, arm, (uint64_t)e + 3) ? v.w : 0.f;
     }
     return v;
 }
@@ -172,46 +163,88 @@ __global__ __launch_bounds__(256) void k_fc1_fwd(const float* __restrict__ x, in
 }
 
 // fc1 epilogue: R1 = relu(scale * sum_ks slab + b1), per-block column mean / M2 for BatchNorm.
-// grid (ceil(B/32), A), 256 threads: thread t -> column t & 127, rows (t >> 7) * 16 .. +16.
+// grid (ceil(B/32), A), 256 threads: thread t -> float4 column group t & 31 (columns 4c..4c+3), rows
+// (t >> 5) + 8 i, i < 4.  All KS x 4 slab loads of a thread are independent float4 loads.
 __global__ __launch_bounds__(256) void k_fc1_epi(const float* __restrict__ slab, const float* __restrict__ params,
                                                  int64_t per_arm, int64_t b_off, float scale,
                                                  float* __restrict__ R1, float* __restrict__ part, int A, int B,
                                                  int H, int KS) {
-    __shared__ float sh[2 * NP];
+    __shared__ float sh[8][NP];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
-    const int col = threadIdx.x & 127, rh = threadIdx.x >> 7;
+    const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int nvalid = min(32, B - b0);
-    float v[16];
-    float s = 0.f;
-    const float bias = (col < H) ? params[(int64_t)arm * per_arm + b_off + col] : 0.f;
+    const float* bp = params + (int64_t)arm * per_arm + b_off;
+    float bias[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = b0 + rh * 16 + i;
-        float z = 0.f;
-        if (row < B) {
-            for (int k = 0; k < KS; ++k) z += slab[(((int64_t)k * A + arm) * B + row) * NP + col];
-            z = fmaxf(scale * z + bias, 0.f);
-            if (col < H) R1[((int64_t)arm * B + row) * H + col] = z;
+    for (int j = 0; j < 4; ++j) bias[j] = (c4 * 4 + j < H) ? bp[min(c4 * 4 + j, H - 1)] : 0.f;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = b0 + rg + 8 * i;
+        const int rc = min(row, B - 1);
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < KS; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(slab + (((int64_t)k * A + arm) * B + rc) * NP + c4 * 4);
+            z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
         }
-        v[i] = (row < B) ? z : 0.f;
-        s += v[i];
+        const bool ok = row < B;
+        z.x = ok ? fmaxf(scale * z.x + bias[0], 0.f) : 0.f;
+        z.y = ok ? fmaxf(scale * z.y + bias[1], 0.f) : 0.f;
+        z.z = ok ? fmaxf(scale * z.z + bias[2], 0.f) : 0.f;
+        z.w = ok ? fmaxf(scale * z.w + bias[3], 0.f) : 0.f;
+        v[i] = z;
+        if (ok) {
+            float* o = R1 + ((int64_t)arm * B + row) * H + c4 * 4;
+            if ((H & 3) == 0) {
+                if (c4 * 4 < H) *reinterpret_cast<float4*>(o) = z;
+            } else {
+                if (c4 * 4 < H) o[0] = z.x;
+                if (c4 * 4 + 1 < H) o[1] = z.y;
+                if (c4 * 4 + 2 < H) o[2] = z.z;
+                if (c4 * 4 + 3 < H) o[3] = z.w;
+            }
+        }
     }
-    sh[rh * NP + col] = s;
-    __syncthreads();
-    const float mean = (sh[col] + sh[NP + col]) / (float)nvalid;
-    __syncthreads();
-    float m2 = 0.f;
+    // column sums over the 32 rows: 4 rows per thread, 8 row groups through LDS
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = b0 + rh * 16 + i;
-        if (row < B) { const float dlt = v[i] - mean; m2 += dlt * dlt; }
-    }
-    sh[rh * NP + col] = m2;
+    for (int i = 0; i < 4; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    *reinterpret_cast<float4*>(&sh[rg][c4 * 4]) = s;
     __syncthreads();
-    if (rh == 0 && col < H) {
+    float4 mean;
+    {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 u = *reinterpret_cast<const float4*>(&sh[g][c4 * 4]);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        const float inv = 1.f / (float)nvalid;
+        mean = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+    __syncthreads();
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (b0 + rg + 8 * i < B) {
+            const float dx = v[i].x - mean.x, dy = v[i].y - mean.y, dz = v[i].z - mean.z, dw = v[i].w - mean.w;
+            m2.x += dx * dx; m2.y += dy * dy; m2.z += dz * dz; m2.w += dw * dw;
+        }
+    }
+    *reinterpret_cast<float4*>(&sh[rg][c4 * 4]) = m2;
+    __syncthreads();
+    if (rg == 0) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 u = *reinterpret_cast<const float4*>(&sh[g][c4 * 4]);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
         float* p = part + (((int64_t)arm * gridDim.x + blk) * 2) * H;
-        p[col] = mean;
-        p[H + col] = sh[col] + sh[NP + col];
+        const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, tt[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c4 * 4 + j < H) { p[c4 * 4 + j] = mm[j]; p[H + c4 * 4 + j] = tt[j]; }
     }
 }
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ float4 mask4(float4 v, uint32_t nib) {
 
 // ---------------------------------------------------------------------------------------------
 // keep-mask bit image: bits[(arm*B + row) * wpr + w] bit i <-> gene 32 w + i.  One thread per word.
-// Same element -> random-word mapping as the general kernels (noise_words / explicit bytes).
+// Same element -> random-bits mapping as the general kernels and mmvae_dump_noise (xmask_keep16).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_make_xbits(NoiseDev nz, int A, int B, int D, int wpr, uint32_t* __restrict__ bits) {
     const int64_t n = (int64_t)A * B * wpr;
@@ -48,22 +48,16 @@ __global__ void k_make_xbits(NoiseDev nz, int A, int B, int D, int wpr, uint32_t
                 const int col = 32 * w + j;
                 if (col < D && m[col]) word |= (1u << j);
             }
-        } else if ((D & 3) == 0) {
-            for (int j = 0; j < 8; ++j) {
-                const int col = 32 * w + 4 * j;
-                if (col < D) {
-                    const u32x4 r = noise_words(nz, arm, STREAM_XMASK, (uint64_t)((int64_t)row * D + col) >> 2);
-                    const uint32_t t = nz.x_keep_thr;
-                    uint32_t nib = (r.x < t ? 1u : 0u) | (r.y < t ? 2u : 0u) | (r.z < t ? 4u : 0u) | (r.w < t ? 8u : 0u);
-                    if (t == 0xFFFFFFFFu) nib = 15u;
-                    word |= nib << (4 * j);
-                }
+        } else if ((D & 7) == 0) {
+            // 32 genes = 4 Philox groups of 8 (rows start on a group boundary)
+            for (int j = 0; j < 4; ++j) {
+                const int col = 32 * w + 8 * j;
+                if (col < D) word |= xmask_keep8(nz, arm, (uint64_t)((int64_t)row * D + col) >> 3) << (8 * j);
             }
         } else {
             for (int j = 0; j < 32; ++j) {
                 const int col = 32 * w + j;
-                if (col < D && noise_keep(nz, arm, STREAM_XMASK, (uint64_t)((int64_t)row * D + col), nz.x_keep_thr))
-                    word |= (1u << j);
+                if (col < D && xmask_keep16(nz, arm, (uint64_t)((int64_t)row * D + col))) word |= (1u << j);
             }
         }
         bits[i] = word;

@@ -36,7 +36,7 @@ NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h) {
         n.k0 = (uint32_t)nz->seed; n.k1 = (uint32_t)(nz->seed >> 32);
         n.step_lo = (uint32_t)nz->offset; n.step_hi = (uint32_t)(nz->offset >> 32);
     }
-    n.x_keep_thr = keep_threshold(h.x_drop);
+    n.x_keep_thr = keep_threshold16(h.x_drop);
     n.s_keep_thr = keep_threshold(h.s_drop);
     return n;
 }
@@ -752,7 +752,7 @@ __global__ void k_dump_noise(NoiseDev nz, int A, int B, int D, int C, int S, uin
     if (x_mask)
         for (int64_t i = i0; i < nx; i += stride) {
             const int arm = (int)(i / ((int64_t)B * D));
-            x_mask[i] = noise_keep(nz, arm, STREAM_XMASK, (uint64_t)(i % ((int64_t)B * D)), nz.x_keep_thr) ? 1 : 0;
+            x_mask[i] = xmask_keep16(nz, arm, (uint64_t)(i % ((int64_t)B * D))) ? 1 : 0;
         }
     if (u_gumbel)
         for (int64_t i = i0; i < ng; i += stride) {

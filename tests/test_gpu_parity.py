@@ -237,6 +237,35 @@ def test_philox_step_equals_explicit_replay():
     assert float((n3["x_mask"] != noise["x_mask"]).float().mean()) > 0.4
 
 
+@pytest.mark.parametrize("D,H", [(50, 10), (100, 12)])   # general kernels (D % 4 != 0) / fast path with D % 8 != 0
+def test_philox_replay_other_paths(D, H):
+    """Same replay check on the general (unaligned) kernels and on the fast path's D % 8 != 0 branch."""
+    U = _U()
+    from distributed_vae_amd import _native as N
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=9, state_dim=2, lowD_dim=4, n_arm=2)
+    B = 70
+    sd = R.init_state_dict(h, 4)
+    x = R.synthetic_batch(B, D).to(U.DEV)
+    res = []
+    noise = None
+    for mode in ("philox", "explicit"):
+        m = U.build_model(h, sd)
+        m.train()
+        if mode == "philox":
+            m._noise_seed, m._noise_offset = 77, 4
+        else:
+            m.set_explicit_noise(noise)
+        out = m(x.expand(2, -1, -1), 1.0, 0.0)
+        lt = m.loss(out[0], [], [], None, out[7], out[8], out[4], out[6], 0.0)
+        lt[0].backward()
+        res.append((float(lt[0]), m.flat_grad().clone()))
+        if mode == "philox":
+            noise = m._engine.dump_noise(m._hyper(1.0, False), N.make_noise(None, 77, 5))
+            assert 0.3 < float(noise["x_mask"].float().mean()) < 0.7
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_adam_kernel_matches_torch():
     U = _U()
     from distributed_vae_amd import _native as N
