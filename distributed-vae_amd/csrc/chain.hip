@@ -143,14 +143,14 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
         if (!(a.ablate & 2) || l == 0) stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
         stamp(1);
-        __syncthreads();
+        lds_barrier();
         stamp(2);
         f32x16 acc = zero16();
         const bool active = wv * 32 < NPad;
         if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, 0, Ws, ld, wv * 32, KP / 8);
         if (stamps) asm volatile("" :: "v"(acc[0]));
         stamp(3);
-        __syncthreads();   // every wave has finished reading Xs / Ws
+        lds_barrier();   // every wave has finished reading Xs / Ws
         stamp(2);
         const int col = wv * 32 + (lane & 31);
         const bool last = (l + 1 == a.nlayers);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
             }
         }
         stamp(4);
-        __syncthreads();
+        lds_barrier();
         stamp(2);
     }
     if (stamps && lane == 0) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
         const BwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, NP8 = rup(N, 8), KPad = rup(K, 32);
         stage_w(Ws, ld, P + Lr.w_off, N, K, NP8, KPad);
-        __syncthreads();
+        lds_barrier();
         // input width K may reach 255 (fc6: K = C + S): up to 8 column tiles, two per wave
         f32x16 accs[2] = {zero16(), zero16()};
 #pragma unroll
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
             const int ct = wv + 4 * ti;
             if (ct * 32 < KPad) mma_nn(accs[ti], Gs, ld, 0, Ws, ld, ct * 32, NP8 / 8);
         }
-        __syncthreads();
+        lds_barrier();
         const bool last = (l + 1 == a.nlayers);
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

@@ -214,15 +214,48 @@ __device__ __forceinline__ float4 ldg4_t(const float* __restrict__ m, int64_t ld
 struct VecTag { static constexpr bool value = true; };
 struct ScalarTag { static constexpr bool value = false; };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0), i.e. for every
+// global store the wave has in flight; after an epilogue that is several microseconds per barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Wave-wide all-reduce without LDS traffic: four DPP steps inside each row of 16 lanes (quad_perm xor 1,
+// quad_perm xor 2, row_half_mirror, row_mirror) and the gfx950 half-exchange instructions
+// v_permlane16_swap / v_permlane32_swap across rows.  (__shfl_xor lowers to ds_bpermute_b32, ~100 cycles
+// of dependent latency per step; the row-wise kernels chain ~15 reductions per cell.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <typename Op>
+__device__ __forceinline__ float wave_allreduce(float v, Op op) {
+    v = op(v, dpp_f<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = op(v, dpp_f<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = op(v, dpp_f<0x141>(v));   // row_half_mirror
+    v = op(v, dpp_f<0x140>(v));   // row_mirror: every lane holds its 16-lane row's result
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    }
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+    }
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    return wave_allreduce(v, [](float a, float b) { return a + b; });
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return wave_allreduce(v, [](float a, float b) { return fmaxf(a, b); });
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    const float f = wave_allreduce(__builtin_bit_cast(float, v), [](float a, float b) {
+        const int x = __builtin_bit_cast(int, a), y = __builtin_bit_cast(int, b);
+        return __builtin_bit_cast(float, x < y ? x : y);
+    });
+    return __builtin_bit_cast(int, f);
 }
 
 // ---- Philox4x32-10 -----------------------------------------------------------------------

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10
         }
         stamp(3);
         if (t + 1 < t1) store_w(Wbuf + (cur ^ 1) * 64 * ldk);
-        __syncthreads();
+        lds_barrier();      // LDS only: the dZ11 / x_rec stores of this step stay in flight
         stamp(4);
         cur ^= 1;
     };

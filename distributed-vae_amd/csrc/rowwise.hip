@@ -14,6 +14,7 @@
 // Wave reductions only (no MFMA): these tensors are [B, <=128] and HBM/L2 resident.
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace mmvae {
 
@@ -122,6 +123,7 @@ struct LatArgs {
     // backward only
     int64_t GZIN, GMS, GZC, G5, bnb_part5, T, c_mean, c_iv;
     float am1, beta, lam;
+    int64_t dbg_off;   // >= 0: diagnostic stamp counters (MMVAE_ABLATE_L=8)
 };
 
 __device__ __forceinline__ float gumbel_u(const NoiseDev& nz, int arm, int B, int C, int b, int col) {
@@ -168,11 +170,25 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
     const int64_t ab = (int64_t)arm * B;
     const float eps = a.eps;
 
+    const bool stamps = a.dbg_off >= 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int i) {
+        if (stamps) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            ph[i] += now - tprev;
+            tprev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
     float cnt = 0.f, cm[CPL] = {0.f, 0.f}, cM2[CPL] = {0.f, 0.f};
     float kl_acc = 0.f, ent_acc = 0.f;
     const float mu5 = lane < L ? ws[a.mean5 + arm * L + lane] : 0.f;
     const float rs5 = lane < L ? ws[a.rstd5 + arm * L + lane] : 0.f;
 
+    stamp(0);   // weight staging + statistics loads
     for (int row = wv; row < 32; row += LAT_NW) {
         const int b = b0 + row;
         if (b >= B) break;   // wave-uniform
@@ -203,6 +219,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
         float cp[CPL], cc[CPL], lc[CPL], ys[CPL], cs[CPL];
 #pragma unroll
         for (int t = 0; t < CPL; ++t) cp[t] = e[t] / ssum;
+        stamp(1);   // x_low, fcc, first softmax
         // ---- c = softmax(c_prob / tau)
         m = -INFINITY;
 #pragma unroll
@@ -250,8 +267,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
             int cand = 1 << 30;
 #pragma unroll
             for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C && ys[t] == mv) cand = min(cand, lane + 64 * t);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+            cand = wave_min_i(cand);
 #pragma unroll
             for (int t = 0; t < CPL; ++t) {
                 const float hv = (lane + 64 * t == cand) ? 1.f : 0.f;
@@ -261,6 +277,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 #pragma unroll
             for (int t = 0; t < CPL; ++t) cs[t] = ys[t];
         }
+        stamp(2);   // second softmax, Gumbel sample (noise)
         // ---- store, accumulate statistics
         cnt += 1.f;
 #pragma unroll
@@ -280,6 +297,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
                 cM2[t] += dl * (cc[t] - cm[t]);
             }
         }
+        stamp(3);   // stores + statistics
         // ---- state head: [mu | sigma_pre] = y [Wmu; Wsigma]^T + b
         float mso = 0.f;
         for (int o = 0; o < 2 * S; ++o) {
@@ -307,6 +325,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
             ws[a.ZIN + (ab + b) * (C + S) + C + lane] = sin_;
             kl_acc += 1.f + lv - mu * mu - expf(lv);
         }
+        stamp(4);   // state head
     }
     // ---- block partials
     kl_acc = wave_sum(kl_acc);
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 #pragma unroll
     for (int t = 0; t < CPL; ++t) { sh_mean[wv][lane + 64 * t] = cm[t]; sh_m2[wv][lane + 64 * t] = cM2[t]; }
     if (lane == 0) { sh_cnt[wv] = cnt; sh_red[wv][0] = kl_acc; sh_red[wv][1] = ent_acc; }
-    __syncthreads();
+    lds_barrier();
     const int col = threadIdx.x;
     if (col < C) {
         float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -337,6 +356,12 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
         for (int w = 0; w < LAT_NW; ++w) { k0 += sh_red[w][0]; k1 += sh_red[w][1]; }
         p[0] = k0;
         p[1] = k1;
+    }
+    stamp(5);   // block reduction
+    if (stamps && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);
+        for (int i = 0; i < 6; ++i) atomicAdd(dbg + i, ph[i]);
+        atomicAdd(dbg + 6, 1ull);
     }
 }
 
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(256) void k_couple(int A, int B, int C, float eps, 
 #pragma unroll
         for (int t = 0; t < CPL; ++t) shT[wv][aa][lane + 64 * t] = Tacc[aa][t];
     if (lane == 0) { sh_red[wv][0] = dist; sh_red[wv][1] = l2; }
-    __syncthreads();
+    lds_barrier();
     for (int i = threadIdx.x; i < A * C; i += 256) {
         const int aa = i / C, col = i % C;
         T_part[((int64_t)blk * A + aa) * C + col] = shT[0][aa][col] + shT[1][aa][col] + shT[2][aa][col] + shT[3][aa][col];
@@ -647,7 +672,7 @@ __global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const Nois
     }
     sh_s[wv][0][lane] = s1;
     sh_s[wv][1][lane] = s2;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < L) {
         const int k = threadIdx.x;
         float* p = ws + a.bnb_part5 + (((int64_t)arm * gridDim.x + blk) * 2) * L;
@@ -783,6 +808,8 @@ static LatArgs make_lat_args(const Ctx& c) {
     a.GZIN = L.GZIN; a.GMS = L.GMS; a.GZC = L.GZC; a.G5 = L.G[5]; a.bnb_part5 = L.bnb_part[5];
     a.T = L.T; a.c_mean = L.c_mean; a.c_iv = L.c_iv;
     a.am1 = (float)(d.A > 1 ? d.A - 1 : 1); a.beta = c.h.beta; a.lam = c.h.lam;
+    static const int abl = getenv("MMVAE_ABLATE_L") ? atoi(getenv("MMVAE_ABLATE_L")) : 0;
+    a.dbg_off = (abl & 8) ? L.loss_scratch + 2048 : -1;
     return a;
 }
 

@@ -1,0 +1,29 @@
+"""Diagnostic: per-phase shader cycles of k_lat_fwd (MMVAE_ABLATE_L=8)."""
+import os, sys, torch, ctypes as C
+os.environ["MMVAE_ABLATE_L"] = "8"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import distributed_vae_amd  # noqa
+from distributed_vae_amd import _native as N
+from distributed_vae_amd.nn_model import mixVAE_model
+A, B, D, H, L, Cc, S = 2, 5000, 5000, 100, 10, 92, 2
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(1)
+x = (torch.rand(B, D, generator=g, device=dev) < 0.2).float() * torch.randn(B, D, generator=g, device=dev).abs() * 3
+torch.manual_seed(546)
+m = mixVAE_model(input_dim=D, fc_dim=H, n_categories=Cc, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev, eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE").to(dev)
+m.train(); eng = m._ensure(B); hyper = m._hyper(1.0, False); noise = N.make_noise(None, 99, 1)
+eng.forward(hyper, noise, m._flat, m._bn_flat, None, x, 0, None, True); eng.loss(hyper); eng.backward(hyper, noise, m._flat, x, 0, m._flat_grad)
+torch.cuda.synchronize()
+L_ = N.lib(); L_.mmvae_ws_debug_offset.restype = C.c_int64; L_.mmvae_ws_debug_offset.argtypes = [C.POINTER(N.Dims)]
+off = L_.mmvae_ws_debug_offset(C.byref(eng.dims))
+dbg = eng.ws[off: off + 64].view(torch.int64)
+names = ["weights to LDS + stats loads", "x_low, fcc, softmax 1", "softmax 2 + Gumbel", "stores + c statistics", "state head", "block reduction"]
+dbg.zero_(); torch.cuda.synchronize()
+eng.debug_stage(6, hyper, noise, m._flat, x, 0, m._flat_grad)
+torch.cuda.synchronize()
+v = dbg.cpu().numpy(); nw = max(int(v[6]), 1); tot = v[:6].sum()
+print("k_lat_fwd waves", nw)
+for n_, c_ in zip(names, v[:6]):
+    print(f"  {n_:30s} {c_ / nw:10.0f} ticks/wave {100.0 * c_ / max(tot,1):5.1f}%")
+print(f"  total {tot / nw:.0f} ticks/wave")
