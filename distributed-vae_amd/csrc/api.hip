@@ -39,7 +39,7 @@ Splits default_splits(const mmvae_dims& d) {
     // dW1 / dW11: 128-gene tiles, 4 workgroups / CU
     s.ks_dw = g_split[2] > 0 ? g_split[2] : fit(cdiv(d.D, fastdims ? 128 : 64) * d.A, 4 * CUS, 16);
     s.ks_dw = min(s.ks_dw, max(1, cdiv(d.B, 32)));
-    s.ks_small = g_split[3] > 0 ? g_split[3] : fit(N_SMALL * d.A, 2 * CUS, 32);
+    s.ks_small = g_split[3] > 0 ? g_split[3] : fit(N_SMALL * d.A, 3 * CUS, 32);   // 3 workgroups / CU (136 VGPRs)
     s.ks_small = min(s.ks_small, max(1, cdiv(d.B, 32)));
     s.ks_gd10 = g_split[4] > 0 ? g_split[4] : fit(nb128 * d.A, 3 * CUS, 16);
     s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, 32)));

@@ -467,6 +467,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
         }
     };
 
+    bool live[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            live[i][j] = (m0 + wm * (TA / 2) + i * 32 < d.Mv) && (n0 + wn * (TB / 2) + j * 32 < d.Nv + d.q_ones);
     if (bt0 < bt1) load_tiles(bt0);
     for (int bt = bt0; bt < bt1; ++bt) {
         store_tiles();
@@ -474,6 +480,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
         if (bt + 1 < bt1) load_tiles(bt + 1);
         const float* pa = Ps + (lane >> 5) * LDA + wm * (TA / 2) + (lane & 31);
         const float* pb = Qs + (lane >> 5) * LDB + wn * (TB / 2) + (lane & 31);
+        // 32x32 sub-tiles that lie entirely in the zero padding (small layers: N = 10, K = 10 ...) are skipped
 #pragma unroll 4
         for (int s = 0; s < BK / 2; ++s) {
             float av[MT], bv[NT];
@@ -484,7 +491,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j)
+                    if (live[i][j]) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
         }
         __syncthreads();
     }
