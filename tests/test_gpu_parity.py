@@ -177,6 +177,54 @@ def test_vs_oracle_odd_shapes(cfg):
         assert G.rel_err(v, g_r[k]) < GRAD_TOL, k
 
 
+EDGE = [
+    # A, B, D, H, L, C, S, hard, s_drop, x_drop
+    (2, 2, 8, 4, 1, 2, 1, False, 0.0, 0.5),          # smallest legal everything (B = 2 rows for batch statistics)
+    (8, 16, 32, 8, 2, 4, 1, False, 0.0, 0.5),        # MMVAE_MAX_ARMS arms: 28 coupled pairs
+    (2, 300, 64, 128, 64, 128, 32, False, 0.5, 0.9), # every kernel limit at once, heavy dropout
+    (3, 65, 260, 36, 9, 30, 2, True, 0.0, 0.5),      # one cell past a 64-row block, 4 genes past a 64-gene tile
+]
+
+
+@pytest.mark.parametrize("cfg", EDGE)
+def test_vs_oracle_edge_shapes(cfg):
+    """Minimum sizes, maximum supported sizes and off-by-one tile boundaries against the oracle."""
+    U = _U()
+    A, B, D, H, L, C, S, hard, sdrop, xdrop = cfg
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=xdrop, s_drop=sdrop, n_arm=A,
+                hard=hard)
+    sd = R.init_state_dict(h, 21)
+    x = R.synthetic_batch(B, D, seed=8)
+    noise = R.draw_noise(h, B, seed=13)
+    out_r, lt_r, g_r = R.grads_autograd({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise)
+    m = U.build_model(h, sd)
+    m.train()
+    out, lt, grads = U.run_step(m, x.to(U.DEV), noise)
+    _loss_close(lt[0], lt_r[0], 5e-5 if B == 2 else LOSS_TOL)
+    assert G.rel_err(torch.stack([t.cpu() for t in out[0]]), torch.stack(list(out_r[0]))) < FWD_TOL
+    gmax = max(float(v.abs().max()) for v in g_r.values())
+    for k, v in grads.items():
+        if float(g_r[k].abs().max()) < 1e-6 * gmax:
+            # B = 2: BatchNorm of two rows is +-1, its backward cancels exactly; the reference only has
+            # rounding noise upstream of a BatchNorm there.  Require "negligible", not "equal noise".
+            assert float(v.abs().max()) < 1e-5 * gmax, k
+        else:
+            assert G.rel_err(v, g_r[k]) < GRAD_TOL, k
+
+
+def test_unsupported_shapes_are_rejected():
+    """Beyond the kernels' limits the engine refuses (NotImplementedError), it never degrades silently."""
+    U = _U()
+    for kw in (dict(fc_dim=129), dict(n_categories=129), dict(lowD_dim=65), dict(n_arm=9)):
+        base = dict(input_dim=32, fc_dim=8, n_categories=4, state_dim=2, lowD_dim=3, n_arm=2)
+        base.update(kw)
+        h = R.Hyper(**base)
+        m = U.build_model(h)
+        x = torch.zeros(8, 32, device=U.DEV)
+        with pytest.raises(NotImplementedError):
+            m(x.expand(h.n_arm, -1, -1), 1.0)
+
+
 def test_distinct_input_per_arm():
     """x given as a list of different tensors (augmenter-style input, cpl_mixvae.py:422-423)."""
     U = _U()
