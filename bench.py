@@ -254,9 +254,26 @@ def measure_stages(model, x, A, B, D, H):
                      "algorithmic_GBs": by(A, B, D, H) / (ms * 1e-3) / 1e9}
     dom = max(res, key=lambda k: res[k]["avg_launch_ms"])
     ach = res[dom]["tflops"]
+    traffic, src = pmc_traffic(dom, A, B, D, H)
     return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": res[dom]["avg_launch_ms"],
-            "stages": res}
+            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+            "traffic_source": src, "avg_launch_ms": res[dom]["avg_launch_ms"], "stages": res}
+
+
+def pmc_traffic(kernel, A, B, D, H):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_summary.csv, made
+    by tools/pmc_summary.py from two separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this
+    bench command). PMC counters cannot be read from inside the process, so the number is only reported for
+    the shape it was collected on; FETCH_SIZE (KB) is doubled as the gfx950 guide prescribes for 16-byte-per-
+    lane loads -- which holds for k_fc11_z only -- and WRITE_SIZE (KB) is taken as is."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_summary.csv")
+    if (A, B, D, H) != (2, 5000, 5000, 100) or kernel != "k_fc11_z" or not os.path.exists(path):
+        return None, None
+    for r in csv.DictReader(open(path)):
+        if r["kernel"].startswith(kernel) and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
+            return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0, "profiles/r01_pmc_hbm_summary.csv"
+    return None, None
 
 
 if __name__ == "__main__":

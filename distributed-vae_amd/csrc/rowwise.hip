@@ -924,10 +924,15 @@ int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost
         aa = AdamArgs{ah->p, ah->m, ah->v, (float)(ah->lr / bc1), (float)(1.0 / sqrt(bc2)), ah->b1, ah->b2, ah->eps,
                       ah->wd, ah->lr, ah->decoupled};
     }
-    // one launch: grid.x sized for the large tensors (small ones leave most of their blocks idle at once)
+    // two launches: the three large tensors want thousands of workgroups, the 23 small ones a handful
     const int64_t big_elems = (int64_t)max(H, 1) * D;
-    const int gx = (int)imin64(256, cdiv64(big_elems, 1024));
-    hipLaunchKernelGGL(k_reduce, dim3(gx, n, A), dim3(256), 0, c.stream, ds, L.sp.ks_dw, L.sp.ks_small, nbig, grads,
+    const int gx = (int)imin64(1024, cdiv64(big_elems, 256));
+    hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, L.sp.ks_dw, L.sp.ks_small, nbig, grads,
+                       c.po.per_arm, aa);
+    HIP_LAUNCH_CHECK("k_reduce<big>");
+    RedDescs ds2{};
+    for (int i = nbig; i < n; ++i) ds2.d[i - nbig] = ds.d[i];
+    hipLaunchKernelGGL(k_reduce, dim3(16, n - nbig, A), dim3(256), 0, c.stream, ds2, L.sp.ks_dw, L.sp.ks_small, 0, grads,
                        c.po.per_arm, aa);
     HIP_LAUNCH_CHECK("k_reduce");
     return 0;
