@@ -180,13 +180,13 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     } else if ((rc = launch_fc1_fwd(c, nz, params, x, xs))) {
         return rc;
     }
-    if ((rc = launch_stats_finalize(c, 0, bn_running, nbt))) return rc;
-    for (int layer = 2; layer <= 5; ++layer) {
-        if ((rc = launch_chain_fwd_enc(c, layer, params))) return rc;
-        if ((rc = launch_stats_finalize(c, layer - 1, bn_running, nbt))) return rc;
-    }
-    if ((rc = launch_lat_fwd(c, nz, params))) return rc;
-    if ((rc = launch_stats_finalize(c, 5, nullptr, nullptr))) return rc;
+    // batch statistics are recombined by the kernel that consumes each BatchNorm (no finalize launches);
+    // eval mode copies the running statistics into the workspace instead
+    for (int i = 0; i < 5; ++i)
+        if ((rc = launch_bn_eval_stats(c, i, bn_running))) return rc;
+    for (int layer = 2; layer <= 5; ++layer)
+        if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
+    if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt))) return rc;
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
     if (fast) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
     return launch_fc11_fused(c, params, x, xs, x_rec, need_grad);
@@ -228,11 +228,8 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     const int nslab = fc11_split_path(c, params, x, xs) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11;
     if ((rc = launch_chain_bwd_dec(c, params, nslab))) return rc;
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
-    if ((rc = launch_bnb_finalize(c, 5))) return rc;
-    for (int layer = 5; layer >= 2; --layer) {
+    for (int layer = 5; layer >= 2; --layer)
         if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
-        if ((rc = launch_bnb_finalize(c, layer - 1))) return rc;
-    }
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
     if (fast) {
         if ((rc = launch_dw_big_fast(c, x, xs, forked ? 1 : 3))) return rc;
@@ -407,7 +404,7 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
             if (fast_path_ok(c, params, x, x_arm_stride)) return launch_dw_big_fast(c, x, x_arm_stride, 3);
             return launch_dw_big(c, nz, x, x_arm_stride);
         case 9: return launch_make_xbits(c, nz);
-        case 20: return launch_chain_fwd_enc(c, 3, params);   // one encoder layer (fc3)
+        case 20: return launch_chain_fwd_enc(c, 3, params, nullptr, nullptr);   // one encoder layer (fc3)
         case 21: return launch_chain_bwd_enc(c, 3, params);
         // single kernels of the fast path (per-kernel roofline timing)
         case 10: case 11: case 12: case 13: case 14:
@@ -420,7 +417,7 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
         case 3: return launch_dw_small(c);
         case 4: return launch_chain_fwd_dec(c, params);
         case 5: return launch_chain_bwd_dec(c, params, fc11_split_path(c, params, x, x_arm_stride) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11);
-        case 6: return launch_lat_fwd(c, nz, params);
+        case 6: return launch_lat_fwd(c, nz, params, nullptr, nullptr);
         case 7: return launch_lat_bwd(c, nz, params);
         case 8: if (!grads) { set_error("grads is null"); return MMVAE_E_BADARG; } return launch_reduce_grads(c, grads, 1.f);
         default: set_error("unknown stage %d", stage); return MMVAE_E_BADARG;

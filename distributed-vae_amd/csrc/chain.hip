@@ -31,6 +31,10 @@ struct ChainFwdArgs {
     int64_t x_off;          // workspace, [A,B,K0]
     int K0;
     int64_t bn_mean_off, bn_rstd_off;   // [A,K0] or -1: input is BatchNorm(x)
+    int64_t bn_part_off;                // >= 0 (training): [A][nblk][2][K0] partials of x to recombine here
+    int64_t run_mean_off, run_var_off, run_arm_stride;   // inside bn_running (updated by row block 0)
+    int bn_idx;
+    float bn_eps, bn_momentum;
     int64_t stats_part_off;             // [A][nblk][2][N_last] or -1
     int B, ld, wrows;
     int64_t per_arm;
@@ -72,7 +76,8 @@ __device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restri
 }
 
 __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
-                                                   float* __restrict__ ws) {
+                                                   float* __restrict__ ws, float* __restrict__ bn_running,
+                                                   int64_t* __restrict__ nbt) {
     // Copy the argument block into registers once.  Read in place, the kernarg segment may alias the
     // stores below as far as hipcc knows: it then re-loads fields after every store and waits vmcnt(0)
     // before each re-load, which serialises the epilogue's stores (measured: 47 % of the kernel).
@@ -80,6 +85,8 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                 // [32][ld]
     float* Ws = smem + 32 * a.ld;     // [wrows][ld]
+    float* mean_s = Ws + a.wrows * a.ld;   // [128]
+    float* rstd_s = mean_s + 128;          // [128]
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int B = a.B, ld = a.ld;
@@ -99,36 +106,65 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
     };
     if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 
+    // ---- statistics of the input's BatchNorm: recombined from the producer's partials (training) or
+    //      the running buffers' values left in the workspace (eval); zero beyond K0
+    if (a.bn_mean_off >= 0) {
+        const int K0 = a.K0;
+        float mean = 0.f, rstd = 0.f;
+        if (a.bn_part_off >= 0) {
+            float m2;
+            unsigned long long st[5] = {0, 0, 0, 0, 0};
+            stats_from_partials<256>(ws + a.bn_part_off + (int64_t)arm * gridDim.x * 2 * K0, gridDim.x, B, K0, Ws, mean, m2,
+                                     stamps ? st : nullptr);
+            if (stamps && lane == 0) {
+                unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);
+                for (int i = 0; i < 4; ++i) atomicAdd(dbg + 8 + i, st[i + 1] - st[i]);
+            }
+            rstd = 1.0f / sqrtf(m2 / (float)B + a.bn_eps);
+            if (blk == 0 && tid < K0) {
+                ws[a.bn_mean_off + (int64_t)arm * K0 + tid] = mean;
+                ws[a.bn_rstd_off + (int64_t)arm * K0 + tid] = rstd;
+                if (bn_running) {
+                    float* rm = bn_running + a.run_mean_off + arm * a.run_arm_stride;
+                    float* rv = bn_running + a.run_var_off + arm * a.run_arm_stride;
+                    rm[tid] = (1.f - a.bn_momentum) * rm[tid] + a.bn_momentum * mean;
+                    rv[tid] = (1.f - a.bn_momentum) * rv[tid] + a.bn_momentum * (m2 / (float)max(B - 1, 1));
+                }
+                if (nbt && tid == 0) nbt[arm * MMVAE_N_BN + a.bn_idx] += 1;
+            }
+        } else if (tid < K0) {
+            mean = ws[a.bn_mean_off + (int64_t)arm * K0 + tid];
+            rstd = ws[a.bn_rstd_off + (int64_t)arm * K0 + tid];
+        }
+        if (tid < 128) { mean_s[tid] = tid < K0 ? mean : 0.f; rstd_s[tid] = tid < K0 ? rstd : 0.f; }
+        lds_barrier();
+    }
     // ---- input tile (optionally BatchNorm-normalised), zero padded to a multiple of 8 columns
     {
         const float* X = ws + a.x_off + (int64_t)arm * B * a.K0;
         const bool bn = a.bn_mean_off >= 0;
-        const float* mu = bn ? ws + a.bn_mean_off + (int64_t)arm * a.K0 : X;
-        const float* rs = bn ? ws + a.bn_rstd_off + (int64_t)arm * a.K0 : X;
         const int c4n = rup(a.K0, 8) >> 2;
         const bool vec = (a.K0 & 3) == 0;    // workspace regions are 256-B aligned, widths multiples of 4
         const int part = tid & 7, row = tid >> 3;
         auto stage_x = [&](auto tag) __attribute__((always_inline)) {
             constexpr bool V = decltype(tag)::value;
             for (int cb = 0; cb < c4n; cb += 32) {
-                float4 v[4], m4[4], r4[4];
+                float4 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = (cb + part + 8 * j) * 4;
-                    v[j] = ldg4_t<V>(X, a.K0, b0 + row, col, B, a.K0);
-                    m4[j] = ldg4_t<V>(mu, 0, 0, col, 1, a.K0);
-                    r4[j] = ldg4_t<V>(rs, 0, 0, col, 1, a.K0);
-                }
+                for (int j = 0; j < 4; ++j) v[j] = ldg4_t<V>(X, a.K0, b0 + row, (cb + part + 8 * j) * 4, B, a.K0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = cb + part + 8 * j;
                     float4 o = v[j];
                     if (bn) {   // padded columns: (0 - 0) * 0 = 0; rows past the batch must stay zero
                         const bool rok = b0 + row < B;
-                        o.x = rok ? (o.x - m4[j].x) * r4[j].x : 0.f;
-                        o.y = rok ? (o.y - m4[j].y) * r4[j].y : 0.f;
-                        o.z = rok ? (o.z - m4[j].z) * r4[j].z : 0.f;
-                        o.w = rok ? (o.w - m4[j].w) * r4[j].w : 0.f;
+                        const int cc = min(c, 31) * 4;   // BatchNorm widths are <= 128
+                        const float4 m4 = *reinterpret_cast<const float4*>(&mean_s[cc]);
+                        const float4 r4 = *reinterpret_cast<const float4*>(&rstd_s[cc]);
+                        o.x = rok ? (o.x - m4.x) * r4.x : 0.f;
+                        o.y = rok ? (o.y - m4.y) * r4.y : 0.f;
+                        o.z = rok ? (o.z - m4.z) * r4.z : 0.f;
+                        o.w = rok ? (o.w - m4.w) * r4.w : 0.f;
                     }
                     if (c < c4n) *reinterpret_cast<float4*>(&Xs[row * ld + c * 4]) = o;
                 }
@@ -218,7 +254,8 @@ struct ChainBwdArgs {
     int64_t g_off;          // [nslab][A,B,N0] gradient w.r.t. the output of L[0] (after its BN if any)
     int nslab;
     int64_t slab_stride;
-    int64_t bnb_sum_off;    // [A][2][N0] batch sums (sum G, sum G*xhat) or -1: BN backward prologue
+    int64_t bnb_part_off;   // [A][nblk][2][N0] per-row-block sums (sum G, sum G*xhat), recombined here, or -1:
+                            // BN backward prologue
     int64_t bn_mean_off, bn_rstd_off;   // statistics of L[0]'s output, [A,N0]
     int64_t gout_off;       // [A,B,Klast]
     int64_t part_off;       // [A][nblk][2][Klast] or -1: sums of gout and gout*xhat_prev
@@ -233,21 +270,31 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Gs = smem;                // [32][ld]
     float* Ws = smem + 32 * a.ld;    // [128][ld]  rows = n (output features), cols = k (input features)
+    float* sums_s = Ws + a.wrows * a.ld;   // [2][128]: sum G, sum G*xhat over the batch
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int B = a.B, ld = a.ld;
     const int nvalid = min(32, B - b0);
     const float* P = params + (int64_t)arm * a.per_arm;
 
+    if (a.bnb_part_off >= 0) {
+        const int N = a.L[0].N;
+        const float r = sums_from_partials<256>(ws + a.bnb_part_off + (int64_t)arm * gridDim.x * 2 * N, gridDim.x, 2 * N,
+                                                reinterpret_cast<double*>(Ws));
+        // thread t < 2N holds sum t of [sum G | sum G*xhat]; spread to [2][128], zero beyond N
+        sums_s[tid] = 0.f;
+        lds_barrier();
+        if (tid < 2 * N) sums_s[tid < N ? tid : 128 + tid - N] = r;
+        lds_barrier();
+    }
     // ---- prologue: dZ of the first (= last forward) layer
     {
         const BwdLayer L0 = a.L[0];
         const int N = L0.N, c4n = rup(N, 8) >> 2;
-        const bool has_act = L0.act_off >= 0, bnb = a.bnb_sum_off >= 0;
+        const bool has_act = L0.act_off >= 0, bnb = a.bnb_part_off >= 0;
         const float* G = ws + a.g_off + (int64_t)arm * B * N;
         const float* act = has_act ? ws + L0.act_off + (int64_t)arm * B * N : G;
         float* dz = ws + L0.dz_off + (int64_t)arm * B * N;
-        const float* s1 = bnb ? ws + a.bnb_sum_off + (int64_t)arm * 2 * N : G;
         const float* mu = bnb ? ws + a.bn_mean_off + (int64_t)arm * N : G;
         const float* rs = bnb ? ws + a.bn_rstd_off + (int64_t)arm * N : G;
         const float invB = 1.f / (float)B;
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
         auto stage_g = [&](auto tag) __attribute__((always_inline)) {
             constexpr bool V = decltype(tag)::value;
             for (int cb = 0; cb < c4n; cb += 32) {
-                float4 gq[4], avq[4], m1q[4], m2q[4], mmq[4], rrq[4];
+                float4 gq[4], avq[4], mmq[4], rrq[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = (cb + part + 8 * j) * 4;
@@ -268,8 +315,6 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
                     }
                     gq[j] = g;
                     avq[j] = ldg4_t<V>(act, N, b0 + row, col, B, N);
-                    m1q[j] = ldg4_t<V>(s1, 0, 0, col, 1, N);
-                    m2q[j] = ldg4_t<V>(s1 + (bnb ? N : 0), 0, 0, col, 1, N);
                     mmq[j] = ldg4_t<V>(mu, 0, 0, col, 1, N);
                     rrq[j] = ldg4_t<V>(rs, 0, 0, col, 1, N);
                 }
@@ -279,7 +324,10 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
                     float4 g = gq[j];
                     const float4 av = avq[j];
                     if (bnb) {
-                        const float4 m1 = m1q[j], m2 = m2q[j], mm = mmq[j], rr = rrq[j];
+                        const int cs = min(c, 31) * 4;   // BatchNorm widths are <= 128
+                        const float4 m1 = *reinterpret_cast<const float4*>(&sums_s[cs]);
+                        const float4 m2 = *reinterpret_cast<const float4*>(&sums_s[128 + cs]);
+                        const float4 mm = mmq[j], rr = rrq[j];
                         g.x = rr.x * (g.x - m1.x * invB - ((av.x - mm.x) * rr.x) * (m2.x * invB));
                         g.y = rr.y * (g.y - m1.y * invB - ((av.y - mm.y) * rr.y) * (m2.y * invB));
                         g.z = rr.z * (g.z - m1.z * invB - ((av.z - mm.z) * rr.z) * (m2.z * invB));
@@ -389,20 +437,28 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
     }
 }
 
-// DZ1 = BNbackward(G1) .* relu'(R1): elementwise, one thread per element
-__global__ void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ R,
-                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                               const float* __restrict__ sums, float* __restrict__ DZ, int A, int B, int W) {
-    const int64_t n = (int64_t)A * B * W;
+// DZ1 = BNbackward(G1) .* relu'(R1).  grid (ceil(B/32), A): every row block recombines the batch sums
+// (part: [A][nblk][2][W] from fc2's backward) and applies them to its 32 rows.
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ R,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ part, float* __restrict__ DZ, int B, int W) {
+    __shared__ __attribute__((aligned(16))) double scratch[1024];
+    __shared__ float sums_s[2][128], mu_s[128], rs_s[128];
+    const int arm = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const float r = sums_from_partials<256>(part + (int64_t)arm * gridDim.x * 2 * W, gridDim.x, 2 * W, scratch);
+    if (tid < 2 * W) sums_s[tid < W ? 0 : 1][tid < W ? tid : tid - W] = r;
+    if (tid < W) { mu_s[tid] = mean[arm * W + tid]; rs_s[tid] = rstd[arm * W + tid]; }
+    lds_barrier();
     const float invB = 1.f / (float)B;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % W);
-        const int arm = (int)(i / ((int64_t)B * W));
-        const float r = R[i];
-        const float mu = mean[arm * W + col], rs = rstd[arm * W + col];
-        const float xh = (r - mu) * rs;
-        const float g = rs * (G[i] - sums[(arm * 2) * W + col] * invB - xh * (sums[(arm * 2 + 1) * W + col] * invB));
-        DZ[i] = r > 0.f ? g : 0.f;
+    const int nvalid = min(32, B - blk * 32);
+    const int64_t base = ((int64_t)arm * B + (int64_t)blk * 32) * W;
+    for (int i = tid; i < nvalid * W; i += 256) {
+        const int col = i % W;
+        const float rv = R[base + i];
+        const float rs = rs_s[col];
+        const float xh = (rv - mu_s[col]) * rs;
+        const float g = rs * (G[base + i] - sums_s[0][col] * invB - xh * (sums_s[1][col] * invB));
+        DZ[base + i] = rv > 0.f ? g : 0.f;
     }
 }
 
@@ -414,9 +470,10 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ G, const float* __restr
 // backward: weight tile is [N rows][K cols] read along K by lane -> ld = rup(K,32) + 4, rup(N,8) rows.
 static int fwd_ld(int maxdim) { return rup(maxdim, 8) + 4; }
 static int bwd_ld(int maxdim) { return rup(maxdim, 32) + 4; }
-static size_t chain_smem(int ld, int wrows) { return (size_t)(32 * ld + wrows * ld) * sizeof(float); }
+// + 256 floats: the BatchNorm statistics (forward) / batch sums (backward) every row block recombines
+static size_t chain_smem(int ld, int wrows) { return (size_t)(32 * ld + wrows * ld + 256) * sizeof(float); }
 
-int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params) {
+int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn_running, int64_t* nbt) {
     // layer in 2..5: out = relu(BN_{layer-1}(R_{layer-1}) W^T + b), statistics of the output
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
@@ -429,6 +486,15 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params) {
     a.K0 = d.H;
     a.bn_mean_off = L.bn_mean[i - 1];
     a.bn_rstd_off = L.bn_rstd[i - 1];
+    // training: this launch recombines BN_{layer-1}'s partials itself (and row block 0 updates the running
+    // buffers); eval: launch_bn_eval_stats has put the running statistics into the workspace
+    a.bn_part_off = c.h.training ? L.bn_part[i - 1] : -1;
+    a.run_mean_off = c.po.bn_mean[i - 1];
+    a.run_var_off = c.po.bn_var[i - 1];
+    a.run_arm_stride = c.po.bn_per_arm;
+    a.bn_idx = i - 1;
+    a.bn_eps = c.h.eps;
+    a.bn_momentum = c.h.bn_momentum;
     a.stats_part_off = L.bn_part[i];
     a.B = d.B;
     a.ld = fwd_ld(max(d.H, N));
@@ -437,7 +503,7 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params) {
     a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
     a.dbg_off = L.loss_scratch + 2048;
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
-                       c.ws);
+                       c.ws, bn_running, nbt);
     HIP_LAUNCH_CHECK("k_chain_fwd<enc>");
     return 0;
 }
@@ -454,7 +520,7 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.L[4] = FwdLayer{c.po.o[24], c.po.o[25], L.Dk[4], d.H, d.H, 1};
     a.x_off = L.ZIN;
     a.K0 = d.C + d.S;
-    a.bn_mean_off = a.bn_rstd_off = -1;
+    a.bn_mean_off = a.bn_rstd_off = a.bn_part_off = -1;
     a.stats_part_off = -1;
     a.B = d.B;
     a.ld = fwd_ld(max(max(d.H, d.L), d.C + d.S));
@@ -463,7 +529,7 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
     a.dbg_off = L.loss_scratch + 2048;
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
-                       c.ws);
+                       c.ws, (float*)nullptr, (int64_t*)nullptr);
     HIP_LAUNCH_CHECK("k_chain_fwd<dec>");
     return 0;
 }
@@ -481,7 +547,7 @@ int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {
     a.g_off = L.GD10_slab;
     a.nslab = nslab;
     a.slab_stride = (int64_t)d.A * d.B * d.H;
-    a.bnb_sum_off = -1;
+    a.bnb_part_off = -1;
     a.bn_mean_off = a.bn_rstd_off = -1;
     a.gout_off = L.GZIN;
     a.part_off = -1;
@@ -508,7 +574,7 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.g_off = L.G[layer];
     a.nslab = 1;
     a.slab_stride = 0;
-    a.bnb_sum_off = L.bnb_sum[layer];
+    a.bnb_part_off = L.bnb_part[layer];
     a.bn_mean_off = L.bn_mean[i];
     a.bn_rstd_off = L.bn_rstd[i];
     a.gout_off = L.G[layer - 1];
@@ -529,10 +595,8 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
 int launch_bn_bwd_apply1(const Ctx& c) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
-    const int64_t n = (int64_t)d.A * d.B * d.H;
-    const int blocks = (int)imin64(2048, cdiv64(n, 256));
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(blocks), dim3(256), 0, c.stream, c.ws + L.G[1], c.ws + L.R[0],
-                       c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_sum[1], c.ws + L.DZ[1], d.A, d.B, d.H);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(L.nblk32, d.A), dim3(256), 0, c.stream, c.ws + L.G[1], c.ws + L.R[0],
+                       c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_part[1], c.ws + L.DZ[1], d.B, d.H);
     HIP_LAUNCH_CHECK("k_bn_bwd_apply");
     return 0;
 }

@@ -258,6 +258,159 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return __builtin_bit_cast(int, f);
 }
 
+// ---- consumer-side recombination of per-row-block partials ---------------------------------
+// Batch statistics cross every row block, so each BatchNorm used to cost a tiny finalize launch
+// between two layers.  Instead every workgroup of the CONSUMING kernel recombines the producers'
+// partials itself (125 KB out of L2 at B = 5000, W = 100; all workgroups compute bit-identical
+// results because the order is fixed by (NT, nblk) alone).
+//
+// part: [nblk][2][W] = (block mean, block M2) over min(32, B - 32 blk) rows.  All NT threads call;
+// thread t < W returns column t's (mean, M2) over the whole batch.  scratch: 3 * PART_MAXG * W floats
+// of LDS the caller does not need until the next barrier it executes itself.
+constexpr int PART_MAXG = 16;
+constexpr int PART_BATCH = 16;
+
+template <bool VEC, int NT>
+__device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int W,
+                                                      float* scratch, float& mean_out, float& m2_out,
+                                                      unsigned long long* st = nullptr) {
+    auto tick = [&](int i) {
+        if (st) {
+            __builtin_amdgcn_sched_barrier(0);
+            st[i] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    tick(0);
+    constexpr int E = VEC ? 4 : 1;
+    const int units = 2 * W / E;   // load units per partial: the first W/E hold means, the rest M2s
+    const int G = max(1, min(min(NT / units, PART_MAXG), nblk));
+    const int t = threadIdx.x, u = t % units, g = t / units;
+    if (g < G) {
+        const bool is_mean = u * E < W;
+        const int col = is_mean ? u * E : u * E - W;
+        const float* p = part + u * E;
+        float sh[E], s1[E], s2[E];
+        float n = 0.f;
+        // the group's first block mean is the shift: s2 - s1^2/n then loses nothing to cancellation
+#pragma unroll
+        for (int e = 0; e < E; ++e) { sh[e] = is_mean ? p[(int64_t)g * 2 * W + e] : 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+        if (st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        tick(1);
+        // PART_BATCH loads in flight per pass, clamped and weighted instead of branched (a branch around
+        // a load makes hipcc wait for every load separately: one memory latency per partial)
+        for (int i0 = g; i0 < nblk; i0 += PART_BATCH * G) {
+            float v[PART_BATCH][E];
+#pragma unroll
+            for (int j = 0; j < PART_BATCH; ++j) {
+                const int i = min(i0 + j * G, nblk - 1);
+                if constexpr (VEC) {
+                    const float4 q = *reinterpret_cast<const float4*>(p + (int64_t)i * 2 * W);
+                    v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
+                } else {
+                    v[j][0] = p[(int64_t)i * 2 * W];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PART_BATCH; ++j) {
+                const int i = i0 + j * G;
+                const float nb = i < nblk ? (float)min(32, B - 32 * i) : 0.f;
+                const float w = is_mean ? nb : (i < nblk ? 1.f : 0.f);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float d = v[j][e] - sh[e];
+                    s1[e] += w * d;
+                    s2[e] += nb * d * d;
+                }
+                n += nb;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (is_mean) {
+                scratch[(g * 3 + 0) * W + col + e] = sh[e] + s1[e] / n;
+                scratch[(g * 3 + 1) * W + col + e] = s2[e] - s1[e] * s1[e] / n;
+            } else {
+                scratch[(g * 3 + 2) * W + col + e] = s1[e];
+            }
+        }
+    }
+    tick(2);
+    lds_barrier();
+    tick(3);
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (t < W) {
+        for (int k = 0; k < G; ++k) {   // Chan's pairwise update over the groups, fixed order
+            const int cnt = (nblk - k + G - 1) / G;
+            const float nb = (float)(32 * cnt - (((nblk - 1) % G == k) ? 32 * nblk - B : 0));
+            const float mg = scratch[(k * 3 + 0) * W + t];
+            const float m2g = scratch[(k * 3 + 1) * W + t] + scratch[(k * 3 + 2) * W + t];
+            const float nn = n + nb, dl = mg - mean;
+            mean += dl * (nb / nn);
+            m2 += m2g + dl * dl * (n * nb / nn);
+            n = nn;
+        }
+    }
+    mean_out = mean;
+    m2_out = m2;
+    tick(4);
+}
+template <int NT>
+__device__ __forceinline__ void stats_from_partials(const float* __restrict__ part, int nblk, int B, int W,
+                                                    float* scratch, float& mean_out, float& m2_out,
+                                                    unsigned long long* st = nullptr) {
+    if ((W & 3) == 0) stats_from_partials_t<true, NT>(part, nblk, B, W, scratch, mean_out, m2_out, st);
+    else stats_from_partials_t<false, NT>(part, nblk, B, W, scratch, mean_out, m2_out, st);
+}
+
+// part: [nblk][n] plain partial sums -> thread t < n returns sum over blocks of part[.][t].
+// scratch: NT * 4 doubles at most (G * n with G = NT / units).
+template <bool VEC, int NT>
+__device__ __forceinline__ float sums_from_partials_t(const float* __restrict__ part, int nblk, int n, double* scratch) {
+    constexpr int E = VEC ? 4 : 1;
+    const int units = n / E;
+    const int G = max(1, min(min(NT / units, PART_MAXG), nblk));
+    const int t = threadIdx.x, u = t % units, g = t / units;
+    if (g < G) {
+        double s[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] = 0.0;
+        const float* p = part + u * E;
+        for (int i0 = g; i0 < nblk; i0 += PART_BATCH * G) {
+            float v[PART_BATCH][E];
+#pragma unroll
+            for (int j = 0; j < PART_BATCH; ++j) {
+                const int i = min(i0 + j * G, nblk - 1);
+                if constexpr (VEC) {
+                    const float4 q = *reinterpret_cast<const float4*>(p + (int64_t)i * n);
+                    v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
+                } else {
+                    v[j][0] = p[(int64_t)i * n];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PART_BATCH; ++j) {
+                const bool ok = i0 + j * G < nblk;
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[e] += ok ? (double)v[j][e] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) scratch[g * n + u * E + e] = s[e];
+    }
+    lds_barrier();
+    double r = 0.0;
+    if (t < n)
+        for (int k = 0; k < G; ++k) r += scratch[k * n + t];
+    return (float)r;
+}
+template <int NT>
+__device__ __forceinline__ float sums_from_partials(const float* __restrict__ part, int nblk, int n, double* scratch) {
+    if ((n & 3) == 0) return sums_from_partials_t<true, NT>(part, nblk, n, scratch);
+    return sums_from_partials_t<false, NT>(part, nblk, n, scratch);
+}
+
 // ---- Philox4x32-10 -----------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -366,9 +519,9 @@ NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h);
 
 // stage launchers (one per kernel family); each returns 0 or MMVAE_E_LAUNCH
 int launch_fc1_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs);
-int launch_stats_finalize(const Ctx& c, int layer /*0..4 BN, 5 = c stats*/, float* bn_running, int64_t* nbt);
-int launch_chain_fwd_enc(const Ctx& c, int layer /*2..5*/, const float* params);
-int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params);
+int launch_bn_eval_stats(const Ctx& c, int layer /*0..4*/, const float* bn_running);
+int launch_chain_fwd_enc(const Ctx& c, int layer /*2..5*/, const float* params, float* bn_running, int64_t* nbt);
+int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt);
 int launch_chain_fwd_dec(const Ctx& c, const float* params);
 int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
 int launch_couple(const Ctx& c);
@@ -376,7 +529,6 @@ int launch_loss_finalize(const Ctx& c, float* loss_out);
 int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab);
 bool fc11_split_path(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params);
-int launch_bnb_finalize(const Ctx& c, int layer /*1..5*/);
 int launch_chain_bwd_enc(const Ctx& c, int layer /*5..2*/, const float* params);
 int launch_bn_bwd_apply1(const Ctx& c);
 int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t xs);

@@ -598,6 +598,289 @@ __global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10
 }
 
 // =============================================================================================
+// fc11 forward + reconstruction loss + dZ11, staggered with 16-byte global accesses (the default fast path).
+//   z = d10 W11^T by MFMA as in k_fc11_z (d10 fragments stationary in registers, W11 tile double buffered in
+//   LDS), but every 4 x 4 block of the accumulator is transposed inside its lane quad (DPP), after which a lane
+//   holds FOUR CONSECUTIVE GENES of one cell: x is read and dZ11 written 16 B per lane and every instruction
+//   covers whole 128-byte lines (8 cells x 32 genes) -- 8 + 8 vector memory instructions per 64-gene step
+//   instead of 32 + 32 (more than the 63 the vmcnt counter can track, so k_fc11_z's loads stalled at issue).
+//   A 512-thread workgroup covers 256 cells.  Waves 4-7 run one epilogue behind waves 0-3: on every SIMD one
+//   wave's epilogue (VALU + stores) runs beside its partner's MFMAs instead of both leaving the matrix pipe
+//   idle together.  One barrier per step.
+//   BIASK: the bias rides in the K padding (d10 fragment k = H is 1, W tile column H is b11; needs H % 8 == 4).
+// grid (ceil(B/256), NS, A)
+// =============================================================================================
+// on entry v[e] on lane i of a quad is M[e][i]; on exit it is M[i][e]
+__device__ __forceinline__ void quad_transpose4(float& v0, float& v1, float& v2, float& v3, bool b0, bool b1) {
+    const float sA = b1 ? v0 : v2, sB = b1 ? v1 : v3;
+    const float rA = dpp_f<0x4E>(sA), rB = dpp_f<0x4E>(sB);      // quad_perm [2,3,0,1]
+    v0 = b1 ? rA : v0; v1 = b1 ? rB : v1; v2 = b1 ? v2 : rA; v3 = b1 ? v3 : rB;
+    const float s0 = b0 ? v0 : v1, s1 = b0 ? v2 : v3;
+    const float r0 = dpp_f<0xB1>(s0), r1 = dpp_f<0xB1>(s1);      // quad_perm [1,0,3,2]
+    v0 = b0 ? r0 : v0; v1 = b0 ? v1 : r0; v2 = b0 ? r1 : v2; v3 = b0 ? v3 : r1;
+}
+
+// XREC: x_rec is written (forward / inference calls); the train step instantiates XREC = false, where dZ11 is
+// always written.  ABL: timing experiments only (1 no MFMA, 2 no x loads, 4 no dZ11 stores); 0 in production --
+// compile-time so that the step body stays one basic block.
+template <int FZ_KG, bool EXACT, bool BIASK, bool XREC, int ABL>
+__global__ __launch_bounds__(512, 2) void k_fc11_zt(const float* __restrict__ d10, const float* __restrict__ params,
+                                                    int64_t per_arm, int64_t w_off, int64_t b_off,
+                                                    const float* __restrict__ x, int64_t x_arm_stride,
+                                                    float* __restrict__ x_rec, float* __restrict__ dz11,
+                                                    float* __restrict__ part, int n11, float coef, int need_grad,
+                                                    int A, int B, int D, int H, int ldk, unsigned long long* dbgc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wbuf = smem;                     // [2][64][ldk]
+    float* red = smem + 2 * 64 * ldk;       // [16]
+    const int arm = blockIdx.z, ns = blockIdx.y, NS = gridDim.y, b0 = blockIdx.x * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+    const int KP = rup(H, 8), kg = KP / 8, nc4 = KP / 4, hc4 = H / 4;
+    const bool late = (ABL & 16) ? wv < 4 : wv >= 4;
+    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
+    const float* bias = params + (int64_t)arm * per_arm + b_off;
+    const float* xa = x + (int64_t)arm * x_arm_stride;
+    float* dza = dz11 + (int64_t)arm * B * D;
+    float* xra = XREC ? x_rec + (int64_t)arm * B * D : nullptr;
+    const bool do_grad = XREC ? (need_grad != 0) : true;
+    const int bw = b0 + 32 * wv;
+    const bool rows_full = b0 + 256 <= B;
+
+    // ---- d10 fragments (MFMA A operand): cell = bw + (lane & 31), k = 8 g + 4 hh .. + 3
+    float4 afr[FZ_KG];
+    {
+        const int row = bw + l31;
+        const float* p = d10 + ((int64_t)arm * B + min(row, B - 1)) * H + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < FZ_KG; ++g) {
+            const int k0 = 8 * g + 4 * hh;
+            const bool ok = row < B && k0 < H;
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? 8 * g : 0));
+            afr[g] = sel4(ok, v);
+            if (BIASK && k0 == H) afr[g].x = 1.f;
+        }
+    }
+    const int ntall = cdiv(D, 64);
+    const int t0 = (int)(((int64_t)ns * ntall) / NS), t1 = (int)(((int64_t)(ns + 1) * ntall) / NS);
+    const int srow = tid >> 3, spart = tid & 7;
+    // The W tile for step t+1 is requested one step ahead and lands in registers while the MFMAs / epilogue run;
+    // masking and the bias column are applied when it is written to LDS (touching the loaded values any
+    // earlier makes the compiler wait for the loads where they are issued).
+    float4 wreg[4];
+    float wbias = 0.f;
+    int wj = 0;
+    auto prefetch_w = [&](int t) {
+        wj = t * 64 + srow;
+        const float* p = W + (int64_t)min(wj, D - 1) * H;
+        if (BIASK) wbias = bias[min(wj, D - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = spart + 8 * i;
+            wreg[i] = *reinterpret_cast<const float4*>(p + (c < hc4 ? c * 4 : 0));
+        }
+    };
+    auto store_w = [&](float* Ws) {
+        const bool jok = wj < D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = spart + 8 * i;
+            float4 v = sel4(jok && c < hc4, wreg[i]);
+            if (BIASK && c == hc4) v.x = jok ? wbias : 0.f;
+            if (c < nc4) *reinterpret_cast<float4*>(&Ws[srow * ldk + c * 4]) = v;
+        }
+    };
+    // after the quad transposes: register group q of a lane is cell cq = bw + 8 q + 4 hh + (lane & 3),
+    // genes j0 + 32 c + 4 ((lane & 31) >> 2) .. + 3
+    const int cbase = bw + 4 * hh + (l31 & 3);
+    const int gcol = 4 * (l31 >> 2);
+    const uint32_t lane_off = (uint32_t)cbase * (uint32_t)D + (uint32_t)gcol;   // interior: + wave-uniform part
+    float se = 0.f;
+    int mism = 0;   // wave-uniform count (ballot + popcount on the scalar unit)
+    f32x16 z0 = zero16(), z1 = zero16();
+    float4 xv[2][4];
+
+    // one 16-byte piece (gene half c, cell group q) of tile t's x
+    auto load_x1 = [&](int t, int c, int q, float4& dst, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        if (ABL & 2) { dst = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+        if (!EDGE) {
+            const float* xu = xa + ((int64_t)8 * q * D + t * 64 + 32 * c);      // wave-uniform
+            dst = *reinterpret_cast<const float4*>(xu + lane_off);
+        } else {
+            const int cellq = min(cbase + 8 * q, B - 1), col = min(t * 64 + 32 * c + gcol, D - 4);
+            dst = *reinterpret_cast<const float4*>(xa + (uint32_t)cellq * (uint32_t)D + (uint32_t)col);
+        }
+    };
+    auto load_x = [&](int t, float4 (&dst)[2][4], auto edge_tag) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_x1(t, c, q, dst[c][q], edge_tag);
+    };
+    auto mfma_tile = [&](const float* Ws) __attribute__((always_inline)) {
+        z0 = zero16();
+        z1 = zero16();
+        const float* pb = Ws + l31 * ldk + 4 * hh;
+        float4 q0 = *reinterpret_cast<const float4*>(pb);
+        float4 q1 = *reinterpret_cast<const float4*>(pb + 32 * ldk);
+        if (!(ABL & 1))
+#pragma unroll
+        for (int g = 0; g < FZ_KG; ++g) {
+            if (EXACT || g < kg) {
+                const int gn = EXACT ? ((g + 1 < FZ_KG) ? g + 1 : g) : ((g + 1 < kg) ? g + 1 : g);
+                const float4 n0 = *reinterpret_cast<const float4*>(pb + 8 * gn);
+                const float4 n1 = *reinterpret_cast<const float4*>(pb + 32 * ldk + 8 * gn);
+                const float4 a = afr[g];
+                z0 = mfma32(a.x, q0.x, z0); z1 = mfma32(a.x, q1.x, z1);
+                z0 = mfma32(a.y, q0.y, z0); z1 = mfma32(a.y, q1.y, z1);
+                z0 = mfma32(a.z, q0.z, z0); z1 = mfma32(a.z, q1.z, z1);
+                z0 = mfma32(a.w, q0.w, z0); z1 = mfma32(a.w, q1.w, z1);
+                q0 = n0; q1 = n1;
+            }
+        }
+    };
+    // x_rec = relu(z + b); e = x_rec - x; dZ11 = coef * e where x_rec > 0 (nn_model.py:544-546 + autograd)
+    auto epilogue = [&](int t, const float4 (&xs)[2][4], auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = t * 64 + 32 * c + gcol;
+            float bq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!BIASK) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + (EDGE ? min(col, D - 4) : col));
+                bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float zz[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zz[e] = (c == 0 ? z0[4 * q + e] : z1[4 * q + e]);
+                quad_transpose4(zz[0], zz[1], zz[2], zz[3], lb0, lb1);
+                const bool ok = !EDGE || ((cbase + 8 * q < B) && (col < D));
+                const unsigned long long okmask = EDGE ? __ballot(ok) : ~0ull;
+                const float xin[4] = {xs[c][q].x, xs[c][q].y, xs[c][q].z, xs[c][q].w};
+                float xr[4], dzv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xr[e] = fmaxf(zz[e] + bq[e], 0.f);
+                    const float er = xr[e] - xin[e];
+                    dzv[e] = (xr[e] > 0.f) ? coef * er : 0.f;
+                    se += ok ? er * er : 0.f;
+                    // mismatch count on the scalar unit: two compares, xor / and / popcount of the lane masks
+                    mism += __popcll((__ballot(xr[e] > 0.1f) ^ __ballot(xin[e] > 0.1f)) & okmask);
+                }
+                if (ok) {
+                    if (!EDGE) {
+                        const int64_t uo = (int64_t)8 * q * D + t * 64 + 32 * c;      // wave-uniform
+                        if (XREC) *reinterpret_cast<float4*>(xra + uo + lane_off) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+                        if (do_grad && !(ABL & 4))
+                            *reinterpret_cast<float4*>(dza + uo + lane_off) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+                    } else {
+                        const uint32_t off = (uint32_t)(cbase + 8 * q) * (uint32_t)D + (uint32_t)col;
+                        if (XREC) *reinterpret_cast<float4*>(xra + off) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+                        if (do_grad) *reinterpret_cast<float4*>(dza + off) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+                    }
+                }
+            }
+        }
+    };
+
+    if (t0 < t1) {
+        prefetch_w(t0);
+        store_w(Wbuf);
+    }
+    __syncthreads();
+    int cur = 0;
+    // ABL bit 3: shader-clock stamps per phase, summed over waves (early waves: counters 0-5, late: 8-13)
+    constexpr bool STAMPS = (ABL & 8) != 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int i) {
+        if (STAMPS) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            ph[i] += now - tprev;
+            tprev = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (STAMPS) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+    // Every step body is straight-line per role: no condition around a load or a store (a conditional epilogue or
+    // prefetch makes the compiler's vmcnt bookkeeping pessimistic at the join, and it then waits for the previous
+    // step's dZ11 stores before touching the W tile).  The W prefetch of the last step re-reads a clamped row and
+    // its LDS copy is never used; the late waves' first step (no tile behind them yet) is a separate instance.
+    auto step = [&](int t, auto edge_tag, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const float* Ws = Wbuf + cur * 64 * ldk;
+        // phase fences: without them the scheduler hoists epilogue work that only needs x (the mismatch
+        // compares) to the top of the step, where it waits for the loads just issued, and sinks W loads behind
+        // the dZ11 stores
+        if (!late) {
+            load_x(t, xv, edge_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(0);
+            mfma_tile(Ws);
+            if (STAMPS) asm volatile("" :: "v"(z0[0]), "v"(z1[15]));
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(1);
+            prefetch_w(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
+            epilogue(t, xv, edge_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(3);
+        } else {
+            // W loads before the epilogue's stores: vmcnt retires in order
+            prefetch_w(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
+            if (!FIRST) epilogue(t - 1, xv, edge_tag);   // z still holds tile t-1
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(3);
+            // x for this tile goes into the registers the epilogue has just drained; it is not needed before the
+            // next step's epilogue, and issuing it here (not at the top of the step with waves 0-3's loads) spreads
+            // the CU's outstanding misses over the step
+            load_x(t, xv, edge_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(0);
+            mfma_tile(Ws);
+            if (STAMPS) asm volatile("" :: "v"(z0[0]), "v"(z1[15]));
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(1);
+        }
+        store_w(Wbuf + (cur ^ 1) * 64 * ldk);
+        stamp(4);
+        lds_barrier();      // LDS only: the dZ11 / x_rec stores stay in flight
+        stamp(5);
+        cur ^= 1;
+    };
+    // first step (guarded body, valid for any tile), interior steps (all 256 cells and all 64 genes in range),
+    // then the guarded ones
+    const int t_mid = rows_full ? max(t0 + 1, min(t1, D / 64)) : t0 + 1;
+    if (t0 < t1) step(t0, VecTag{}, VecTag{});
+    for (int t = t0 + 1; t < t_mid; ++t) step(t, ScalarTag{}, ScalarTag{});      // ::value == false: interior body
+    for (int t = max(t_mid, t0 + 1); t < t1; ++t) step(t, VecTag{}, ScalarTag{});    // guarded body
+    if (late && t1 > t0) epilogue(t1 - 1, xv, VecTag{});
+    if (STAMPS && lane == 0) {
+        unsigned long long* dbg = dbgc + (late ? 8 : 0);
+        for (int i = 0; i < 6; ++i) atomicAdd(dbg + i, ph[i]);
+        atomicAdd(dbg + 6, 1ull);
+    }
+    se = wave_sum(se);
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = (float)mism; }
+    __syncthreads();
+    if (tid == 0) {
+        float* p = part + ((int64_t)arm * n11 + (int64_t)blockIdx.x * NS + ns) * 2;
+        float s0 = 0.f, s1 = 0.f;
+        for (int w = 0; w < 8; ++w) { s0 += red[w * 2]; s1 += red[w * 2 + 1]; }
+        p[0] = s0;
+        p[1] = s1;
+    }
+}
+
+// =============================================================================================
 // d(d10) = dZ11 W11: M = cells, N = H, K = genes.  Tile 128 x 128, K tile 32, wave tile 64 x 64.
 // A = dZ11 (K contiguous, b128 fragment reads), B = W11 rows (h contiguous, b32 reads).
 // grid (ceil(B/128), KS, A) -> slabs [KS][A][B][H]
@@ -751,24 +1034,63 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         return 0;
     }
     if (which & 1) {
-    // loss partials: the launches below fill a subset of the reserved slots
-    hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
-    if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
-    {
-        const size_t shm = (size_t)(2 * 64 * ldk + 8) * sizeof(float);
-        const int nball = cdiv(d.B, 128), ntall = cdiv(d.D, 64);
+        // loss partials: the launch below fills a subset of the reserved slots
+        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
+        const int ntall = cdiv(d.D, 64);
         const int kgv = rup(d.H, 8) / 8;
         static const int ablz = getenv("MMVAE_ABLATE_Z") ? atoi(getenv("MMVAE_ABLATE_Z")) : 0;   // timing experiments
-        const int nsplit = max(1, min(NS, ntall));
-        dim3 grid(nball, nsplit, d.A);
+        static const int zold = getenv("MMVAE_FC11_ZOLD") ? atoi(getenv("MMVAE_FC11_ZOLD")) : 0;  // A/B timing
+        if (!zold) {
+            // one 512-thread workgroup per CU: split the gene range so that the grid fills the chip once
+            const int nb = cdiv(d.B, 256);
+            int nsz = max(1, min(min(256 / max(nb * d.A, 1), 16), ntall));
+            while (nsz > 1 && (int64_t)nb * nsz > L.n11) --nsz;
+            static const int nsz_env = getenv("MMVAE_FC11_NSZ") ? atoi(getenv("MMVAE_FC11_NSZ")) : 0;
+            if (nsz_env > 0 && (int64_t)nb * nsz_env <= L.n11) nsz = min(nsz_env, ntall);
+            const size_t shm = (size_t)(2 * 64 * ldk + 16) * sizeof(float);
+            dim3 grid(nb, nsz, d.A);
+#define FZT_ARGS c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,        \
+                 c.ws + L.fc11_part, L.n11, coef, need_grad, d.A, d.B, d.D, d.H, ldk,                            \
+                 reinterpret_cast<unsigned long long*>(c.ws + L.loss_scratch + 2048)
+#define FZT_LAUNCH(KG, EX, BK, XR, AB) \
+    hipLaunchKernelGGL((k_fc11_zt<KG, EX, BK, XR, AB>), grid, dim3(512), shm, c.stream, FZT_ARGS)
+            const bool xr = x_rec != nullptr;
+            // without x_rec the kernel always writes dZ11 (workspace), wanted or not: one variant fewer
+            if (kgv == 13 && d.H == 100) {
+                if (xr) FZT_LAUNCH(13, true, true, true, 0);
+                else if (ablz == 1) FZT_LAUNCH(13, true, true, false, 1);
+                else if (ablz == 2) FZT_LAUNCH(13, true, true, false, 2);
+                else if (ablz == 4) FZT_LAUNCH(13, true, true, false, 4);
+                else if (ablz == 6) FZT_LAUNCH(13, true, true, false, 6);
+                else if (ablz == 7) FZT_LAUNCH(13, true, true, false, 7);
+                else if (ablz == 8) FZT_LAUNCH(13, true, true, false, 8);
+                else if (ablz == 24) FZT_LAUNCH(13, true, true, false, 24);
+                else if (ablz == 16) FZT_LAUNCH(13, true, true, false, 16);
+                else FZT_LAUNCH(13, true, true, false, 0);
+            } else if (kgv == 16 && d.H == 128) {
+                if (xr) FZT_LAUNCH(16, true, false, true, 0);
+                else FZT_LAUNCH(16, true, false, false, 0);
+            } else {
+                if (xr) FZT_LAUNCH(16, false, false, true, 0);
+                else FZT_LAUNCH(16, false, false, false, 0);
+            }
+#undef FZT_LAUNCH
+#undef FZT_ARGS
+            HIP_LAUNCH_CHECK("k_fc11_zt");
+        } else {
+            const size_t shm = (size_t)(2 * 64 * ldk + 8) * sizeof(float);
+            const int nball = cdiv(d.B, 128);
+            const int nsplit = max(1, min(NS, ntall));
+            dim3 grid(nball, nsplit, d.A);
 #define FZ_ARGS c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,        \
                 c.ws + L.fc11_part, L.n11, 0, coef, need_grad, d.A, d.B, d.D, d.H, ldk, 0, 0, ntall, ablz
-        if (kgv == 13) hipLaunchKernelGGL((k_fc11_z<13, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-        else if (kgv == 16) hipLaunchKernelGGL((k_fc11_z<16, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-        else hipLaunchKernelGGL((k_fc11_z<16, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            if (kgv == 13) hipLaunchKernelGGL((k_fc11_z<13, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            else if (kgv == 16) hipLaunchKernelGGL((k_fc11_z<16, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
+            else hipLaunchKernelGGL((k_fc11_z<16, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
 #undef FZ_ARGS
-        HIP_LAUNCH_CHECK("k_fc11_z");
-    }
+            HIP_LAUNCH_CHECK("k_fc11_z");
+        }
     }
     if (need_grad && (which & 2)) {
         hipLaunchKernelGGL(k_gd10_v2, dim3(cdiv(d.B, 128), L.sp.ks_gd10, d.A), dim3(256), 0, c.stream, c.ws + L.DZ11,

@@ -1,14 +1,14 @@
 // Row-wise (one wavefront per cell) kernels and the small reductions between them:
 //
-//   k_stats_finalize  block (mean, M2) partials -> batch mean / rstd (BatchNorm1d, nn_model.py:208-255,
-//                     running statistics included) or mean / inv_var (nn_model.py:75-77)
+//   (batch statistics: every consumer recombines the producers' per-row-block (mean, M2) partials itself,
+//    common.hpp stats_from_partials -- BatchNorm1d incl. running statistics, nn_model.py:208-255, and
+//    inv_var, nn_model.py:75-77; eval mode: k_stats_from_running)
 //   k_lat_fwd         x_low = BN5(R5); c_prob = softmax(fcc x_low); c = softmax(c_prob/tau);
 //                     Gumbel-softmax sample; state head; reparameterise; decoder input
 //                     (nn_model.py:268-269, :337-351, :413-493)
 //   k_couple          pairwise coupling terms over arms (nn_model.py:558-569)
 //   k_loss_finalize   scalars of nn_model.py:542-598
 //   k_lat_bwd         autograd of k_lat_fwd + coupling / entropy / KL terms
-//   k_bnb_finalize    batch sums for the BatchNorm backward
 //   k_reduce          slabs -> flat gradient buffer;  k_adam: torch.optim.Adam(W) update
 //
 // Wave reductions only (no MFMA): these tensors are [B, <=128] and HBM/L2 resident.
@@ -42,65 +42,6 @@ NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h) {
     return n;
 }
 
-// ---------------------------------------------------------------------------------------------
-// statistics finalisation.  part: [A][nblk][2][W] (block mean, block M2 over min(32, B-32*blk) rows)
-// kind 0: BatchNorm -> mean, rstd = 1/sqrt(M2/B + eps); running_mean/var momentum update.
-// kind 1: inv_var   -> mean, iv   = 1/sqrt(M2/(B-1) + eps)
-// Chan's pairwise update keeps the variance exact to rounding.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stats_finalize(const float* __restrict__ part, int nblk, int B, int W,
-                                                        int kind, float eps, float momentum,
-                                                        float* __restrict__ mean_out, float* __restrict__ second_out,
-                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                        int64_t run_arm_stride, int64_t* __restrict__ nbt,
-                                                        int nbt_index) {
-    // grid (A, ceil(W/32)); thread (g, c): row-block group g = tid >> 5 handles blocks g, g+8, ...
-    __shared__ float sn[8][32], sm[8][32], s2[8][32];
-    const int arm = blockIdx.x, c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int col = blockIdx.y * 32 + c;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (col < W) {
-        for (int b = g; b < nblk; b += 8) {
-            const float nb = (float)min(32, B - 32 * b);
-            const float* p = part + (((int64_t)arm * nblk + b) * 2) * W;
-            const float mb = p[col], m2b = p[W + col];
-            const float nn = n + nb;
-            const float dl = mb - mean;
-            mean += dl * (nb / nn);
-            m2 += m2b + dl * dl * (n * nb / nn);
-            n = nn;
-        }
-    }
-    sn[g][c] = n; sm[g][c] = mean; s2[g][c] = m2;
-    __syncthreads();
-    if (g == 0 && col < W) {
-        n = 0.f; mean = 0.f; m2 = 0.f;
-        for (int k = 0; k < 8; ++k) {
-            const float nb = sn[k][c];
-            if (nb > 0.f) {
-                const float nn = n + nb, dl = sm[k][c] - mean;
-                mean += dl * (nb / nn);
-                m2 += s2[k][c] + dl * dl * (n * nb / nn);
-                n = nn;
-            }
-        }
-        mean_out[arm * W + col] = mean;
-        if (kind == 0) {
-            second_out[arm * W + col] = 1.0f / sqrtf(m2 / (float)B + eps);
-            if (run_mean) {
-                float* rm = run_mean + arm * run_arm_stride;
-                float* rv = run_var + arm * run_arm_stride;
-                const float var_u = m2 / (float)max(B - 1, 1);
-                rm[col] = (1.f - momentum) * rm[col] + momentum * mean;
-                rv[col] = (1.f - momentum) * rv[col] + momentum * var_u;
-            }
-        } else {
-            second_out[arm * W + col] = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
-        }
-    }
-    if (kind == 0 && nbt && threadIdx.x == 0 && blockIdx.y == 0) nbt[arm * MMVAE_N_BN + nbt_index] += 1;
-}
-
 // eval mode: statistics come from the running buffers
 __global__ void k_stats_from_running(const float* __restrict__ run_mean, const float* __restrict__ run_var,
                                      int64_t run_arm_stride, int W, float eps, float* __restrict__ mean_out,
@@ -124,6 +65,9 @@ struct LatArgs {
     int64_t GZIN, GMS, GZC, G5, bnb_part5, T, c_mean, c_iv;
     float am1, beta, lam;
     int64_t dbg_off;   // >= 0: diagnostic stamp counters (MMVAE_ABLATE_L=8)
+    // forward, training: BN5's partials [A][nblk][2][L] are recombined by every row block
+    int64_t bn_part5, run_mean_off, run_var_off, run_arm_stride;
+    float bn_momentum;
 };
 
 __device__ __forceinline__ float gumbel_u(const NoiseDev& nz, int arm, int B, int C, int b, int col) {
@@ -153,11 +97,15 @@ __device__ __forceinline__ void lat_stage_weights(float* WcT, float* Wm, const f
 
 // grid (ceil(B/32), A), 1024 threads; wave w handles rows b0 + w, b0 + w + 16
 __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const NoiseDev nz_in,
-                                                  const float* __restrict__ params, float* __restrict__ ws) {
+                                                  const float* __restrict__ params, float* __restrict__ ws,
+                                                  float* __restrict__ bn_running, int64_t* __restrict__ nbt) {
     const LatArgs a = a_in;      // argument blocks into registers once (see k_chain_fwd)
     const NoiseDev nz = nz_in;
     extern __shared__ __attribute__((aligned(16))) float lat_smem[];
-    __shared__ float sh_mean[LAT_NW][CPL * 64], sh_m2[LAT_NW][CPL * 64], sh_cnt[LAT_NW], sh_red[LAT_NW][2];
+    __shared__ __attribute__((aligned(16))) float sh_stat[2][LAT_NW][CPL * 64];
+    __shared__ float sh_cnt[LAT_NW], sh_red[LAT_NW][2], sh_bn5[2][64];
+    float (*sh_mean)[CPL * 64] = sh_stat[0];
+    float (*sh_m2)[CPL * 64] = sh_stat[1];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int B = a.B, L = a.L, C = a.C, S = a.S;
@@ -185,8 +133,31 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
     if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
     float cnt = 0.f, cm[CPL] = {0.f, 0.f}, cM2[CPL] = {0.f, 0.f};
     float kl_acc = 0.f, ent_acc = 0.f;
-    const float mu5 = lane < L ? ws[a.mean5 + arm * L + lane] : 0.f;
-    const float rs5 = lane < L ? ws[a.rstd5 + arm * L + lane] : 0.f;
+    if (a.bn_part5 >= 0) {   // training: BN5 batch statistics from fc5's per-row-block partials
+        float mean, m2;
+        stats_from_partials<64 * LAT_NW>(ws + a.bn_part5 + (int64_t)arm * gridDim.x * 2 * L, gridDim.x, B, L,
+                                         &sh_stat[0][0][0], mean, m2);
+        if (threadIdx.x < L) {
+            const int t = threadIdx.x;
+            const float rstd = 1.0f / sqrtf(m2 / (float)B + eps);
+            sh_bn5[0][t] = mean;
+            sh_bn5[1][t] = rstd;
+            if (blk == 0) {
+                ws[a.mean5 + arm * L + t] = mean;
+                ws[a.rstd5 + arm * L + t] = rstd;
+                if (bn_running) {
+                    float* rm = bn_running + a.run_mean_off + arm * a.run_arm_stride;
+                    float* rv = bn_running + a.run_var_off + arm * a.run_arm_stride;
+                    rm[t] = (1.f - a.bn_momentum) * rm[t] + a.bn_momentum * mean;
+                    rv[t] = (1.f - a.bn_momentum) * rv[t] + a.bn_momentum * (m2 / (float)max(B - 1, 1));
+                }
+                if (nbt && t == 0) nbt[arm * MMVAE_N_BN + 4] += 1;
+            }
+        }
+        lds_barrier();
+    }
+    const float mu5 = lane < L ? (a.bn_part5 >= 0 ? sh_bn5[0][lane] : ws[a.mean5 + arm * L + lane]) : 0.f;
+    const float rs5 = lane < L ? (a.bn_part5 >= 0 ? sh_bn5[1][lane] : ws[a.rstd5 + arm * L + lane]) : 0.f;
 
     stamp(0);   // weight staging + statistics loads
     for (int row = wv; row < 32; row += LAT_NW) {
@@ -372,19 +343,32 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 // grid (ceil(B/32)), 256 threads.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_couple(int A, int B, int C, float eps, float lam, const float* __restrict__ CCp,
-                                                const float* __restrict__ CSMPp, const float* __restrict__ civ,
+                                                const float* __restrict__ CSMPp, const float* __restrict__ c_part,
+                                                float* __restrict__ c_mean, float* __restrict__ c_iv,
                                                 float* __restrict__ couple_part, float* __restrict__ T_part) {
-    __shared__ float shT[4][MMVAE_MAX_ARMS][CPL * 64];
-    __shared__ float sh_red[4][2];
+    __shared__ __attribute__((aligned(16))) float shT[4][MMVAE_MAX_ARMS][CPL * 64];
+    __shared__ float sh_red[4][2], sh_iv[MMVAE_MAX_ARMS][CPL * 64];
     const int blk = blockIdx.x, b0 = blk * 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // inv_var of every arm's c over the batch (nn_model.py:558-560): mean and unbiased variance recombined
+    // from k_lat_fwd's per-row-block partials [A][nblk][2][C]; row block 0 keeps them for the backward
+    for (int aa = 0; aa < A; ++aa) {
+        float mean, m2;
+        stats_from_partials<256>(c_part + (int64_t)aa * gridDim.x * 2 * C, gridDim.x, B, C, &shT[0][0][0], mean, m2);
+        if (threadIdx.x < C) {
+            const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
+            sh_iv[aa][threadIdx.x] = ivv;
+            if (blk == 0) { c_mean[aa * C + threadIdx.x] = mean; c_iv[aa * C + threadIdx.x] = ivv; }
+        }
+        lds_barrier();
+    }
     float iv[MMVAE_MAX_ARMS][CPL], Tacc[MMVAE_MAX_ARMS][CPL];
 #pragma unroll
     for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
 #pragma unroll
         for (int t = 0; t < CPL; ++t) {
             const int col = lane + 64 * t;
-            iv[aa][t] = (aa < A && col < C) ? civ[aa * C + col] : 0.f;
+            iv[aa][t] = (aa < A && col < C) ? sh_iv[aa][col] : 0.f;
             Tacc[aa][t] = 0.f;
         }
     float dist = 0.f, l2 = 0.f;
@@ -683,24 +667,6 @@ __global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const Nois
     }
 }
 
-// out[g][i] = sum_b part[g][b][i]  (i < n): grid (G, ceil(n/32)), 256 threads = 8 block groups x 32 columns
-__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int nblk, int64_t group_stride,
-                                                      int64_t blk_stride, int n, float* __restrict__ out) {
-    __shared__ double sh[8][32];
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int i = blockIdx.y * 32 + c;
-    const float* p = part + (int64_t)blockIdx.x * group_stride;
-    double s = 0.0;
-    if (i < n)
-        for (int b = g; b < nblk; b += 8) s += p[(int64_t)b * blk_stride + i];
-    sh[g][c] = s;
-    __syncthreads();
-    if (g == 0 && i < n) {
-        for (int k = 1; k < 8; ++k) s += sh[k][c];
-        out[(int64_t)blockIdx.x * n + i] = (float)s;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // slabs -> flat gradient buffer
 // ---------------------------------------------------------------------------------------------
@@ -808,43 +774,35 @@ static LatArgs make_lat_args(const Ctx& c) {
     a.GZIN = L.GZIN; a.GMS = L.GMS; a.GZC = L.GZC; a.G5 = L.G[5]; a.bnb_part5 = L.bnb_part[5];
     a.T = L.T; a.c_mean = L.c_mean; a.c_iv = L.c_iv;
     a.am1 = (float)(d.A > 1 ? d.A - 1 : 1); a.beta = c.h.beta; a.lam = c.h.lam;
+    a.bn_part5 = c.h.training ? L.bn_part[4] : -1;
+    a.run_mean_off = c.po.bn_mean[4]; a.run_var_off = c.po.bn_var[4]; a.run_arm_stride = c.po.bn_per_arm;
+    a.bn_momentum = c.h.bn_momentum;
     static const int abl = getenv("MMVAE_ABLATE_L") ? atoi(getenv("MMVAE_ABLATE_L")) : 0;
     a.dbg_off = (abl & 8) ? L.loss_scratch + 2048 : -1;
     return a;
 }
 
-int launch_stats_finalize(const Ctx& c, int layer, float* bn_running, int64_t* nbt) {
+// eval mode: BatchNorm `layer` (0..4) normalises with the running buffers; in training mode the kernel that
+// consumes the layer recombines the batch statistics itself and nothing is launched here
+int launch_bn_eval_stats(const Ctx& c, int layer, const float* bn_running) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
-    if (layer == 5) {   // statistics of c for inv_var
-        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A, cdiv(d.C, 32)), dim3(256), 0, c.stream, c.ws + L.c_part, L.nblk32, d.B, d.C, 1,
-                           c.h.eps, 0.f, c.ws + L.c_mean, c.ws + L.c_iv, (float*)nullptr, (float*)nullptr, (int64_t)0,
-                           (int64_t*)nullptr, 0);
-        HIP_LAUNCH_CHECK("k_stats_finalize<c>");
-        return 0;
-    }
+    if (c.h.training) return 0;
+    if (!bn_running) { set_error("eval-mode forward needs bn_running"); return MMVAE_E_BADARG; }
     const int W = (layer == 4) ? d.L : d.H;
-    float* rm = bn_running ? bn_running + c.po.bn_mean[layer] : nullptr;
-    float* rv = bn_running ? bn_running + c.po.bn_var[layer] : nullptr;
-    if (c.h.training) {
-        hipLaunchKernelGGL(k_stats_finalize, dim3(d.A, cdiv(W, 32)), dim3(256), 0, c.stream, c.ws + L.bn_part[layer], L.nblk32, d.B,
-                           W, 0, c.h.eps, c.h.bn_momentum, c.ws + L.bn_mean[layer], c.ws + L.bn_rstd[layer], rm, rv,
-                           c.po.bn_per_arm, nbt, layer);
-        HIP_LAUNCH_CHECK("k_stats_finalize");
-    } else {
-        if (!bn_running) { set_error("eval-mode forward needs bn_running"); return MMVAE_E_BADARG; }
-        hipLaunchKernelGGL(k_stats_from_running, dim3(d.A), dim3(128), 0, c.stream, rm, rv, c.po.bn_per_arm, W, c.h.eps,
-                           c.ws + L.bn_mean[layer], c.ws + L.bn_rstd[layer]);
-        HIP_LAUNCH_CHECK("k_stats_from_running");
-    }
+    hipLaunchKernelGGL(k_stats_from_running, dim3(d.A), dim3(128), 0, c.stream, bn_running + c.po.bn_mean[layer],
+                       bn_running + c.po.bn_var[layer], c.po.bn_per_arm, W, c.h.eps, c.ws + L.bn_mean[layer],
+                       c.ws + L.bn_rstd[layer]);
+    HIP_LAUNCH_CHECK("k_stats_from_running");
     return 0;
 }
 
-int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
+int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblk32, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws);
+    hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblk32, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws,
+                       bn_running, nbt);
     HIP_LAUNCH_CHECK("k_lat_fwd");
     return 0;
 }
@@ -853,7 +811,8 @@ int launch_couple(const Ctx& c) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     hipLaunchKernelGGL(k_couple, dim3(L.nblk32), dim3(256), 0, c.stream, d.A, d.B, d.C, c.h.eps, c.h.lam, c.ws + L.CC,
-                       c.ws + L.CSMP, c.ws + L.c_iv, c.ws + L.couple_part, c.ws + L.T_part);
+                       c.ws + L.CSMP, c.ws + L.c_part, c.ws + L.c_mean, c.ws + L.c_iv, c.ws + L.couple_part,
+                       c.ws + L.T_part);
     HIP_LAUNCH_CHECK("k_couple");
     return 0;
 }
@@ -874,16 +833,6 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
     hipLaunchKernelGGL(k_lat_bwd, dim3(c.lay.nblk32, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws);
     HIP_LAUNCH_CHECK("k_lat_bwd");
-    return 0;
-}
-
-int launch_bnb_finalize(const Ctx& c, int layer) {
-    const mmvae_dims& d = c.d;
-    const Layout& L = c.lay;
-    const int W = (layer == 5) ? d.L : d.H;
-    hipLaunchKernelGGL(k_sum_partials, dim3(d.A, cdiv(2 * W, 32)), dim3(256), 0, c.stream, c.ws + L.bnb_part[layer],
-                       L.nblk32, (int64_t)L.nblk32 * 2 * W, (int64_t)2 * W, 2 * W, c.ws + L.bnb_sum[layer]);
-    HIP_LAUNCH_CHECK("k_sum_partials<bn>");
     return 0;
 }
 

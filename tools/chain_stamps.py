@@ -29,3 +29,4 @@ for sid, label in [(20, "encoder layer fc3 (1 layer)"), (4, "decoder chain fc6..
     for n_, c_ in zip(names, v[:5]):
         print(f"  {n_:28s} {c_ / nw:10.0f} cycles/wave {100.0 * c_ / max(tot,1):5.1f}%")
     print(f"  total {tot / nw:.0f} cycles/wave")
+    print("  stats prologue: shift load %.0f, batched loads+accumulate %.0f, barrier %.0f, combine %.0f" % tuple(v[8:12] / nw))

@@ -1,9 +1,8 @@
-"""Diagnostic: per-phase shader cycles of k_fc11_z (MMVAE_ABLATE_Z=8 enables the in-kernel stamps)."""
-import os, sys, torch
-os.environ["MMVAE_ABLATE_Z"] = "8"
+"""Diagnostic: per-phase shader cycles of k_fc11_zt (MMVAE_ABLATE_Z=8 selects the stamped variant)."""
+import os, sys, torch, ctypes as C
+os.environ["MMVAE_ABLATE_Z"] = os.environ.get("STAMP_VARIANT", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import ctypes as C
 import distributed_vae_amd  # noqa
 from distributed_vae_amd import _native as N
 from distributed_vae_amd.nn_model import mixVAE_model
@@ -16,25 +15,17 @@ m = mixVAE_model(input_dim=D, fc_dim=H, n_categories=Cc, state_dim=S, lowD_dim=L
 m.train(); eng = m._ensure(B); hyper = m._hyper(1.0, False); noise = N.make_noise(None, 99, 1)
 eng.forward(hyper, noise, m._flat, m._bn_flat, None, x, 0, None, True); eng.loss(hyper); eng.backward(hyper, noise, m._flat, x, 0, m._flat_grad)
 torch.cuda.synchronize()
-eng.ws.zero_()
-eng.forward(hyper, noise, m._flat, m._bn_flat, None, x, 0, None, True)
+L_ = N.lib(); L_.mmvae_ws_debug_offset.restype = C.c_int64; L_.mmvae_ws_debug_offset.argtypes = [C.POINTER(N.Dims)]
+off = L_.mmvae_ws_debug_offset(C.byref(eng.dims))
+dbg = eng.ws[off: off + 64].view(torch.int64)
+dbg.zero_(); torch.cuda.synchronize()
+eng.debug_stage(10, hyper, noise, m._flat, x, 0, m._flat_grad)
 torch.cuda.synchronize()
-# locate fc11_part: not exported -> scan for the counter block = nonzero u64 sextet; simpler: recompute offset via the C layout
-# (fc11_part follows fc1_slab in make_layout; expose through ws_offset id 19 'dz11' minus GD10 slab is brittle) -> brute force:
-w = eng.ws.view(torch.int64)
-nz = torch.nonzero(w[: w.numel()] > (1 << 20)).flatten()
-cand = [int(i) for i in nz.tolist()[:0]]
-import numpy as np
-wn = w.cpu().numpy()
-# counters: 5 large values followed by the wave count (= 4 * blocks)
-for i in range(len(wn) - 6):
-    if 0 < wn[i + 5] < 100000 and all(wn[i + k] > 1000000 for k in range(5)) and wn[i+5] % 4 == 0:
-        vals = wn[i:i + 6]
-        nw = vals[5]
-        names = ["x-load issue", "z GEMM (104 MFMA)", "W prefetch issue", "epilogue", "W->LDS + barrier"]
-        tot = vals[:5].sum()
-        print("waves", nw)
-        for n_, v in zip(names, vals[:5]):
-            print(f"  {n_:22s} {v / nw:12.0f} cycles/wave  {100.0 * v / tot:5.1f}%")
-        print(f"  total {tot / nw:.0f} cycles/wave = {tot / nw / 2.35e3:.1f} us at 2.35 GHz")
-        break
+v = dbg.cpu().numpy()
+names = ["x-load issue", "MFMA tile (104)", "W prefetch issue", "epilogue", "W->LDS", "barrier wait"]
+for label, o in (("early waves 0-3", 0), ("late waves 4-7", 8)):
+    nw = max(int(v[o + 6]), 1); tot = v[o:o + 6].sum()
+    print(label, "waves", nw)
+    for n_, c_ in zip(names, v[o:o + 6]):
+        print(f"  {n_:20s} {c_ / nw:10.0f} ticks/wave {100.0 * c_ / max(tot, 1):5.1f}%")
+    print(f"  total {tot / nw:.0f} ticks/wave")
