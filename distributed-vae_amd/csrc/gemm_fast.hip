@@ -697,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void k_fc11_zt(const float* __restrict__ d1
     const int gcol = 4 * (l31 >> 2);
     const uint32_t lane_off = (uint32_t)cbase * (uint32_t)D + (uint32_t)gcol;   // interior: + wave-uniform part
     float se = 0.f;
-    int mism = 0;   // wave-uniform count (ballot + popcount on the scalar unit)
+    int mism = 0;   // per-lane count
     f32x16 z0 = zero16(), z1 = zero16();
     float4 xv[2][4];
 
@@ -759,7 +759,6 @@ __global__ __launch_bounds__(512, 2) void k_fc11_zt(const float* __restrict__ d1
                 for (int e = 0; e < 4; ++e) zz[e] = (c == 0 ? z0[4 * q + e] : z1[4 * q + e]);
                 quad_transpose4(zz[0], zz[1], zz[2], zz[3], lb0, lb1);
                 const bool ok = !EDGE || ((cbase + 8 * q < B) && (col < D));
-                const unsigned long long okmask = EDGE ? __ballot(ok) : ~0ull;
                 const float xin[4] = {xs[c][q].x, xs[c][q].y, xs[c][q].z, xs[c][q].w};
                 float xr[4], dzv[4];
 #pragma unroll
@@ -768,8 +767,8 @@ __global__ __launch_bounds__(512, 2) void k_fc11_zt(const float* __restrict__ d1
                     const float er = xr[e] - xin[e];
                     dzv[e] = (xr[e] > 0.f) ? coef * er : 0.f;
                     se += ok ? er * er : 0.f;
-                    // mismatch count on the scalar unit: two compares, xor / and / popcount of the lane masks
-                    mism += __popcll((__ballot(xr[e] > 0.1f) ^ __ballot(xin[e] > 0.1f)) & okmask);
+                    // per-lane count (keeping 64 ballot masks alive spills SGPRs into VGPR lanes)
+                    mism += (ok && ((xr[e] > 0.1f) != (xin[e] > 0.1f))) ? 1 : 0;
                 }
                 if (ok) {
                     if (!EDGE) {
@@ -783,6 +782,12 @@ __global__ __launch_bounds__(512, 2) void k_fc11_zt(const float* __restrict__ d1
                         if (do_grad) *reinterpret_cast<float4*>(dza + off) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
                     }
                 }
+                // piece fence.  The accumulators are pinned here: integer adds are associative, so left alone the
+                // optimiser turns the 32 mismatch increments of a step into one tree at its end and keeps every
+                // compare result (and the x_rec / x values feeding it) alive until then; and the scheduler hoists
+                // all compares to the top and spills their lane masks into VGPR lanes.
+                asm volatile("" : "+v"(mism), "+v"(se));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -869,7 +874,8 @@ __global__ __launch_bounds__(512, 2) void k_fc11_zt(const float* __restrict__ d1
         atomicAdd(dbg + 6, 1ull);
     }
     se = wave_sum(se);
-    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = (float)mism; }
+    const float mismf = wave_sum((float)mism);
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mismf; }
     __syncthreads();
     if (tid == 0) {
         float* p = part + ((int64_t)arm * n11 + (int64_t)blockIdx.x * NS + ns) * 2;
@@ -1041,7 +1047,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         const int kgv = rup(d.H, 8) / 8;
         static const int ablz = getenv("MMVAE_ABLATE_Z") ? atoi(getenv("MMVAE_ABLATE_Z")) : 0;   // timing experiments
         static const int zold = getenv("MMVAE_FC11_ZOLD") ? atoi(getenv("MMVAE_FC11_ZOLD")) : 0;  // A/B timing
-        if (!zold) {
+        if (zold != 1) {
             // one 512-thread workgroup per CU: split the gene range so that the grid fills the chip once
             const int nb = cdiv(d.B, 256);
             int nsz = max(1, min(min(256 / max(nb * d.A, 1), 16), ntall));
