@@ -687,34 +687,100 @@ struct AdamArgs {
 
 // grid (blocks, ndesc, A): descriptor y, arm z; the first `nbig` descriptors use KSbig slabs.  With
 // adam.p != null the Adam/AdamW update of the element is applied in the same pass (single-GPU step).
-__global__ void k_reduce(const RedDescs ds, int KSbig, int KSsmall, int nbig, float* __restrict__ grads,
-                         int64_t per_arm, const AdamArgs adam) {
+// HBM-bound (every slab element is read once): VEC threads own four consecutive columns (16-byte loads), the
+// slab loads of an element are issued sixteen at a time before the first add (a `for k < KS` loop with a
+// running sum waits for one memory latency per slab), and the index arithmetic is 32-bit.
+__device__ __forceinline__ float adam_update1(const AdamArgs& adam, int64_t o, float gi) {
+    float pi = adam.p[o];
+    if (adam.wd != 0.f) {
+        if (adam.decoupled) pi *= (1.f - adam.lr * adam.wd);
+        else gi += adam.wd * pi;
+    }
+    const float mi = adam.b1 * adam.m[o] + (1.f - adam.b1) * gi;
+    const float vi = adam.b2 * adam.v[o] + (1.f - adam.b2) * gi * gi;
+    adam.m[o] = mi;
+    adam.v[o] = vi;
+    return pi - adam.lr_bc1 * (mi / (sqrtf(vi) * adam.inv_sqrt_bc2 + adam.eps));
+}
+
+template <bool VEC>
+__device__ __forceinline__ void reduce_desc(const RedDesc& d, int KS, int arm, float* __restrict__ grads, int64_t per_arm,
+                                            const AdamArgs& adam) {
+    constexpr int E = VEC ? 4 : 1;
+    const uint32_t cpr = (uint32_t)d.cols / E;                       // work items per row
+    const uint32_t n = (uint32_t)d.rows * cpr;
+    const float* base = d.slab + (int64_t)arm * d.arm_stride + d.col0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t r = i / cpr, cidx = (i - r * cpr) * E;
+        const float* p = base + (int64_t)r * d.ld + cidx;
+        float s[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] = 0.f;
+        for (int k0 = 0; k0 < KS; k0 += 16) {
+            float v[16][E];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float* q = p + (int64_t)min(k0 + k, KS - 1) * d.ks_stride;
+                if constexpr (VEC) {
+                    const float4 t = *reinterpret_cast<const float4*>(q);
+                    v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
+                } else {
+                    v[k][0] = *q;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[e] += (k0 + k < KS) ? v[k][e] : 0.f;
+        }
+        const int64_t o = (int64_t)arm * per_arm + d.dst_off + (int64_t)r * d.dst_ld + cidx;
+        float g[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) g[e] = s[e] * d.scale;
+        if constexpr (VEC) {
+            *reinterpret_cast<float4*>(grads + o) = make_float4(g[0], g[1], g[2], g[3]);
+            if (adam.p) {
+                const float4 pi = *reinterpret_cast<const float4*>(adam.p + o);
+                const float4 mi = *reinterpret_cast<const float4*>(adam.m + o);
+                const float4 vi = *reinterpret_cast<const float4*>(adam.v + o);
+                const float pin[4] = {pi.x, pi.y, pi.z, pi.w}, min_[4] = {mi.x, mi.y, mi.z, mi.w}, vin[4] = {vi.x, vi.y, vi.z, vi.w};
+                float po[4], mo[4], vo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = pin[e], ge = g[e];
+                    if (adam.wd != 0.f) {
+                        if (adam.decoupled) pe *= (1.f - adam.lr * adam.wd);
+                        else ge += adam.wd * pe;
+                    }
+                    mo[e] = adam.b1 * min_[e] + (1.f - adam.b1) * ge;
+                    vo[e] = adam.b2 * vin[e] + (1.f - adam.b2) * ge * ge;
+                    po[e] = pe - adam.lr_bc1 * (mo[e] / (sqrtf(vo[e]) * adam.inv_sqrt_bc2 + adam.eps));
+                }
+                *reinterpret_cast<float4*>(adam.m + o) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+                *reinterpret_cast<float4*>(adam.v + o) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+                *reinterpret_cast<float4*>(adam.p + o) = make_float4(po[0], po[1], po[2], po[3]);
+            }
+        } else {
+            grads[o] = g[0];
+            if (adam.p) adam.p[o] = adam_update1(adam, o, g[0]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce(const RedDescs ds, int KSbig, int KSsmall, int nbig,
+                                                float* __restrict__ grads, int64_t per_arm, const AdamArgs adam_in) {
     const int di = blockIdx.y, arm = blockIdx.z;
     const RedDesc& dr = ds.d[di];
     const RedDesc d = {dr.slab, dr.ks_stride, dr.arm_stride, dr.ld, dr.col0, dr.rows, dr.cols, dr.dst_off, dr.dst_ld, dr.scale};
+    const AdamArgs adam = adam_in;
     const int KS = di < nbig ? KSbig : KSsmall;
-    const int64_t n = (int64_t)d.rows * d.cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / d.cols), cidx = (int)(i % d.cols);
-        const float* p = d.slab + (int64_t)arm * d.arm_stride + (int64_t)r * d.ld + d.col0 + cidx;
-        float s = 0.f;
-        for (int k = 0; k < KS; ++k) s += p[(int64_t)k * d.ks_stride];
-        const int64_t o = (int64_t)arm * per_arm + d.dst_off + (int64_t)r * d.dst_ld + cidx;
-        float gi = s * d.scale;
-        grads[o] = gi;
-        if (adam.p) {
-            float pi = adam.p[o];
-            if (adam.wd != 0.f) {
-                if (adam.decoupled) pi *= (1.f - adam.lr * adam.wd);
-                else gi += adam.wd * pi;
-            }
-            const float mi = adam.b1 * adam.m[o] + (1.f - adam.b1) * gi;
-            const float vi = adam.b2 * adam.v[o] + (1.f - adam.b2) * gi * gi;
-            adam.m[o] = mi;
-            adam.v[o] = vi;
-            adam.p[o] = pi - adam.lr_bc1 * (mi / (sqrtf(vi) * adam.inv_sqrt_bc2 + adam.eps));
-        }
-    }
+    // 16-byte path: four-column groups aligned in every slab, in the gradient and in the parameter / moment buffers
+    const bool vec = ((d.cols | d.ld | d.col0 | d.dst_ld) & 3) == 0 && ((d.ks_stride | d.arm_stride | d.dst_off | per_arm) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(d.slab) | reinterpret_cast<uintptr_t>(grads) |
+                       reinterpret_cast<uintptr_t>(adam.p) | reinterpret_cast<uintptr_t>(adam.m) |
+                       reinterpret_cast<uintptr_t>(adam.v)) & 15) == 0;
+    if (vec) reduce_desc<true>(d, KS, arm, grads, per_arm, adam);
+    else reduce_desc<false>(d, KS, arm, grads, per_arm, adam);
 }
 
 __global__ void k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -875,7 +941,7 @@ int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost
     }
     // two launches: the three large tensors want thousands of workgroups, the 23 small ones a handful
     const int64_t big_elems = (int64_t)max(H, 1) * D;
-    const int gx = (int)imin64(1024, cdiv64(big_elems, 256));
+    const int gx = (int)imin64(2048, cdiv64(big_elems / 4, 256));
     hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, L.sp.ks_dw, L.sp.ks_small, nbig, grads,
                        c.po.per_arm, aa);
     HIP_LAUNCH_CHECK("k_reduce<big>");
