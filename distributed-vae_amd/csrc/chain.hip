@@ -308,10 +308,20 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = (cb + part + 8 * j) * 4;
+                    // split-K slabs of the producing GEMM: all (up to 16) requested before the first add -- a loop
+                    // with a running sum waits for one memory latency per slab
                     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int sl = 0; sl < a.nslab; ++sl) {
-                        const float4 t = ldg4_t<V>(G + (int64_t)sl * a.slab_stride, N, b0 + row, col, B, N);
-                        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                    if (a.nslab == 1) g = ldg4_t<V>(G, N, b0 + row, col, B, N);
+                    else for (int s0 = 0; s0 < a.nslab; s0 += 16) {
+                        float4 t[16];
+#pragma unroll
+                        for (int sl = 0; sl < 16; ++sl)
+                            t[sl] = ldg4_t<V>(G + (int64_t)min(s0 + sl, a.nslab - 1) * a.slab_stride, N, b0 + row, col, B, N);
+#pragma unroll
+                        for (int sl = 0; sl < 16; ++sl) {
+                            const bool on = s0 + sl < a.nslab;
+                            g.x += on ? t[sl].x : 0.f; g.y += on ? t[sl].y : 0.f; g.z += on ? t[sl].z : 0.f; g.w += on ? t[sl].w : 0.f;
+                        }
                     }
                     gq[j] = g;
                     avq[j] = ldg4_t<V>(act, N, b0 + row, col, B, N);
