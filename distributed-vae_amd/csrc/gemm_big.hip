@@ -182,10 +182,18 @@ __global__ __launch_bounds__(256) void k_fc1_epi(const float* __restrict__ slab,
     for (int i = 0; i < 4; ++i) {
         const int row = b0 + rg + 8 * i;
         const int rc = min(row, B - 1);
+        // split-K slabs: sixteen requested before the first add (a running-sum loop waits for every load in turn)
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < KS; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(slab + (((int64_t)k * A + arm) * B + rc) * NP + c4 * 4);
-            z.x += t.x; z.y += t.y; z.z += t.z; z.w += t.w;
+        for (int k0 = 0; k0 < KS; k0 += 16) {
+            float4 t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                t[k] = *reinterpret_cast<const float4*>(slab + (((int64_t)min(k0 + k, KS - 1) * A + arm) * B + rc) * NP + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool on = k0 + k < KS;
+                z.x += on ? t[k].x : 0.f; z.y += on ? t[k].y : 0.f; z.z += on ? t[k].z : 0.f; z.w += on ? t[k].w : 0.f;
+            }
         }
         const bool ok = row < B;
         z.x = ok ? fmaxf(scale * z.x + bias[0], 0.f) : 0.f;
