@@ -1,11 +1,17 @@
-// Small-layer chains (every Linear whose dimensions are <= 128 x 256): a row block of 32 cells is
-// carried through up to five layers inside one workgroup, activations staying in LDS, weights
-// staged per layer.  MFMA fp32 32x32x2; wave w owns output columns [32w, 32w+32).
+// Small-layer chains (every Linear whose dimensions are <= 128 x 256): a block of CHAIN_ROWS cells is
+// carried through up to five layers inside one 4 x CHAIN_ROWS / 32-wave workgroup, activations staying in LDS, weights
+// staged per layer.  MFMA fp32 32x32x2; wave (rt, ct) = (wave >> 2, wave & 3) owns rows [32 rt, 32 rt + 32) and
+// output columns [32 ct, 32 ct + 32).
 //
 //   k_chain_fwd   encoder fc2..fc5 one layer per launch (BatchNorm needs the whole batch between
 //                 layers: nn_model.py:265-268), decoder fc6..fc10 in one launch (:277-284)
 //   k_chain_bwd   their autograd: dZ = G .* relu'(out); G_prev = dZ W; with the BatchNorm backward
 //                 folded into the prologue and its batch sums emitted by the epilogue
+//
+// These launches are latency chains (load -> LDS -> 13 MFMAs -> store), not throughput kernels: what a workgroup
+// does once -- recombining the batch statistics from the producer's per-workgroup partials, staging the layer's
+// weights -- is shared by sixteen waves instead of four, and 128-row workgroups emit a quarter of the partials
+// the next launch has to recombine (40 instead of 157 at B = 5000).
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -20,6 +26,9 @@ namespace mmvae {
         }                                                                             \
     } while (0)
 
+constexpr int CH_RT = CHAIN_ROWS / 32;     // 32-row tiles per workgroup
+constexpr int CH_NT = 256 * CH_RT;         // threads per workgroup
+
 struct FwdLayer {
     int64_t w_off, b_off;   // inside one arm's parameter segment
     int64_t out_off;        // workspace, [A,B,N]
@@ -31,11 +40,12 @@ struct ChainFwdArgs {
     int64_t x_off;          // workspace, [A,B,K0]
     int K0;
     int64_t bn_mean_off, bn_rstd_off;   // [A,K0] or -1: input is BatchNorm(x)
-    int64_t bn_part_off;                // >= 0 (training): [A][nblk][2][K0] partials of x to recombine here
+    int64_t bn_part_off;                // >= 0 (training): [A][part_n][2][K0] partials of x to recombine here
+    int part_n, part_rows;              // their count and the rows each covers
     int64_t run_mean_off, run_var_off, run_arm_stride;   // inside bn_running (updated by row block 0)
     int bn_idx;
     float bn_eps, bn_momentum;
-    int64_t stats_part_off;             // [A][nblk][2][N_last] or -1
+    int64_t stats_part_off;             // [A][gridDim.x][2][N_last] or -1
     int B, ld, wrows;
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
@@ -43,7 +53,7 @@ struct ChainFwdArgs {
 };
 
 // stage W [N][K] (global, row-major) into LDS rows [0, rows_pad) x cols [0, cols_pad), zero padded.
-// 8 threads per row (128-B segments), two rows x four chunks in flight per thread, no per-element
+// 8 threads per row (128-B segments), 128 rows per pass, four chunks in flight per thread, no per-element
 // branches: all loads of a pass issue before the first LDS store waits.
 template <bool VEC>
 __device__ __forceinline__ void stage_w_t(float* Ws, int ld, const float* __restrict__ W, int N, int K,
@@ -51,20 +61,15 @@ __device__ __forceinline__ void stage_w_t(float* Ws, int ld, const float* __rest
     const int c4n = cols_pad >> 2;
     const int part = threadIdx.x & 7, r0 = threadIdx.x >> 3;
     for (int cb = 0; cb < c4n; cb += 32) {
-        for (int row = r0; row < rows_pad; row += 64) {
-            float4 v[2][4];
+        for (int row = r0; row < rows_pad; row += CH_NT / 8) {
+            float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int j = 0; j < 4; ++j) v[j] = ldg4_t<VEC>(W, K, row, (cb + part + 8 * j) * 4, N, K);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[u][j] = ldg4_t<VEC>(W, K, row + 32 * u, (cb + part + 8 * j) * 4, N, K);
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = cb + part + 8 * j, rr = row + 32 * u;
-                    if (c < c4n && rr < rows_pad) *reinterpret_cast<float4*>(&Ws[rr * ld + c * 4]) = v[u][j];
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int c = cb + part + 8 * j;
+                if (c < c4n) *reinterpret_cast<float4*>(&Ws[row * ld + c * 4]) = v[j];
+            }
         }
     }
 }
@@ -75,7 +80,7 @@ __device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restri
     else stage_w_t<false>(Ws, ld, W, N, K, rows_pad, cols_pad);
 }
 
-__global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
+__global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
                                                    float* __restrict__ ws, float* __restrict__ bn_running,
                                                    int64_t* __restrict__ nbt) {
     // Copy the argument block into registers once.  Read in place, the kernarg segment may alias the
@@ -83,14 +88,14 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
     // before each re-load, which serialises the epilogue's stores (measured: 47 % of the kernel).
     const ChainFwdArgs a = a_in;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                 // [32][ld]
-    float* Ws = smem + 32 * a.ld;     // [wrows][ld]
-    float* mean_s = Ws + a.wrows * a.ld;   // [128]
-    float* rstd_s = mean_s + 128;          // [128]
-    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* Xs = smem;                         // [CHAIN_ROWS][ld]
+    float* Ws = smem + CHAIN_ROWS * a.ld;     // [wrows][ld]
+    float* mean_s = Ws + a.wrows * a.ld;      // [128]
+    float* rstd_s = mean_s + 128;             // [128]
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * CHAIN_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rt = wv >> 2, ct = wv & 3;
     const int B = a.B, ld = a.ld;
-    const int nvalid = min(32, B - b0);
+    const int nvalid = min(CHAIN_ROWS, B - b0);
     const float* P = params + (int64_t)arm * a.per_arm;
     const bool stamps = (a.ablate & 8) != 0 && a.dbg_off >= 0;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -114,8 +119,8 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
         if (a.bn_part_off >= 0) {
             float m2;
             unsigned long long st[5] = {0, 0, 0, 0, 0};
-            stats_from_partials<256>(ws + a.bn_part_off + (int64_t)arm * gridDim.x * 2 * K0, gridDim.x, B, K0, Ws, mean, m2,
-                                     stamps ? st : nullptr);
+            stats_from_partials<CH_NT>(ws + a.bn_part_off + (int64_t)arm * a.part_n * 2 * K0, a.part_n, B, a.part_rows, K0,
+                                       Ws, mean, m2, stamps ? st : nullptr);
             if (stamps && lane == 0) {
                 unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);
                 for (int i = 0; i < 4; ++i) atomicAdd(dbg + 8 + i, st[i + 1] - st[i]);
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
         const bool bn = a.bn_mean_off >= 0;
         const int c4n = rup(a.K0, 8) >> 2;
         const bool vec = (a.K0 & 3) == 0;    // workspace regions are 256-B aligned, widths multiples of 4
-        const int part = tid & 7, row = tid >> 3;
+        const int part = tid & 7, row = tid >> 3;      // 128 rows x 8 sixteen-byte parts
         auto stage_x = [&](auto tag) __attribute__((always_inline)) {
             constexpr bool V = decltype(tag)::value;
             for (int cb = 0; cb < c4n; cb += 32) {
@@ -177,26 +182,26 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
     for (int l = 0; l < a.nlayers; ++l) {
         const FwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
-        if (!(a.ablate & 2) || l == 0) stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
+        stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
+        const int col = ct * 32 + (lane & 31);
+        const bool active = ct * 32 < NPad;
+        const float bias = (active && col < N) ? P[Lr.b_off + col] : 0.f;   // requested before the barrier
         stamp(1);
         lds_barrier();
         stamp(2);
         f32x16 acc = zero16();
-        const bool active = wv * 32 < NPad;
-        if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, 0, Ws, ld, wv * 32, KP / 8);
+        if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, rt * 32, Ws, ld, ct * 32, KP / 8);
         if (stamps) asm volatile("" :: "v"(acc[0]));
         stamp(3);
         lds_barrier();   // every wave has finished reading Xs / Ws
         stamp(2);
-        const int col = wv * 32 + (lane & 31);
         const bool last = (l + 1 == a.nlayers);
         float vals[16];
         if (active) {
-            const float bias = (col < N) ? P[Lr.b_off + col] : 0.f;
             float* out = ws + Lr.out_off + (int64_t)arm * B * N;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, lane);
+                const int row = rt * 32 + acc_row(r, lane);
                 float v = 0.f;
                 if (col < N && row < nvalid) {
                     v = acc[r] + bias;
@@ -209,25 +214,41 @@ __global__ __launch_bounds__(256) void k_chain_fwd(const ChainFwdArgs a_in, cons
             }
         }
         if (last && a.stats_part_off >= 0) {
-            // per-block column mean and M2 over the nvalid rows; lanes l and l^32 share a column
+            // per-workgroup column mean and M2 over the nvalid rows: each wave over its own (up to 32) rows --
+            // lanes l and l^32 share a column --, then Chan's update over the four row tiles through LDS
+            // (Ws is free: every wave is past the GEMM barrier)
+            const int nv = max(0, min(32, nvalid - rt * 32));
             if (active) {
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += vals[r];
                 s += __shfl_xor(s, 32, 64);
-                const float mean = s / (float)nvalid;
+                const float mean = nv > 0 ? s / (float)nv : 0.f;
                 float m2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(r, lane);
+                    const int row = rt * 32 + acc_row(r, lane);
                     if (row < nvalid) { const float dl = vals[r] - mean; m2 += dl * dl; }
                 }
                 m2 += __shfl_xor(m2, 32, 64);
-                if (lane < 32 && col < N) {
-                    float* p = ws + a.stats_part_off + (((int64_t)arm * gridDim.x + blk) * 2) * N;
-                    p[col] = mean;
-                    p[N + col] = m2;
+                if (lane < 32) { Ws[(rt * 2 + 0) * 128 + col] = mean; Ws[(rt * 2 + 1) * 128 + col] = m2; }
+            }
+            lds_barrier();
+            if (rt == 0 && active && lane < 32 && col < N) {
+                float n = 0.f, mu = 0.f, M2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH_RT; ++k) {
+                    const float nb = (float)max(0, min(32, nvalid - k * 32));
+                    if (nb > 0.f) {
+                        const float nn = n + nb, dl = Ws[(k * 2 + 0) * 128 + col] - mu;
+                        mu += dl * (nb / nn);
+                        M2 += Ws[(k * 2 + 1) * 128 + col] + dl * dl * (n * nb / nn);
+                        n = nn;
+                    }
                 }
+                float* p = ws + a.stats_part_off + (((int64_t)arm * gridDim.x + blk) * 2) * N;
+                p[col] = mu;
+                p[N + col] = M2;
             }
         }
         stamp(4);
@@ -254,35 +275,35 @@ struct ChainBwdArgs {
     int64_t g_off;          // [nslab][A,B,N0] gradient w.r.t. the output of L[0] (after its BN if any)
     int nslab;
     int64_t slab_stride;
-    int64_t bnb_part_off;   // [A][nblk][2][N0] per-row-block sums (sum G, sum G*xhat), recombined here, or -1:
-                            // BN backward prologue
+    int64_t bnb_part_off;   // [A][bnb_n][2][N0] per-workgroup sums (sum G, sum G*xhat), recombined here, or -1:
+    int bnb_n;              // BN backward prologue
     int64_t bn_mean_off, bn_rstd_off;   // statistics of L[0]'s output, [A,N0]
     int64_t gout_off;       // [A,B,Klast]
-    int64_t part_off;       // [A][nblk][2][Klast] or -1: sums of gout and gout*xhat_prev
+    int64_t part_off;       // [A][gridDim.x][2][Klast] or -1: sums of gout and gout*xhat_prev
     int64_t rprev_off, rprev_mean_off, rprev_rstd_off;   // the BN input that produced the chain input
     int B, ld, wrows;
     int64_t per_arm;
 };
 
-__global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, const float* __restrict__ params,
+__global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, const float* __restrict__ params,
                                                    float* __restrict__ ws) {
     const ChainBwdArgs a = a_in;   // see k_chain_fwd: keep the argument block out of memory
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Gs = smem;                // [32][ld]
-    float* Ws = smem + 32 * a.ld;    // [128][ld]  rows = n (output features), cols = k (input features)
-    float* sums_s = Ws + a.wrows * a.ld;   // [2][128]: sum G, sum G*xhat over the batch
-    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* Gs = smem;                        // [CHAIN_ROWS][ld]
+    float* Ws = smem + CHAIN_ROWS * a.ld;    // [wrows][ld]  rows = n (output features), cols = k (input features)
+    float* sums_s = Ws + a.wrows * a.ld;     // [2][128]: sum G, sum G*xhat over the batch
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * CHAIN_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rt = wv >> 2, ct = wv & 3;
     const int B = a.B, ld = a.ld;
-    const int nvalid = min(32, B - b0);
+    const int nvalid = min(CHAIN_ROWS, B - b0);
     const float* P = params + (int64_t)arm * a.per_arm;
 
     if (a.bnb_part_off >= 0) {
         const int N = a.L[0].N;
-        const float r = sums_from_partials<256>(ws + a.bnb_part_off + (int64_t)arm * gridDim.x * 2 * N, gridDim.x, 2 * N,
-                                                reinterpret_cast<double*>(Ws));
+        const float r = sums_from_partials<CH_NT>(ws + a.bnb_part_off + (int64_t)arm * a.bnb_n * 2 * N, a.bnb_n, 2 * N,
+                                                  reinterpret_cast<double*>(Ws));
         // thread t < 2N holds sum t of [sum G | sum G*xhat]; spread to [2][128], zero beyond N
-        sums_s[tid] = 0.f;
+        if (tid < 256) sums_s[tid] = 0.f;
         lds_barrier();
         if (tid < 2 * N) sums_s[tid < N ? tid : 128 + tid - N] = r;
         lds_barrier();
@@ -299,7 +320,7 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
         const float* rs = bnb ? ws + a.bn_rstd_off + (int64_t)arm * N : G;
         const float invB = 1.f / (float)B;
         const bool vec = (N & 3) == 0;
-        const int part = tid & 7, row = tid >> 3;
+        const int part = tid & 7, row = tid >> 3;      // 128 rows x 8 sixteen-byte parts
         const bool rok = row < nvalid;
         auto stage_g = [&](auto tag) __attribute__((always_inline)) {
             constexpr bool V = decltype(tag)::value;
@@ -376,17 +397,18 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
         f32x16 accs[2] = {zero16(), zero16()};
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
-            const int ct = wv + 4 * ti;
-            if (ct * 32 < KPad) mma_nn(accs[ti], Gs, ld, 0, Ws, ld, ct * 32, NP8 / 8);
+            const int cti = ct + 4 * ti;
+            if (cti * 32 < KPad) mma_nn(accs[ti], Gs, ld, rt * 32, Ws, ld, cti * 32, NP8 / 8);
         }
         lds_barrier();
         const bool last = (l + 1 == a.nlayers);
+        float ps1[2] = {0.f, 0.f}, ps2[2] = {0.f, 0.f};
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
-            const int ct = wv + 4 * ti;
-            if (ct * 32 >= KPad) continue;
+            const int cti = ct + 4 * ti;
+            if (cti * 32 >= KPad) continue;
             const f32x16 acc = accs[ti];
-            const int col = ct * 32 + (lane & 31);
+            const int col = cti * 32 + (lane & 31);
             if (!last) {
                 const BwdLayer Ln = a.L[l + 1];   // its N == this K
                 const float* act = Ln.act_off >= 0 ? ws + Ln.act_off + (int64_t)arm * B * K : nullptr;
@@ -394,13 +416,13 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
                 float av[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(r, lane);
+                    const int row = rt * 32 + acc_row(r, lane);
                     const bool ok = col < K && row < nvalid;
                     av[r] = (act && ok) ? act[(int64_t)(b0 + row) * K + col] : 1.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(r, lane);
+                    const int row = rt * 32 + acc_row(r, lane);
                     const bool ok = col < K && row < nvalid;
                     const float v = (ok && av[r] > 0.f) ? acc[r] : 0.f;
                     if (ok) dz[(int64_t)(b0 + row) * K + col] = v;
@@ -419,13 +441,13 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
                 float rv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(r, lane);
+                    const int row = rt * 32 + acc_row(r, lane);
                     const bool ok = col < K && row < nvalid;
                     rv[r] = (want && ok) ? rp[(int64_t)(b0 + row) * K + col] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(r, lane);
+                    const int row = rt * 32 + acc_row(r, lane);
                     if (col < K && row < nvalid) {
                         go[(int64_t)(b0 + row) * K + col] = acc[r];
                         s1 += acc[r];
@@ -435,12 +457,26 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
                 if (want) {
                     s1 += __shfl_xor(s1, 32, 64);
                     s2 += __shfl_xor(s2, 32, 64);
-                    if (lane < 32 && col < K) {
-                        float* p = ws + a.part_off + (((int64_t)arm * gridDim.x + blk) * 2) * K;
-                        p[col] = s1;
-                        p[K + col] = s2;
-                    }
+                    ps1[ti] = s1;
+                    ps2[ti] = s2;
                 }
+            }
+        }
+        if (last && a.part_off >= 0) {
+            // per-workgroup sums over the row tiles through LDS (Ws is free after the GEMM barrier): [rt][2][256]
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int col = (ct + 4 * ti) * 32 + (lane & 31);
+                if (lane < 32) { Ws[(rt * 2 + 0) * 256 + col] = ps1[ti]; Ws[(rt * 2 + 1) * 256 + col] = ps2[ti]; }
+            }
+            lds_barrier();
+            if (tid < K) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < CH_RT; ++k) { t1 += Ws[(k * 2 + 0) * 256 + tid]; t2 += Ws[(k * 2 + 1) * 256 + tid]; }
+                float* p = ws + a.part_off + (((int64_t)arm * gridDim.x + blk) * 2) * K;
+                p[tid] = t1;
+                p[K + tid] = t2;
             }
         }
         lds_barrier();
@@ -448,14 +484,15 @@ __global__ __launch_bounds__(256) void k_chain_bwd(const ChainBwdArgs a_in, cons
 }
 
 // DZ1 = BNbackward(G1) .* relu'(R1).  grid (ceil(B/32), A): every row block recombines the batch sums
-// (part: [A][nblk][2][W] from fc2's backward) and applies them to its 32 rows.
+// (part: [A][npart][2][W] from fc2's backward) and applies them to its 32 rows.
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ R,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      const float* __restrict__ part, float* __restrict__ DZ, int B, int W) {
+                                                      const float* __restrict__ part, int npart, float* __restrict__ DZ,
+                                                      int B, int W) {
     __shared__ __attribute__((aligned(16))) double scratch[1024];
     __shared__ float sums_s[2][128], mu_s[128], rs_s[128];
     const int arm = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
-    const float r = sums_from_partials<256>(part + (int64_t)arm * gridDim.x * 2 * W, gridDim.x, 2 * W, scratch);
+    const float r = sums_from_partials<256>(part + (int64_t)arm * npart * 2 * W, npart, 2 * W, scratch);
     if (tid < 2 * W) sums_s[tid < W ? 0 : 1][tid < W ? tid : tid - W] = r;
     if (tid < W) { mu_s[tid] = mean[arm * W + tid]; rs_s[tid] = rstd[arm * W + tid]; }
     lds_barrier();
@@ -478,10 +515,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // forward: activations and weights are K-contiguous rows -> ld = max width rounded to 8, + 4
 // (ld/4 odd: conflict-free ds_read_b128); weights need rup(N,32) rows.
 // backward: weight tile is [N rows][K cols] read along K by lane -> ld = rup(K,32) + 4, rup(N,8) rows.
+// The weight tile doubles as scratch: statistics prologue 3 x 16 x 128 floats, batch-sum prologue 16 x 256 doubles,
+// epilogue sums CH_RT x 2 x 256 floats.
+constexpr int WS_SCRATCH = 8192;
 static int fwd_ld(int maxdim) { return rup(maxdim, 8) + 4; }
 static int bwd_ld(int maxdim) { return rup(maxdim, 32) + 4; }
 // + 256 floats: the BatchNorm statistics (forward) / batch sums (backward) every row block recombines
-static size_t chain_smem(int ld, int wrows) { return (size_t)(32 * ld + wrows * ld + 256) * sizeof(float); }
+static size_t chain_smem(int ld, int wrows) { return (size_t)(CHAIN_ROWS * ld + wrows * ld + 256) * sizeof(float); }
 
 int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn_running, int64_t* nbt) {
     // layer in 2..5: out = relu(BN_{layer-1}(R_{layer-1}) W^T + b), statistics of the output
@@ -498,7 +538,10 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     a.bn_rstd_off = L.bn_rstd[i - 1];
     // training: this launch recombines BN_{layer-1}'s partials itself (and row block 0 updates the running
     // buffers); eval: launch_bn_eval_stats has put the running statistics into the workspace
+    // BN1's partials come from the fc1 epilogue (32-row blocks), the others from the previous chain launch
     a.bn_part_off = c.h.training ? L.bn_part[i - 1] : -1;
+    a.part_n = (layer == 2) ? L.nblk32 : L.nblkc;
+    a.part_rows = (layer == 2) ? 32 : CHAIN_ROWS;
     a.run_mean_off = c.po.bn_mean[i - 1];
     a.run_var_off = c.po.bn_var[i - 1];
     a.run_arm_stride = c.po.bn_per_arm;
@@ -508,11 +551,11 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     a.stats_part_off = L.bn_part[i];
     a.B = d.B;
     a.ld = fwd_ld(max(d.H, N));
-    a.wrows = rup(N, 32);
+    a.wrows = max(rup(N, 32), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch (statistics prologue / epilogue)
     a.per_arm = c.po.per_arm;
     a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
     a.dbg_off = L.loss_scratch + 2048;
-    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws, bn_running, nbt);
     HIP_LAUNCH_CHECK("k_chain_fwd<enc>");
     return 0;
@@ -538,7 +581,7 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.per_arm = c.po.per_arm;
     a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
     a.dbg_off = L.loss_scratch + 2048;
-    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws, (float*)nullptr, (int64_t*)nullptr);
     HIP_LAUNCH_CHECK("k_chain_fwd<dec>");
     return 0;
@@ -564,9 +607,9 @@ int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {
     a.rprev_off = a.rprev_mean_off = a.rprev_rstd_off = -1;
     a.B = d.B;
     a.ld = bwd_ld(max(max(d.H, d.L), d.C + d.S));
-    a.wrows = rup(max(d.H, d.L), 8);
+    a.wrows = max(rup(max(d.H, d.L), 8), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch of the epilogue's sums
     a.per_arm = c.po.per_arm;
-    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws);
     HIP_LAUNCH_CHECK("k_chain_bwd<dec>");
     return 0;
@@ -584,7 +627,9 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.g_off = L.G[layer];
     a.nslab = 1;
     a.slab_stride = 0;
+    // BN_layer's backward sums: per 32-row block from the latent backward (layer 5), else from the previous launch
     a.bnb_part_off = L.bnb_part[layer];
+    a.bnb_n = (layer == 5) ? L.nblk32 : L.nblkc;
     a.bn_mean_off = L.bn_mean[i];
     a.bn_rstd_off = L.bn_rstd[i];
     a.gout_off = L.G[layer - 1];
@@ -594,9 +639,9 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.rprev_rstd_off = L.bn_rstd[i - 1];
     a.B = d.B;
     a.ld = bwd_ld(max(d.H, N));
-    a.wrows = rup(N, 8);
+    a.wrows = max(rup(N, 8), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch (batch-sum prologue / epilogue)
     a.per_arm = c.po.per_arm;
-    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblk32, d.A), dim3(256), chain_smem(a.ld, a.wrows), c.stream, a, params,
+    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws);
     HIP_LAUNCH_CHECK("k_chain_bwd<enc>");
     return 0;
@@ -606,7 +651,7 @@ int launch_bn_bwd_apply1(const Ctx& c) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(L.nblk32, d.A), dim3(256), 0, c.stream, c.ws + L.G[1], c.ws + L.R[0],
-                       c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_part[1], c.ws + L.DZ[1], d.B, d.H);
+                       c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_part[1], L.nblkc, c.ws + L.DZ[1], d.B, d.H);
     HIP_LAUNCH_CHECK("k_bn_bwd_apply");
     return 0;
 }

@@ -40,6 +40,7 @@ struct Layout {
     Splits sp;
     // forward, saved for backward
     int64_t R[5];                  // R1..R4 [A,B,H], R5 [A,B,L]
+    int nblkc;                       // ceil(B / CHAIN_ROWS)
     int64_t bn_mean[5], bn_rstd[5];  // [A,W]
     int64_t bn_part[5];            // [A][nblk32][2][W]   (block mean, block M2)
     int64_t XLOW, CPROB, CC, YSOFT, CSMP, Y, MS, MU, LV, SS, ZIN;
@@ -264,14 +265,16 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // partials itself (125 KB out of L2 at B = 5000, W = 100; all workgroups compute bit-identical
 // results because the order is fixed by (NT, nblk) alone).
 //
-// part: [nblk][2][W] = (block mean, block M2) over min(32, B - 32 blk) rows.  All NT threads call;
+// part: [nblk][2][W] = (block mean, block M2) over min(PR, B - PR blk) rows.  All NT threads call;
 // thread t < W returns column t's (mean, M2) over the whole batch.  scratch: 3 * PART_MAXG * W floats
 // of LDS the caller does not need until the next barrier it executes itself.
 constexpr int PART_MAXG = 16;
 constexpr int PART_BATCH = 16;
+// rows per workgroup of the small-layer chain kernels (chain.hip) = rows per statistics partial they emit
+constexpr int CHAIN_ROWS = 64;
 
 template <bool VEC, int NT>
-__device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int W,
+__device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int PR, int W,
                                                       float* scratch, float& mean_out, float& m2_out,
                                                       unsigned long long* st = nullptr) {
     auto tick = [&](int i) {
@@ -315,7 +318,7 @@ __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < PART_BATCH; ++j) {
                 const int i = i0 + j * G;
-                const float nb = i < nblk ? (float)min(32, B - 32 * i) : 0.f;
+                const float nb = i < nblk ? (float)min(PR, B - PR * i) : 0.f;
                 const float w = is_mean ? nb : (i < nblk ? 1.f : 0.f);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
@@ -343,7 +346,7 @@ __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ 
     if (t < W) {
         for (int k = 0; k < G; ++k) {   // Chan's pairwise update over the groups, fixed order
             const int cnt = (nblk - k + G - 1) / G;
-            const float nb = (float)(32 * cnt - (((nblk - 1) % G == k) ? 32 * nblk - B : 0));
+            const float nb = (float)(PR * cnt - (((nblk - 1) % G == k) ? PR * nblk - B : 0));
             const float mg = scratch[(k * 3 + 0) * W + t];
             const float m2g = scratch[(k * 3 + 1) * W + t] + scratch[(k * 3 + 2) * W + t];
             const float nn = n + nb, dl = mg - mean;
@@ -357,11 +360,11 @@ __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ 
     tick(4);
 }
 template <int NT>
-__device__ __forceinline__ void stats_from_partials(const float* __restrict__ part, int nblk, int B, int W,
+__device__ __forceinline__ void stats_from_partials(const float* __restrict__ part, int nblk, int B, int PR, int W,
                                                     float* scratch, float& mean_out, float& m2_out,
                                                     unsigned long long* st = nullptr) {
-    if ((W & 3) == 0) stats_from_partials_t<true, NT>(part, nblk, B, W, scratch, mean_out, m2_out, st);
-    else stats_from_partials_t<false, NT>(part, nblk, B, W, scratch, mean_out, m2_out, st);
+    if ((W & 3) == 0) stats_from_partials_t<true, NT>(part, nblk, B, PR, W, scratch, mean_out, m2_out, st);
+    else stats_from_partials_t<false, NT>(part, nblk, B, PR, W, scratch, mean_out, m2_out, st);
 }
 
 // part: [nblk][n] plain partial sums -> thread t < n returns sum over blocks of part[.][t].

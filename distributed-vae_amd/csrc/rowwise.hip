@@ -67,6 +67,7 @@ struct LatArgs {
     int64_t dbg_off;   // >= 0: diagnostic stamp counters (MMVAE_ABLATE_L=8)
     // forward, training: BN5's partials [A][nblk][2][L] are recombined by every row block
     int64_t bn_part5, run_mean_off, run_var_off, run_arm_stride;
+    int bn5_n;             // partials fc5's launch emitted (one per CHAIN_ROWS cells)
     float bn_momentum;
 };
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
     float kl_acc = 0.f, ent_acc = 0.f;
     if (a.bn_part5 >= 0) {   // training: BN5 batch statistics from fc5's per-row-block partials
         float mean, m2;
-        stats_from_partials<64 * LAT_NW>(ws + a.bn_part5 + (int64_t)arm * gridDim.x * 2 * L, gridDim.x, B, L,
+        stats_from_partials<64 * LAT_NW>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L,
                                          &sh_stat[0][0][0], mean, m2);
         if (threadIdx.x < L) {
             const int t = threadIdx.x;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void k_couple(int A, int B, int C, float eps, 
     // from k_lat_fwd's per-row-block partials [A][nblk][2][C]; row block 0 keeps them for the backward
     for (int aa = 0; aa < A; ++aa) {
         float mean, m2;
-        stats_from_partials<256>(c_part + (int64_t)aa * gridDim.x * 2 * C, gridDim.x, B, C, &shT[0][0][0], mean, m2);
+        stats_from_partials<256>(c_part + (int64_t)aa * gridDim.x * 2 * C, gridDim.x, B, 32, C, &shT[0][0][0], mean, m2);
         if (threadIdx.x < C) {
             const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
             sh_iv[aa][threadIdx.x] = ivv;
@@ -841,6 +842,7 @@ static LatArgs make_lat_args(const Ctx& c) {
     a.T = L.T; a.c_mean = L.c_mean; a.c_iv = L.c_iv;
     a.am1 = (float)(d.A > 1 ? d.A - 1 : 1); a.beta = c.h.beta; a.lam = c.h.lam;
     a.bn_part5 = c.h.training ? L.bn_part[4] : -1;
+    a.bn5_n = L.nblkc;
     a.run_mean_off = c.po.bn_mean[4]; a.run_var_off = c.po.bn_var[4]; a.run_arm_stride = c.po.bn_per_arm;
     a.bn_momentum = c.h.bn_momentum;
     static const int abl = getenv("MMVAE_ABLATE_L") ? atoi(getenv("MMVAE_ABLATE_L")) : 0;
