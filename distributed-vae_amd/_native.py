@@ -104,6 +104,11 @@ def lib():
         getattr(L, fn).restype = C.c_int
     if L.mmvae_abi_version() != 1:
         raise NativeError("libmmvae_hip.so ABI version mismatch")
+    # tuning knobs (timing experiments): MMVAE_SPLIT<i>=<n> overrides split factor i of mmvae_set_split
+    for w in range(6):
+        v = os.environ.get(f"MMVAE_SPLIT{w}")
+        if v:
+            L.mmvae_set_split(w, int(v))
     _lib = L
     return L
 

@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static int g_split[5] = {0, 0, 0, 0, 0};
+static int g_split[6] = {0, 0, 0, 0, 0, 0};
 
 // Split factors are chosen so that each large kernel's grid fills the chip's resident-workgroup
 // slots once (256 CUs x workgroups per CU that its registers / LDS admit) without spilling into a
@@ -39,6 +39,11 @@ Splits default_splits(const mmvae_dims& d) {
     // dW1 / dW11: 128-gene tiles, 4 workgroups / CU
     s.ks_dw = g_split[2] > 0 ? g_split[2] : fit(cdiv(d.D, fastdims ? 128 : 64) * d.A, 4 * CUS, 16);
     s.ks_dw = min(s.ks_dw, max(1, cdiv(d.B, 32)));
+    // dW11 runs on the side stream beside the latency-bound backward chain, which hides it: fewer, longer
+    // workgroups (about 1.6 per CU) cost nothing there and halve the slabs the reduction has to read
+    s.ks_dw11 = g_split[5] > 0 ? g_split[5] : fit(cdiv(d.D, 128) * d.A, 13 * CUS / 8, 16);
+    s.ks_dw11 = min(s.ks_dw11, max(1, cdiv(d.B, 32)));
+    if (!fastdims) s.ks_dw11 = s.ks_dw;
     s.ks_small = g_split[3] > 0 ? g_split[3] : fit(N_SMALL * d.A, 3 * CUS, 32);   // 3 workgroups / CU (136 VGPRs)
     s.ks_small = min(s.ks_small, max(1, cdiv(d.B, 32)));
     s.ks_gd10 = g_split[4] > 0 ? g_split[4] : fit(nb128 * d.A, 3 * CUS, 16);
@@ -110,7 +115,7 @@ Layout make_layout(const mmvae_dims& d) {
         L.bnb_sum[i] = take(A * 2 * W);
     }
     L.dw1_slab = take((int64_t)L.sp.ks_dw * A * H * D);
-    L.dw11_slab = take((int64_t)L.sp.ks_dw * A * D * DW11_LD);
+    L.dw11_slab = take((int64_t)max(L.sp.ks_dw, L.sp.ks_dw11) * A * D * DW11_LD);
     L.small_slab = take((int64_t)L.sp.ks_small * A * N_SMALL * NP * SMALL_LD);
     L.xbits = take(A * B * cdiv(d.D, 32));
     L.loss_scratch = take(4096);
@@ -239,7 +244,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     }
     if ((rc = launch_dw_small(c))) return rc;
     if (forked && hipStreamWaitEvent(c.stream, g_ev_join, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
-    return launch_reduce_grads(c, grads, grad_scale, adam);
+    return launch_reduce_grads(c, grads, grad_scale, adam, fast);
 }
 
 }  // namespace mmvae
@@ -258,7 +263,7 @@ int mmvae_set_side_stream(void* side_stream) {
 }
 
 int mmvae_set_split(int which, int value) {
-    if (which < 0 || which > 4 || value < 0 || value > 64) { set_error("bad split"); return MMVAE_E_BADARG; }
+    if (which < 0 || which > 5 || value < 0 || value > 64) { set_error("bad split"); return MMVAE_E_BADARG; }
     g_split[which] = value;
     return 0;
 }
@@ -420,7 +425,7 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
         case 5: return launch_chain_bwd_dec(c, params, fc11_split_path(c, params, x, x_arm_stride) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11);
         case 6: return launch_lat_fwd(c, nz, params, nullptr, nullptr);
         case 7: return launch_lat_bwd(c, nz, params);
-        case 8: if (!grads) { set_error("grads is null"); return MMVAE_E_BADARG; } return launch_reduce_grads(c, grads, 1.f);
+        case 8: if (!grads) { set_error("grads is null"); return MMVAE_E_BADARG; } return launch_reduce_grads(c, grads, 1.f, nullptr, fast_path_ok(c, params, x, x_arm_stride));
         default: set_error("unknown stage %d", stage); return MMVAE_E_BADARG;
     }
 }

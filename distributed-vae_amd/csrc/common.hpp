@@ -27,7 +27,8 @@ __host__ __device__ inline int64_t imin64(int64_t a, int64_t b) { return a < b ?
 struct Splits {
     int ks_fc1;   // split-K of fc1 forward
     int ns_fc11;  // column splits of the fused fc11 kernel
-    int ks_dw;    // batch splits of the dW1 / dW11 GEMMs
+    int ks_dw;    // batch splits of the dW1 GEMM (and of both big dW GEMMs on the general path)
+    int ks_dw11;  // batch splits of the dW11 GEMM on the fast path
     int ks_small; // batch splits of the batched small-layer dW GEMM
     int ks_gd10;  // gene splits of the d(d10) = dZ11 W11 GEMM (fast path; the fused general kernel uses ns_fc11)
 };
@@ -538,7 +539,7 @@ int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t x
 int launch_dw_small(const Ctx& c);
 struct AdamHost { float* p; float* m; float* v; int64_t step; float lr, b1, b2, eps, wd; int decoupled; };
 // slabs -> grads; with `adam` (p != null) the Adam update is fused into the same pass
-int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale, const AdamHost* adam = nullptr);
+int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale, const AdamHost* adam, bool dw11_fast);
 int launch_adam(int64_t n, float* p, const float* g, float* m, float* v, int64_t step, float lr, float b1,
                 float b2, float eps, float wd, int decoupled, hipStream_t s);
 bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs);

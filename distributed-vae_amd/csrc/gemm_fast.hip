@@ -1128,10 +1128,11 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
     }
     if (which & 2) {   // [dW11 | db11][j][h] = sum_b dZ11[b][j] [d10 | 1][b][h]   -> slab [KS][A][D][DW11_LD]
         const int tiles_n = cdiv(d.H + 1, 128);
-        dim3 grid(cdiv(d.D, 128) * tiles_n, KS, d.A);
+        const int KS11 = L.sp.ks_dw11;
+        dim3 grid(cdiv(d.D, 128) * tiles_n, KS11, d.A);
         hipLaunchKernelGGL((k_tn_v2<false, true>), grid, dim3(256), 0, c.stream, c.ws + L.DZ11, (int64_t)d.B * d.D,
                            d.D, d.D, c.ws + L.Dk[4], (int64_t)d.B * d.H, d.H, d.H, bits, wpr, c.ws + L.dw11_slab,
-                           (int64_t)d.D * DW11_LD, (int64_t)d.A * d.D * DW11_LD, DW11_LD, d.B, KS, tiles_n);
+                           (int64_t)d.D * DW11_LD, (int64_t)d.A * d.D * DW11_LD, DW11_LD, d.B, KS11, tiles_n);
         HIP_LAUNCH_CHECK("k_tn_v2<dW11>");
     }
     return 0;

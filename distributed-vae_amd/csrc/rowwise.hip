@@ -676,6 +676,7 @@ struct RedDesc {
     int rows, cols;
     int64_t dst_off; int dst_ld;
     float scale;
+    int ks;   // slabs to sum
 };
 constexpr int MAX_RED = 28;
 struct RedDescs { RedDesc d[MAX_RED]; };
@@ -686,7 +687,7 @@ struct AdamArgs {
     int decoupled;
 };
 
-// grid (blocks, ndesc, A): descriptor y, arm z; the first `nbig` descriptors use KSbig slabs.  With
+// grid (blocks, ndesc, A): descriptor y, arm z.  With
 // adam.p != null the Adam/AdamW update of the element is applied in the same pass (single-GPU step).
 // HBM-bound (every slab element is read once): VEC threads own four consecutive columns (16-byte loads), the
 // slab loads of an element are issued sixteen at a time before the first add (a `for k < KS` loop with a
@@ -768,13 +769,13 @@ __device__ __forceinline__ void reduce_desc(const RedDesc& d, int KS, int arm, f
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce(const RedDescs ds, int KSbig, int KSsmall, int nbig,
-                                                float* __restrict__ grads, int64_t per_arm, const AdamArgs adam_in) {
+__global__ __launch_bounds__(256) void k_reduce(const RedDescs ds, float* __restrict__ grads, int64_t per_arm,
+                                                const AdamArgs adam_in) {
     const int di = blockIdx.y, arm = blockIdx.z;
     const RedDesc& dr = ds.d[di];
-    const RedDesc d = {dr.slab, dr.ks_stride, dr.arm_stride, dr.ld, dr.col0, dr.rows, dr.cols, dr.dst_off, dr.dst_ld, dr.scale};
+    const RedDesc d = {dr.slab, dr.ks_stride, dr.arm_stride, dr.ld, dr.col0, dr.rows, dr.cols, dr.dst_off, dr.dst_ld, dr.scale, dr.ks};
     const AdamArgs adam = adam_in;
-    const int KS = di < nbig ? KSbig : KSsmall;
+    const int KS = d.ks;
     // 16-byte path: four-column groups aligned in every slab, in the gradient and in the parameter / moment buffers
     const bool vec = ((d.cols | d.ld | d.col0 | d.dst_ld) & 3) == 0 && ((d.ks_stride | d.arm_stride | d.dst_off | per_arm) & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(d.slab) | reinterpret_cast<uintptr_t>(grads) |
@@ -904,23 +905,24 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     return 0;
 }
 
-int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost* ah) {
+int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost* ah, bool dw11_fast) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int A = d.A, H = d.H, D = d.D, Ld = d.L, C = d.C, S = d.S;
     RedDescs ds{};
     int n = 0;
     const float xscale = (c.h.training && c.h.x_drop > 0.f) ? 1.f / (1.f - c.h.x_drop) : 1.f;
-    // big: fc1.w, fc11.w, fc11.b
-    ds.d[n++] = RedDesc{c.ws + L.dw1_slab, (int64_t)A * H * D, (int64_t)H * D, D, 0, H, D, c.po.o[0], D, gscale * xscale};
-    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * DW11_LD, (int64_t)D * DW11_LD, DW11_LD, 0, D, H, c.po.o[26], H, gscale};
-    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * DW11_LD, (int64_t)D * DW11_LD, DW11_LD, H, D, 1, c.po.o[27], 1, gscale};
+    // big: fc1.w, fc11.w, fc11.b (the general path's dW11 uses ks_dw slabs, the fast path's its own count)
+    const int ks11 = dw11_fast ? L.sp.ks_dw11 : L.sp.ks_dw;
+    ds.d[n++] = RedDesc{c.ws + L.dw1_slab, (int64_t)A * H * D, (int64_t)H * D, D, 0, H, D, c.po.o[0], D, gscale * xscale, L.sp.ks_dw};
+    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * DW11_LD, (int64_t)D * DW11_LD, DW11_LD, 0, D, H, c.po.o[26], H, gscale, ks11};
+    ds.d[n++] = RedDesc{c.ws + L.dw11_slab, (int64_t)A * D * DW11_LD, (int64_t)D * DW11_LD, DW11_LD, H, D, 1, c.po.o[27], 1, gscale, ks11};
     const int nbig = n;
     const int64_t sks = (int64_t)A * N_SMALL * NP * SMALL_LD, sarm = (int64_t)N_SMALL * NP * SMALL_LD;
     auto small = [&](int i, int N, int K, int64_t w_off, int64_t b_off) {
         const float* s = c.ws + L.small_slab + (int64_t)i * NP * SMALL_LD;
-        if (K > 0) ds.d[n++] = RedDesc{s, sks, sarm, SMALL_LD, 0, N, K, w_off, K, gscale};
-        ds.d[n++] = RedDesc{s, sks, sarm, SMALL_LD, K, N, 1, b_off, 1, gscale};
+        if (K > 0) ds.d[n++] = RedDesc{s, sks, sarm, SMALL_LD, 0, N, K, w_off, K, gscale, L.sp.ks_small};
+        ds.d[n++] = RedDesc{s, sks, sarm, SMALL_LD, K, N, 1, b_off, 1, gscale, L.sp.ks_small};
     };
     small(0, H, H, c.po.o[2], c.po.o[3]);
     small(1, H, H, c.po.o[4], c.po.o[5]);
@@ -944,13 +946,11 @@ int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost
     // two launches: the three large tensors want thousands of workgroups, the 23 small ones a handful
     const int64_t big_elems = (int64_t)max(H, 1) * D;
     const int gx = (int)imin64(2048, cdiv64(big_elems / 4, 256));
-    hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, L.sp.ks_dw, L.sp.ks_small, nbig, grads,
-                       c.po.per_arm, aa);
+    hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, grads, c.po.per_arm, aa);
     HIP_LAUNCH_CHECK("k_reduce<big>");
     RedDescs ds2{};
     for (int i = nbig; i < n; ++i) ds2.d[i - nbig] = ds.d[i];
-    hipLaunchKernelGGL(k_reduce, dim3(16, n - nbig, A), dim3(256), 0, c.stream, ds2, L.sp.ks_dw, L.sp.ks_small, 0, grads,
-                       c.po.per_arm, aa);
+    hipLaunchKernelGGL(k_reduce, dim3(16, n - nbig, A), dim3(256), 0, c.stream, ds2, grads, c.po.per_arm, aa);
     HIP_LAUNCH_CHECK("k_reduce");
     return 0;
 }

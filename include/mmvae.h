@@ -211,8 +211,8 @@ int mmvae_debug_stage(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noi
 int mmvae_set_side_stream(void *side_stream);
 
 /* Tuning knobs (process-wide, host side): split factors of the three large GEMMs.
- * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW1/dW11 split over the batch,
- * 3 = small-layer dW split over the batch, 4 = d(d10) GEMM split over the genes.  value 0 = auto.
+ * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW1 split over the batch, 3 = small-layer dW split
+ * over the batch, 4 = d(d10) GEMM split over the genes, 5 = dW11 split over the batch.  value 0 = auto.
  * Changes the workspace size. */
 int mmvae_set_split(int which, int value);
 
