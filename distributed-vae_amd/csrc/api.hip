@@ -175,8 +175,13 @@ static int check_noise(const Ctx& c, const mmvae_noise* nz) {
     return 0;
 }
 
+static thread_local hipStream_t g_side = nullptr;
+static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_lat = nullptr, g_ev_couple = nullptr;
+
+// couple_side (train step with a side stream): the coupling kernel needs only the latent block's outputs, so it
+// runs on the side stream beside the decoder chain and fc11; *couple_done tells do_loss to join instead of launch
 static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
-                      const float* x, int64_t xs, float* x_rec, int need_grad) {
+                      const float* x, int64_t xs, float* x_rec, int need_grad, bool* couple_done = nullptr) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
     if (fast) {
@@ -193,19 +198,36 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     for (int layer = 2; layer <= 5; ++layer)
         if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt))) return rc;
+    if (couple_done && g_side) {
+        if (!g_ev_lat && (hipEventCreateWithFlags(&g_ev_lat, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&g_ev_couple, hipEventDisableTiming) != hipSuccess)) {
+            set_error("event creation failed");
+            return MMVAE_E_LAUNCH;
+        }
+        Ctx cs = c;
+        cs.stream = g_side;
+        if (hipEventRecord(g_ev_lat, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_lat, 0) != hipSuccess) {
+            set_error("stream fork failed");
+            return MMVAE_E_LAUNCH;
+        }
+        if ((rc = launch_couple(cs))) return rc;
+        if (hipEventRecord(g_ev_couple, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+        *couple_done = true;
+    }
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
     if (fast) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
     return launch_fc11_fused(c, params, x, xs, x_rec, need_grad);
 }
 
-static int do_loss(const Ctx& c, float* loss_out) {
+static int do_loss(const Ctx& c, float* loss_out, bool couple_done = false) {
     int rc;
-    if ((rc = launch_couple(c))) return rc;
+    if (couple_done) {
+        if (hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
+    } else if ((rc = launch_couple(c))) {
+        return rc;
+    }
     return launch_loss_finalize(c, loss_out);
 }
-
-static thread_local hipStream_t g_side = nullptr;
-static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
 
 static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs,
                        float grad_scale, float* grads, const AdamHost* adam = nullptr) {
@@ -377,8 +399,9 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
     if (int rc = check_noise(c, nz)) return rc;
     if (!h->training) { set_error("train_step requires training mode"); return MMVAE_E_UNSUPPORTED; }
     int rc;
-    if ((rc = do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, nullptr, 1))) return rc;
-    if ((rc = do_loss(c, loss_out))) return rc;
+    bool couple_done = false;
+    if ((rc = do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, nullptr, 1, &couple_done))) return rc;
+    if ((rc = do_loss(c, loss_out, couple_done))) return rc;
     if (do_adam) {
         // the Adam update rides on the slab reduction (alignment gaps of the flat buffers hold zeros and
         // need no update)
