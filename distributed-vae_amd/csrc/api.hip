@@ -176,12 +176,16 @@ static int check_noise(const Ctx& c, const mmvae_noise* nz) {
 }
 
 static thread_local hipStream_t g_side = nullptr;
-static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_lat = nullptr, g_ev_couple = nullptr;
+static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_lat = nullptr, g_ev_couple = nullptr,
+                               g_ev_fc11 = nullptr;
 
-// couple_side (train step with a side stream): the coupling kernel needs only the latent block's outputs, so it
-// runs on the side stream beside the decoder chain and fc11; *couple_done tells do_loss to join instead of launch
+// Train step with a side stream (couple_done != null): the coupling kernel needs only the latent block's outputs
+// and the loss scalars only the coupling and fc11 partials, so both run on the side stream -- the coupling beside
+// the decoder chain and fc11, the finalisation (loss_out != null) beside the d(d10) GEMM.  *couple_done tells the
+// caller that the loss is on its way (event g_ev_couple) and do_loss must not launch anything.
 static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
-                      const float* x, int64_t xs, float* x_rec, int need_grad, bool* couple_done = nullptr) {
+                      const float* x, int64_t xs, float* x_rec, int need_grad, bool* couple_done = nullptr,
+                      float* loss_out = nullptr) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
     if (fast) {
@@ -211,26 +215,41 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
             return MMVAE_E_LAUNCH;
         }
         if ((rc = launch_couple(cs))) return rc;
-        if (hipEventRecord(g_ev_couple, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
         *couple_done = true;
     }
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
+    if (fast && fc11_split_path(c, params, x, xs) && couple_done && *couple_done && loss_out) {
+        if (!g_ev_fc11 && hipEventCreateWithFlags(&g_ev_fc11, hipEventDisableTiming) != hipSuccess) {
+            set_error("event creation failed");
+            return MMVAE_E_LAUNCH;
+        }
+        Ctx cs = c;
+        cs.stream = g_side;
+        if ((rc = launch_fc11_fast(c, params, x, xs, x_rec, need_grad, 1))) return rc;
+        if (hipEventRecord(g_ev_fc11, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fc11, 0) != hipSuccess) {
+            set_error("stream fork failed");
+            return MMVAE_E_LAUNCH;
+        }
+        if ((rc = launch_loss_finalize(cs, loss_out))) return rc;
+        if (hipEventRecord(g_ev_couple, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+        return launch_fc11_fast(c, params, x, xs, x_rec, need_grad, 2);
+    }
+    if (couple_done && *couple_done && hipEventRecord(g_ev_couple, g_side) != hipSuccess) {
+        set_error("event record failed");
+        return MMVAE_E_LAUNCH;
+    }
     if (fast) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
     return launch_fc11_fused(c, params, x, xs, x_rec, need_grad);
 }
 
-static int do_loss(const Ctx& c, float* loss_out, bool couple_done = false) {
+static int do_loss(const Ctx& c, float* loss_out) {
     int rc;
-    if (couple_done) {
-        if (hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
-    } else if ((rc = launch_couple(c))) {
-        return rc;
-    }
+    if ((rc = launch_couple(c))) return rc;
     return launch_loss_finalize(c, loss_out);
 }
 
 static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs,
-                       float grad_scale, float* grads, const AdamHost* adam = nullptr) {
+                       float grad_scale, float* grads, const AdamHost* adam = nullptr, bool wait_loss = false) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
     // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain
@@ -255,6 +274,8 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     }
     const int nslab = fc11_split_path(c, params, x, xs) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11;
     if ((rc = launch_chain_bwd_dec(c, params, nslab))) return rc;
+    // T (sum of G log c, from the loss finalisation) is first needed here
+    if (wait_loss && hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
     for (int layer = 5; layer >= 2; --layer)
         if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
@@ -399,17 +420,23 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
     if (int rc = check_noise(c, nz)) return rc;
     if (!h->training) { set_error("train_step requires training mode"); return MMVAE_E_UNSUPPORTED; }
     int rc;
-    bool couple_done = false;
-    if ((rc = do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, nullptr, 1, &couple_done))) return rc;
-    if ((rc = do_loss(c, loss_out, couple_done))) return rc;
+    bool side_loss = false;   // coupling (+ loss scalars on the fast path) already running on the side stream
+    if ((rc = do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, nullptr, 1, &side_loss, loss_out))) return rc;
+    const bool loss_on_side = side_loss && fc11_split_path(c, params, x, x_arm_stride);
+    if (side_loss && !loss_on_side) {   // general path: coupling done on the side, finalise here
+        if (hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
+        if ((rc = launch_loss_finalize(c, loss_out))) return rc;
+    } else if (!side_loss && (rc = do_loss(c, loss_out))) {
+        return rc;
+    }
     if (do_adam) {
         // the Adam update rides on the slab reduction (alignment gaps of the flat buffers hold zeros and
         // need no update)
         if (!exp_avg || !exp_avg_sq || step < 1) { set_error("adam state missing"); return MMVAE_E_BADARG; }
         const AdamHost ah{params, exp_avg, exp_avg_sq, step, lr, beta1, beta2, adam_eps, weight_decay, decoupled};
-        return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, &ah);
+        return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, &ah, loss_on_side);
     }
-    return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads);
+    return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, nullptr, loss_on_side);
 }
 
 int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, int stage,
