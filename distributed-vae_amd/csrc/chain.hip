@@ -80,6 +80,39 @@ __device__ __forceinline__ void stage_w(float* Ws, int ld, const float* __restri
     else stage_w_t<false>(Ws, ld, W, N, K, rows_pad, cols_pad);
 }
 
+// Split form of stage_w for weights with K % 4 == 0 and a padded tile of at most 128 x 128: w_load only REQUESTS
+// the tile (raw clamped loads, nothing touches the values), w_store masks it and writes it to LDS later.  The
+// request for layer l+1 is issued before layer l's GEMM and lands under the GEMM and the epilogue, so a chain
+// pays the weight latency once instead of once per layer.
+constexpr int WQ_N = 4 * (128 / (CH_NT / 8));   // float4 per thread: 128 rows / (threads / 8 per row) passes x 4 chunks
+__device__ __forceinline__ bool w_split_ok(const float* W, int K, int rows_pad, int cols_pad) {
+    return (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && rows_pad <= 128 && cols_pad <= 128;
+}
+__device__ __forceinline__ void w_load(float4 (&wq)[WQ_N], const float* __restrict__ W, int N, int K) {
+    const int part = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int p = 0; p < WQ_N / 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + (CH_NT / 8) * p, col = (part + 8 * j) * 4;
+            const bool ok = row < N && col < K;
+            wq[p * 4 + j] = *reinterpret_cast<const float4*>(W + (int64_t)(ok ? row : 0) * K + (ok ? col : 0));
+        }
+}
+__device__ __forceinline__ void w_store(float* Ws, int ld, const float4 (&wq)[WQ_N], int N, int K, int rows_pad, int cols_pad) {
+    const int part = threadIdx.x & 7, r0 = threadIdx.x >> 3, c4n = cols_pad >> 2;
+#pragma unroll
+    for (int p = 0; p < WQ_N / 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r0 + (CH_NT / 8) * p, c = part + 8 * j;
+            const bool ok = row < N && c * 4 < K;
+            const float4 q = wq[p * 4 + j];
+            const float4 v = make_float4(ok ? q.x : 0.f, ok ? q.y : 0.f, ok ? q.z : 0.f, ok ? q.w : 0.f);
+            if (c < c4n && row < rows_pad) *reinterpret_cast<float4*>(&Ws[row * ld + c * 4]) = v;
+        }
+}
+
 __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
                                                    float* __restrict__ ws, float* __restrict__ bn_running,
                                                    int64_t* __restrict__ nbt) {
@@ -179,16 +212,25 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         else stage_x(ScalarTag{});
     }
     stamp(0);
+    float4 wq[WQ_N];
+    bool wq_valid = false;
     for (int l = 0; l < a.nlayers; ++l) {
         const FwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
-        stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
+        if (wq_valid) w_store(Ws, ld, wq, N, K, NPad, KP);      // requested during the previous layer
+        else stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
         const int col = ct * 32 + (lane & 31);
         const bool active = ct * 32 < NPad;
         const float bias = (active && col < N) ? P[Lr.b_off + col] : 0.f;   // requested before the barrier
         stamp(1);
         lds_barrier();
         stamp(2);
+        wq_valid = false;
+        if (l + 1 < a.nlayers) {   // next layer's weights travel while this layer computes
+            const FwdLayer Ln = a.L[l + 1];
+            wq_valid = w_split_ok(P + Ln.w_off, Ln.K, rup(Ln.N, 32), rup(Ln.K, 8));
+            if (wq_valid) w_load(wq, P + Ln.w_off, Ln.N, Ln.K);
+        }
         f32x16 acc = zero16();
         if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, rt * 32, Ws, ld, ct * 32, KP / 8);
         if (stamps) asm volatile("" :: "v"(acc[0]));
@@ -388,11 +430,20 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
         if (vec) stage_g(VecTag{});
         else stage_g(ScalarTag{});
     }
+    float4 wq[WQ_N];
+    bool wq_valid = false;
     for (int l = 0; l < a.nlayers; ++l) {
         const BwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, NP8 = rup(N, 8), KPad = rup(K, 32);
-        stage_w(Ws, ld, P + Lr.w_off, N, K, NP8, KPad);
+        if (wq_valid) w_store(Ws, ld, wq, N, K, NP8, KPad);      // requested during the previous layer
+        else stage_w(Ws, ld, P + Lr.w_off, N, K, NP8, KPad);
         lds_barrier();
+        wq_valid = false;
+        if (l + 1 < a.nlayers) {   // next layer's weights travel while this layer computes
+            const BwdLayer Ln = a.L[l + 1];
+            wq_valid = w_split_ok(P + Ln.w_off, Ln.K, rup(Ln.N, 8), rup(Ln.K, 32));
+            if (wq_valid) w_load(wq, P + Ln.w_off, Ln.N, Ln.K);
+        }
         // input width K may reach 255 (fc6: K = C + S): up to 8 column tiles, two per wave
         f32x16 accs[2] = {zero16(), zero16()};
 #pragma unroll
