@@ -31,7 +31,8 @@ Splits default_splits(const mmvae_dims& d) {
     const int nb128 = cdiv(d.B, 128), nb64 = cdiv(d.B, 64);
     const bool fastdims = (d.D & 3) == 0 && (d.H & 3) == 0;
     // fc1 forward: fast kernel 128-row blocks, 3 workgroups / CU; general kernel 64-row blocks
-    s.ks_fc1 = g_split[0] > 0 ? g_split[0] : (fastdims ? fit(nb128 * d.A, 3 * CUS, 16) : fit(nb64 * d.A, 4 * CUS, 16));
+    // (fc_dim 100: k_fc1_fwd_v3, two workgroups / CU)
+    s.ks_fc1 = g_split[0] > 0 ? g_split[0] : (fastdims ? fit(nb128 * d.A, (d.H == 100 ? 2 : 3) * CUS, 16) : fit(nb64 * d.A, 4 * CUS, 16));
     s.ks_fc1 = min(s.ks_fc1, max(1, cdiv(d.D, 32)));
     // fc11 x_rec/loss/dZ11 kernel: 128-row blocks, 2 workgroups / CU (general fused kernel: 64-row blocks)
     s.ns_fc11 = g_split[1] > 0 ? g_split[1] : (fastdims ? fit(nb128 * d.A, 2 * CUS, 16) : fit(nb64 * d.A, 2 * CUS, 16));

@@ -168,6 +168,119 @@ __global__ __launch_bounds__(256) void k_fc1_fwd_v2(const float* __restrict__ x,
 }
 
 // =============================================================================================
+// fc1 forward for fc_dim = 100: the same tiles as k_fc1_fwd_v2, but a wave owns 32 rows x (3 MFMA column tiles
+// + 4 leftover columns) instead of 64 x 64 of a 128-wide tile whose last 28 columns are padding.  The leftover
+// columns 96..99 are plain FMAs on the A fragments the wave already holds (16 per 12 MFMAs): a quarter fewer
+// MFMAs for the same result.  Columns >= 100 of the slab rows are not written (the epilogue never uses them).
+// =============================================================================================
+template <bool USE_MASK>
+__global__ __launch_bounds__(256, 2) void k_fc1_fwd_v3(const float* __restrict__ x, int64_t x_arm_stride,
+                                                    const float* __restrict__ params, int64_t per_arm, int64_t w_off,
+                                                    const uint32_t* __restrict__ bits, int wpr,
+                                                    float* __restrict__ slab, int A, int B, int D, int H, int KS,
+                                                    int ablate) {
+    __shared__ __attribute__((aligned(16))) float As[128 * V2_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[128 * V2_LD];
+    const int arm = blockIdx.z, ks = blockIdx.y, b0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float* xa = x + (int64_t)arm * x_arm_stride;
+    const float* W = params + (int64_t)arm * per_arm + w_off;
+    const int nkt = cdiv(D, 32);
+    const int kt0 = (int)(((int64_t)ks * nkt) / KS), kt1 = (int)(((int64_t)(ks + 1) * nkt) / KS);
+    const int r0 = tid >> 3, c4 = tid & 7;
+
+    const float* pa[4];
+    const float* pb[4];
+    const uint32_t* pm[4];
+    bool okb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = min(b0 + r0 + 32 * i, B - 1);      // rows past B recompute row B-1; never stored
+        pa[i] = xa + (int64_t)ra * D + c4 * 4;
+        pm[i] = bits + ((int64_t)arm * B + ra) * wpr;
+        const int rb = r0 + 32 * i;
+        okb[i] = rb < H;
+        pb[i] = W + (int64_t)min(rb, H - 1) * D + c4 * 4;
+    }
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};   // columns [32 j, 32 j + 32), rows [32 wv, 32 wv + 32)
+    float lo[4] = {0.f, 0.f, 0.f, 0.f};               // columns 96..99 of row (lane & 31): this lane's k's only
+
+    float4 ra4[4], rb4[4];
+    auto load_tiles = [&](int kt) {
+        const bool colok = kt * 32 + c4 * 4 < D;
+        const int koff = colok ? kt * 32 : 0;
+        uint32_t wd[4];
+        if (USE_MASK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wd[i] = pm[i][kt];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra4[i] = *reinterpret_cast<const float4*>(pa[i] + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb4[i] = *reinterpret_cast<const float4*>(pb[i] + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = sel4(colok, ra4[i]);
+            if (USE_MASK) v = mask4(v, wd[i] >> (c4 * 4));
+            ra4[i] = v;
+            rb4[i] = sel4(colok && okb[i], rb4[i]);
+        }
+    };
+    if (kt0 < kt1) load_tiles(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * V2_LD + c4 * 4]) = ra4[i];
+            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * V2_LD + c4 * 4]) = rb4[i];
+        }
+        __syncthreads();
+        if (kt + 1 < kt1 && !(ablate & 2)) load_tiles(kt + 1);
+        const float* la = As + (wv * 32 + l31) * V2_LD + 4 * hh;
+        const float* lb = Bs + l31 * V2_LD + 4 * hh;
+        const float* ll = Bs + 96 * V2_LD + 4 * hh;      // rows 96..99 of W1: the same address for a whole half wave
+        if (!(ablate & 1))
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(la + 8 * g);
+            const float4 q0 = *reinterpret_cast<const float4*>(lb + 8 * g);
+            const float4 q1 = *reinterpret_cast<const float4*>(lb + 32 * V2_LD + 8 * g);
+            const float4 q2 = *reinterpret_cast<const float4*>(lb + 64 * V2_LD + 8 * g);
+            const float4 w0 = *reinterpret_cast<const float4*>(ll + 8 * g);
+            const float4 w1 = *reinterpret_cast<const float4*>(ll + V2_LD + 8 * g);
+            const float4 w2 = *reinterpret_cast<const float4*>(ll + 2 * V2_LD + 8 * g);
+            const float4 w3 = *reinterpret_cast<const float4*>(ll + 3 * V2_LD + 8 * g);
+            acc[0] = mfma32(a.x, q0.x, acc[0]); acc[1] = mfma32(a.x, q1.x, acc[1]); acc[2] = mfma32(a.x, q2.x, acc[2]);
+            acc[0] = mfma32(a.y, q0.y, acc[0]); acc[1] = mfma32(a.y, q1.y, acc[1]); acc[2] = mfma32(a.y, q2.y, acc[2]);
+            acc[0] = mfma32(a.z, q0.z, acc[0]); acc[1] = mfma32(a.z, q1.z, acc[1]); acc[2] = mfma32(a.z, q2.z, acc[2]);
+            acc[0] = mfma32(a.w, q0.w, acc[0]); acc[1] = mfma32(a.w, q1.w, acc[1]); acc[2] = mfma32(a.w, q2.w, acc[2]);
+            // the four columns that do not fill a 32-wide MFMA tile: 16 VALU FMAs in the MFMAs' shadow
+            lo[0] = fmaf(a.x, w0.x, lo[0]); lo[1] = fmaf(a.x, w1.x, lo[1]); lo[2] = fmaf(a.x, w2.x, lo[2]); lo[3] = fmaf(a.x, w3.x, lo[3]);
+            lo[0] = fmaf(a.y, w0.y, lo[0]); lo[1] = fmaf(a.y, w1.y, lo[1]); lo[2] = fmaf(a.y, w2.y, lo[2]); lo[3] = fmaf(a.y, w3.y, lo[3]);
+            lo[0] = fmaf(a.z, w0.z, lo[0]); lo[1] = fmaf(a.z, w1.z, lo[1]); lo[2] = fmaf(a.z, w2.z, lo[2]); lo[3] = fmaf(a.z, w3.z, lo[3]);
+            lo[0] = fmaf(a.w, w0.w, lo[0]); lo[1] = fmaf(a.w, w1.w, lo[1]); lo[2] = fmaf(a.w, w2.w, lo[2]); lo[3] = fmaf(a.w, w3.w, lo[3]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the fragment registers of one k group at a time
+        }
+        __syncthreads();
+    }
+    float* out = slab + (((int64_t)ks * A + arm) * B) * NP;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = b0 + wv * 32 + acc_row(r, lane);
+            if (row < B) out[(int64_t)row * NP + j * 32 + l31] = acc[j][r];
+        }
+    // lanes l and l ^ 32 hold the two k halves of the same row
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lo[c] += __shfl_xor(lo[c], 32, 64);
+    {
+        const int row = b0 + wv * 32 + l31;
+        if (hh == 0 && row < B) *reinterpret_cast<float4*>(out + (int64_t)row * NP + 96) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+// =============================================================================================
 // TN over the batch, fast: out[m][n] = sum_b P[b][m] Q[b][n]; tile 128 x 128, 32 batch rows per step,
 // wave tile 64 x 64.  grid (tiles_m * tiles_n, KS, A).  Q may carry the keep-mask (x) or a trailing
 // ones column (bias gradient).
@@ -1010,6 +1123,17 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
     static const int padlds = getenv("MMVAE_PADLDS") ? atoi(getenv("MMVAE_PADLDS")) : 0;   // occupancy experiments
     dim3 grid(cdiv(d.B, 128), KS, d.A);
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits);
+    static const int v3off = getenv("MMVAE_FC1_V2") ? atoi(getenv("MMVAE_FC1_V2")) : 0;   // A/B timing
+    if (d.H == 100 && !v3off) {
+        if (use_mask)
+            hipLaunchKernelGGL((k_fc1_fwd_v3<true>), grid, dim3(256), padlds, c.stream, x, xs, params, c.po.per_arm,
+                               c.po.o[0], bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS, ablate);
+        else
+            hipLaunchKernelGGL((k_fc1_fwd_v3<false>), grid, dim3(256), 0, c.stream, x, xs, params, c.po.per_arm,
+                               c.po.o[0], bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS, ablate);
+        HIP_LAUNCH_CHECK("k_fc1_fwd_v3");
+        return 0;
+    }
     if (use_mask)
         hipLaunchKernelGGL((k_fc1_fwd_v2<true>), grid, dim3(256), padlds, c.stream, x, xs, params, c.po.per_arm, c.po.o[0],
                            bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS, ablate);

