@@ -47,7 +47,7 @@ Splits default_splits(const mmvae_dims& d) {
     if (!fastdims) s.ks_dw11 = s.ks_dw;
     s.ks_small = g_split[3] > 0 ? g_split[3] : fit(N_SMALL * d.A, 3 * CUS, 32);   // 3 workgroups / CU (136 VGPRs)
     s.ks_small = min(s.ks_small, max(1, cdiv(d.B, 32)));
-    s.ks_gd10 = g_split[4] > 0 ? g_split[4] : fit(nb128 * d.A, 3 * CUS, 16);
+    s.ks_gd10 = g_split[4] > 0 ? g_split[4] : fit(nb128 * d.A, (fastdims && d.H == 100 ? 2 : 3) * CUS, 16);   // fc_dim 100: k_gd10_v3, 2 / CU
     s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, 32)));
     return s;
 }

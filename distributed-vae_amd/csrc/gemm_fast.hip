@@ -376,6 +376,103 @@ __global__ __launch_bounds__(256) void k_tn_v2(const float* __restrict__ P, int6
             }
 }
 
+// TN product with M = 100 output rows (dW1 at fc_dim 100): as k_tn_v2, but a wave owns (3 MFMA row tiles + 4 leftover
+// rows done by plain FMAs on the Q fragment it already holds) x 32 columns instead of 64 x 64 of a 128-row tile with
+// 28 padding rows
+template <bool QMASK>
+__global__ __launch_bounds__(256, 2) void k_tn_v3m(const float* __restrict__ P, int64_t p_arm, int ldp, int Mv,
+                                               const float* __restrict__ Q, int64_t q_arm, int ldq, int Nv,
+                                               const uint32_t* __restrict__ bits, int wpr, float* __restrict__ out,
+                                               int64_t out_arm, int64_t out_ks, int ldo, int B, int KS, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float Ps[32 * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Qs[32 * TN_LD];
+    const int arm = blockIdx.z, ks = blockIdx.y;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float* Pa = P + (int64_t)arm * p_arm;
+    const float* Qa = Q + (int64_t)arm * q_arm;
+    const int nbt = cdiv(B, 32);
+    const int bt0 = (int)(((int64_t)ks * nbt) / KS), bt1 = (int)(((int64_t)(ks + 1) * nbt) / KS);
+    const int rr = tid >> 5, c4 = tid & 31;
+    const int pc = m0 + c4 * 4, qc = n0 + c4 * 4;
+    const bool pok = pc < Mv, qok = qc < Nv;
+    const bool qone = false && (qc == Nv);
+    const int pcc = pok ? pc : 0, qcc = qok ? qc : 0;
+
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};   // rows [32 i, 32 i + 32), columns [32 wv, 32 wv + 32)
+    float lo[4] = {0.f, 0.f, 0.f, 0.f};               // rows 96..99 at column (lane & 31): this lane's batch rows only
+    float4 rp[4], rq[4];
+    auto load_tiles = [&](int bt) {
+        uint32_t wd[4];
+        int rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = bt * 32 + rr + 8 * i;
+        if (QMASK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wd[i] = bits[((int64_t)arm * B + min(rows[i], B - 1)) * wpr + (qcc >> 5)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rp[i] = *reinterpret_cast<const float4*>(Pa + (int64_t)min(rows[i], B - 1) * ldp + pcc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rq[i] = *reinterpret_cast<const float4*>(Qa + (int64_t)min(rows[i], B - 1) * ldq + qcc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rp[i] = sel4(pok && rows[i] < B, rp[i]);      // zero P rows past the batch: their products vanish
+            float4 v = sel4(qok, rq[i]);
+            if (QMASK) v = mask4(v, wd[i] >> (qcc & 31));
+            if (qone) v.x = 1.f;
+            rq[i] = v;
+        }
+    };
+    if (bt0 < bt1) load_tiles(bt0);
+    for (int bt = bt0; bt < bt1; ++bt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&Ps[(rr + 8 * i) * TN_LD + c4 * 4]) = rp[i];
+            *reinterpret_cast<float4*>(&Qs[(rr + 8 * i) * TN_LD + c4 * 4]) = rq[i];
+        }
+        __syncthreads();
+        if (bt + 1 < bt1) load_tiles(bt + 1);
+        const float* la = Ps + hh * TN_LD + l31;
+        const float* lb = Qs + hh * TN_LD + wv * 32 + l31;
+        const float* ll = Ps + hh * TN_LD + 96;       // P[b][96..99]: one address per half wave
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float a0 = la[2 * s * TN_LD], a1 = la[2 * s * TN_LD + 32], a2 = la[2 * s * TN_LD + 64];
+            const float q = lb[2 * s * TN_LD];
+            const float4 p4 = *reinterpret_cast<const float4*>(ll + 2 * s * TN_LD);
+            acc[0] = mfma32(a0, q, acc[0]);
+            acc[1] = mfma32(a1, q, acc[1]);
+            acc[2] = mfma32(a2, q, acc[2]);
+            // the four output rows that do not fill a 32-row MFMA tile: VALU FMAs in the MFMAs' shadow
+            lo[0] = fmaf(p4.x, q, lo[0]); lo[1] = fmaf(p4.y, q, lo[1]); lo[2] = fmaf(p4.z, q, lo[2]); lo[3] = fmaf(p4.w, q, lo[3]);
+        }
+        __syncthreads();
+    }
+    float* o = out + (int64_t)ks * out_ks + (int64_t)arm * out_arm;
+    const int n = n0 + wv * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + i * 32 + acc_row(r, lane);
+            if (m < Mv && n < Nv) o[(int64_t)m * ldo + n] = acc[i][r];
+        }
+    // lanes l and l ^ 32 hold the even / odd batch rows of the same column
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lo[c] += __shfl_xor(lo[c], 32, 64);
+    if (hh == 0 && n < Nv) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (m0 + 96 + c < Mv) o[(int64_t)(m0 + 96 + c) * ldo + n] = lo[c];
+    }
+}
+
 // =============================================================================================
 // fused fc11, fast.  Same tiling as k_fc11_fused (64 cells x 64 genes per step, waves 2 x 2), with the
 // next weight tile prefetched into registers and this tile's x values requested before the first
@@ -1085,6 +1182,98 @@ __global__ __launch_bounds__(256) void k_gd10_v2(const float* __restrict__ dz11,
             }
 }
 
+// d(d10) for fc_dim = 100: as k_gd10_v2, but a wave owns 32 rows x (3 MFMA column tiles + 4 leftover columns done
+// by plain FMAs on the A fragments it already holds) instead of 64 x 64 of a 128-wide tile with 28 padding columns
+__global__ __launch_bounds__(256, 2) void k_gd10_v3(const float* __restrict__ dz11, const float* __restrict__ params,
+                                                 int64_t per_arm, int64_t w_off, float* __restrict__ slab, int A, int B,
+                                                 int D, int H, int KS) {
+    __shared__ __attribute__((aligned(16))) float As[128 * V2_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * TN_LD];
+    const int arm = blockIdx.z, ks = blockIdx.y, b0 = blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float* Z = dz11 + (int64_t)arm * B * D;
+    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
+    const int nkt = cdiv(D, 32);
+    const int kt0 = (int)(((int64_t)ks * nkt) / KS), kt1 = (int)(((int64_t)(ks + 1) * nkt) / KS);
+    const int r0 = tid >> 3, c4 = tid & 7;      // A staging
+    const int rr = tid >> 5, bc4 = tid & 31;    // B staging
+    const bool bok = bc4 * 4 < H;
+    const float* pa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pa[i] = Z + (int64_t)min(b0 + r0 + 32 * i, B - 1) * D + c4 * 4;
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};   // columns [32 j, 32 j + 32), rows [32 wv, 32 wv + 32)
+    float lo[4] = {0.f, 0.f, 0.f, 0.f};               // columns 96..99 of row (lane & 31): this lane's k's only
+    float4 ra4[4], rb4[4];
+    auto load_tiles = [&](int kt) {
+        const bool colok = kt * 32 + c4 * 4 < D;
+        const int koff = colok ? kt * 32 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra4[i] = *reinterpret_cast<const float4*>(pa[i] + koff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = kt * 32 + rr + 8 * i;
+            const bool ok = bok && (j < D);
+            rb4[i] = *reinterpret_cast<const float4*>(W + (int64_t)(ok ? j : 0) * H + (ok ? bc4 * 4 : 0));
+            rb4[i] = sel4(ok, rb4[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra4[i] = sel4(colok, ra4[i]);
+    };
+    if (kt0 < kt1) load_tiles(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * V2_LD + c4 * 4]) = ra4[i];
+            *reinterpret_cast<float4*>(&Bs[(rr + 8 * i) * TN_LD + bc4 * 4]) = rb4[i];
+        }
+        __syncthreads();
+        if (kt + 1 < kt1) load_tiles(kt + 1);
+        const float* la = As + (wv * 32 + l31) * V2_LD + 4 * hh;
+        const float* lb = Bs + (4 * hh) * TN_LD + l31;
+        const float* ll = Bs + (4 * hh) * TN_LD + 96;     // columns 96..99 of W11's rows: one address per half wave
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(la + 8 * g);
+            const float* q = lb + (8 * g) * TN_LD;
+            const float q00 = q[0], q01 = q[32], q02 = q[64];
+            const float q10 = q[TN_LD], q11 = q[TN_LD + 32], q12 = q[TN_LD + 64];
+            const float q20 = q[2 * TN_LD], q21 = q[2 * TN_LD + 32], q22 = q[2 * TN_LD + 64];
+            const float q30 = q[3 * TN_LD], q31 = q[3 * TN_LD + 32], q32 = q[3 * TN_LD + 64];
+            const float4 w0 = *reinterpret_cast<const float4*>(ll + (8 * g) * TN_LD);
+            const float4 w1 = *reinterpret_cast<const float4*>(ll + (8 * g + 1) * TN_LD);
+            const float4 w2 = *reinterpret_cast<const float4*>(ll + (8 * g + 2) * TN_LD);
+            const float4 w3 = *reinterpret_cast<const float4*>(ll + (8 * g + 3) * TN_LD);
+            acc[0] = mfma32(a.x, q00, acc[0]); acc[1] = mfma32(a.x, q01, acc[1]); acc[2] = mfma32(a.x, q02, acc[2]);
+            acc[0] = mfma32(a.y, q10, acc[0]); acc[1] = mfma32(a.y, q11, acc[1]); acc[2] = mfma32(a.y, q12, acc[2]);
+            acc[0] = mfma32(a.z, q20, acc[0]); acc[1] = mfma32(a.z, q21, acc[1]); acc[2] = mfma32(a.z, q22, acc[2]);
+            acc[0] = mfma32(a.w, q30, acc[0]); acc[1] = mfma32(a.w, q31, acc[1]); acc[2] = mfma32(a.w, q32, acc[2]);
+            // the four columns that do not fill a 32-wide MFMA tile: 16 VALU FMAs in the MFMAs' shadow
+            lo[0] = fmaf(a.x, w0.x, lo[0]); lo[1] = fmaf(a.x, w0.y, lo[1]); lo[2] = fmaf(a.x, w0.z, lo[2]); lo[3] = fmaf(a.x, w0.w, lo[3]);
+            lo[0] = fmaf(a.y, w1.x, lo[0]); lo[1] = fmaf(a.y, w1.y, lo[1]); lo[2] = fmaf(a.y, w1.z, lo[2]); lo[3] = fmaf(a.y, w1.w, lo[3]);
+            lo[0] = fmaf(a.z, w2.x, lo[0]); lo[1] = fmaf(a.z, w2.y, lo[1]); lo[2] = fmaf(a.z, w2.z, lo[2]); lo[3] = fmaf(a.z, w2.w, lo[3]);
+            lo[0] = fmaf(a.w, w3.x, lo[0]); lo[1] = fmaf(a.w, w3.y, lo[1]); lo[2] = fmaf(a.w, w3.z, lo[2]); lo[3] = fmaf(a.w, w3.w, lo[3]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the fragment registers of one k group at a time
+        }
+        __syncthreads();
+    }
+    float* out = slab + (((int64_t)ks * A + arm) * B) * H;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = b0 + wv * 32 + acc_row(r, lane);
+            if (row < B) out[(int64_t)row * H + j * 32 + l31] = acc[j][r];
+        }
+    // lanes l and l ^ 32 hold the two k halves of the same row
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lo[c] += __shfl_xor(lo[c], 32, 64);
+    {
+        const int row = b0 + wv * 32 + l31;
+        if (hh == 0 && row < B) *reinterpret_cast<float4*>(out + (int64_t)row * H + 96) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -1223,6 +1412,11 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         }
     }
     if (need_grad && (which & 2)) {
+        static const int v2only = getenv("MMVAE_GD10_V2") ? atoi(getenv("MMVAE_GD10_V2")) : 0;   // A/B timing
+        if (d.H == 100 && !v2only)
+            hipLaunchKernelGGL(k_gd10_v3, dim3(cdiv(d.B, 128), L.sp.ks_gd10, d.A), dim3(256), 0, c.stream, c.ws + L.DZ11,
+                               params, c.po.per_arm, c.po.o[26], c.ws + L.GD10_slab, d.A, d.B, d.D, d.H, L.sp.ks_gd10);
+        else
         hipLaunchKernelGGL(k_gd10_v2, dim3(cdiv(d.B, 128), L.sp.ks_gd10, d.A), dim3(256), 0, c.stream, c.ws + L.DZ11,
                            params, c.po.per_arm, c.po.o[26], c.ws + L.GD10_slab, d.A, d.B, d.D, d.H, L.sp.ks_gd10);
         HIP_LAUNCH_CHECK("k_gd10_v2");
@@ -1240,6 +1434,18 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
     if (which & 1) {   // dW1[h][d] = sum_b dZ1[b][h] x~[b][d]   -> slab [KS][A][H][D]
         const int tiles_n = cdiv(d.D, 128);
         dim3 grid(cdiv(d.H, 128) * tiles_n, KS, d.A);
+        static const int v2only = getenv("MMVAE_DW1_V2") ? atoi(getenv("MMVAE_DW1_V2")) : 0;   // A/B timing
+        if (d.H == 100 && !v2only) {
+            if (use_mask)
+                hipLaunchKernelGGL((k_tn_v3m<true>), grid, dim3(256), 0, c.stream, c.ws + L.DZ[1],
+                                   (int64_t)d.B * d.H, d.H, d.H, x, xs, d.D, d.D, bits, wpr, c.ws + L.dw1_slab,
+                                   (int64_t)d.H * d.D, (int64_t)d.A * d.H * d.D, d.D, d.B, KS, tiles_n);
+            else
+                hipLaunchKernelGGL((k_tn_v3m<false>), grid, dim3(256), 0, c.stream, c.ws + L.DZ[1],
+                                   (int64_t)d.B * d.H, d.H, d.H, x, xs, d.D, d.D, bits, wpr, c.ws + L.dw1_slab,
+                                   (int64_t)d.H * d.D, (int64_t)d.A * d.H * d.D, d.D, d.B, KS, tiles_n);
+            HIP_LAUNCH_CHECK("k_tn_v3m<dW1>");
+        } else
         if (use_mask)
             hipLaunchKernelGGL((k_tn_v2<true, false>), grid, dim3(256), 0, c.stream, c.ws + L.DZ[1],
                                (int64_t)d.B * d.H, d.H, d.H, x, xs, d.D, d.D, bits, wpr, c.ws + L.dw1_slab,
