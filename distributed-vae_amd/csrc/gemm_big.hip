@@ -482,6 +482,49 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc,
         for (int j = 0; j < NT; ++j)
             live[i][j] = (m0 + wm * (TA / 2) + i * 32 < d.Mv) && (n0 + wn * (TB / 2) + j * 32 < d.Nv + d.q_ones);
     if (bt0 < bt1) load_tiles(bt0);
+    if (TA == 128 && TB == 128 && d.Mv > 96 && d.Mv <= 100 && tm == 0) {
+        // 100-row outputs (the H x H small layers): a wave owns (3 MFMA row tiles + 4 leftover rows done by plain FMAs
+        // on the Q fragment it already holds) x 32 columns instead of 64 x 64 of a 128-row tile with 28 padding rows
+        f32x16 a3[3] = {zero16(), zero16(), zero16()};
+        float lo[4] = {0.f, 0.f, 0.f, 0.f};
+        const int l31 = lane & 31, hh = lane >> 5;
+        for (int bt = bt0; bt < bt1; ++bt) {
+            store_tiles();
+            __syncthreads();
+            if (bt + 1 < bt1) load_tiles(bt + 1);
+            const float* pa = Ps + hh * LDA + l31;
+            const float* pb = Qs + hh * LDB + wv * 32 + l31;
+            const float* pl = Ps + hh * LDA + 96;      // P[b][96..99]: one address per half wave
+#pragma unroll 4
+            for (int s = 0; s < BK / 2; ++s) {
+                const float a0 = pa[2 * s * LDA], a1 = pa[2 * s * LDA + 32], a2 = pa[2 * s * LDA + 64];
+                const float q = pb[2 * s * LDB];
+                const float4 p4 = *reinterpret_cast<const float4*>(pl + 2 * s * LDA);
+                a3[0] = mfma32(a0, q, a3[0]);
+                a3[1] = mfma32(a1, q, a3[1]);
+                a3[2] = mfma32(a2, q, a3[2]);
+                lo[0] = fmaf(p4.x, q, lo[0]); lo[1] = fmaf(p4.y, q, lo[1]); lo[2] = fmaf(p4.z, q, lo[2]); lo[3] = fmaf(p4.w, q, lo[3]);
+            }
+            __syncthreads();
+        }
+        float* out = d.out + (int64_t)ks * d.out_ks_stride + (int64_t)arm * d.out_arm_stride;
+        const int ncols = d.Nv + d.q_ones, n = n0 + wv * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = i * 32 + acc_row(r, lane);
+                if (n < ncols) out[(int64_t)m * d.ldo + n] = a3[i][r];
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lo[c] += __shfl_xor(lo[c], 32, 64);   // even / odd batch rows of the same column
+        if (hh == 0 && n < ncols) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (96 + c < d.Mv) out[(int64_t)(96 + c) * d.ldo + n] = lo[c];
+        }
+        return;
+    }
     for (int bt = bt0; bt < bt1; ++bt) {
         store_tiles();
         __syncthreads();
