@@ -376,6 +376,104 @@ __global__ __launch_bounds__(256) void k_tn_v2(const float* __restrict__ P, int6
             }
 }
 
+// TN product with N = 100 + ones column (dW11 | db11 at fc_dim 100): a wave owns 32 rows x (3 MFMA column tiles + 5
+// leftover columns done by plain FMAs on the P fragment it already holds); requires ldo % 4 == 0 and Nv == 100
+__global__ __launch_bounds__(256, 2) void k_tn_v3n(const float* __restrict__ P, int64_t p_arm, int ldp, int Mv,
+                                               const float* __restrict__ Q, int64_t q_arm, int ldq, int Nv,
+                                               const uint32_t* __restrict__ bits, int wpr, float* __restrict__ out,
+                                               int64_t out_arm, int64_t out_ks, int ldo, int B, int KS, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float Ps[32 * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Qs[32 * TN_LD];
+    const int arm = blockIdx.z, ks = blockIdx.y;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const float* Pa = P + (int64_t)arm * p_arm;
+    const float* Qa = Q + (int64_t)arm * q_arm;
+    const int nbt = cdiv(B, 32);
+    const int bt0 = (int)(((int64_t)ks * nbt) / KS), bt1 = (int)(((int64_t)(ks + 1) * nbt) / KS);
+    const int rr = tid >> 5, c4 = tid & 31;
+    const int pc = m0 + c4 * 4, qc = n0 + c4 * 4;
+    const bool pok = pc < Mv, qok = qc < Nv;
+    const bool qone = true && (qc == Nv);
+    const int pcc = pok ? pc : 0, qcc = qok ? qc : 0;
+
+    f32x16 acc[3] = {zero16(), zero16(), zero16()};   // rows [32 wv, 32 wv + 32), columns [32 j, 32 j + 32)
+    float lo[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // columns 96..100 of row (lane & 31): this lane's batch rows only
+    float4 rp[4], rq[4];
+    auto load_tiles = [&](int bt) {
+        uint32_t wd[4];
+        int rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = bt * 32 + rr + 8 * i;
+        if (false) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wd[i] = bits[((int64_t)arm * B + min(rows[i], B - 1)) * wpr + (qcc >> 5)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rp[i] = *reinterpret_cast<const float4*>(Pa + (int64_t)min(rows[i], B - 1) * ldp + pcc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rq[i] = *reinterpret_cast<const float4*>(Qa + (int64_t)min(rows[i], B - 1) * ldq + qcc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rp[i] = sel4(pok && rows[i] < B, rp[i]);      // zero P rows past the batch: their products vanish
+            float4 v = sel4(qok, rq[i]);
+            if (false) v = mask4(v, wd[i] >> (qcc & 31));
+            if (qone) v.x = 1.f;
+            rq[i] = v;
+        }
+    };
+    if (bt0 < bt1) load_tiles(bt0);
+    for (int bt = bt0; bt < bt1; ++bt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&Ps[(rr + 8 * i) * TN_LD + c4 * 4]) = rp[i];
+            *reinterpret_cast<float4*>(&Qs[(rr + 8 * i) * TN_LD + c4 * 4]) = rq[i];
+        }
+        __syncthreads();
+        if (bt + 1 < bt1) load_tiles(bt + 1);
+        const float* la = Ps + hh * TN_LD + wv * 32 + l31;
+        const float* lb = Qs + hh * TN_LD + l31;
+        const float* ll = Qs + hh * TN_LD + 96;       // Q[b][96..100]: one address per half wave
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float a = la[2 * s * TN_LD];
+            const float q0 = lb[2 * s * TN_LD], q1 = lb[2 * s * TN_LD + 32], q2 = lb[2 * s * TN_LD + 64];
+            const float4 w4 = *reinterpret_cast<const float4*>(ll + 2 * s * TN_LD);
+            const float w5 = ll[2 * s * TN_LD + 4];
+            acc[0] = mfma32(a, q0, acc[0]);
+            acc[1] = mfma32(a, q1, acc[1]);
+            acc[2] = mfma32(a, q2, acc[2]);
+            // the five output columns (four of d10 and the ones column) that do not fill a 32-wide MFMA tile
+            lo[0] = fmaf(a, w4.x, lo[0]); lo[1] = fmaf(a, w4.y, lo[1]); lo[2] = fmaf(a, w4.z, lo[2]); lo[3] = fmaf(a, w4.w, lo[3]);
+            lo[4] = fmaf(a, w5, lo[4]);
+        }
+        __syncthreads();
+    }
+    float* o = out + (int64_t)ks * out_ks + (int64_t)arm * out_arm;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wv * 32 + acc_row(r, lane);
+            if (m < Mv) o[(int64_t)m * ldo + j * 32 + l31] = acc[j][r];
+        }
+    // lanes l and l ^ 32 hold the even / odd batch rows of the same output row
+#pragma unroll
+    for (int c = 0; c < 5; ++c) lo[c] += __shfl_xor(lo[c], 32, 64);
+    {
+        const int m = m0 + wv * 32 + l31;
+        if (hh == 0 && m < Mv) {
+            *reinterpret_cast<float4*>(o + (int64_t)m * ldo + 96) = make_float4(lo[0], lo[1], lo[2], lo[3]);
+            o[(int64_t)m * ldo + 100] = lo[4];
+        }
+    }
+}
+
 // TN product with M = 100 output rows (dW1 at fc_dim 100): as k_tn_v2, but a wave owns (3 MFMA row tiles + 4 leftover
 // rows done by plain FMAs on the Q fragment it already holds) x 32 columns instead of 64 x 64 of a 128-row tile with
 // 28 padding rows
@@ -1460,6 +1558,12 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
         const int tiles_n = cdiv(d.H + 1, 128);
         const int KS11 = L.sp.ks_dw11;
         dim3 grid(cdiv(d.D, 128) * tiles_n, KS11, d.A);
+        static const int v2o = getenv("MMVAE_DW11_V2") ? atoi(getenv("MMVAE_DW11_V2")) : 0;   // A/B timing
+        if (d.H == 100 && !v2o)
+            hipLaunchKernelGGL(k_tn_v3n, grid, dim3(256), 0, c.stream, c.ws + L.DZ11, (int64_t)d.B * d.D,
+                               d.D, d.D, c.ws + L.Dk[4], (int64_t)d.B * d.H, d.H, d.H, bits, wpr, c.ws + L.dw11_slab,
+                               (int64_t)d.D * DW11_LD, (int64_t)d.A * d.D * DW11_LD, DW11_LD, d.B, KS11, tiles_n);
+        else
         hipLaunchKernelGGL((k_tn_v2<false, true>), grid, dim3(256), 0, c.stream, c.ws + L.DZ11, (int64_t)d.B * d.D,
                            d.D, d.D, c.ws + L.Dk[4], (int64_t)d.B * d.H, d.H, d.H, bits, wpr, c.ws + L.dw11_slab,
                            (int64_t)d.D * DW11_LD, (int64_t)d.A * d.D * DW11_LD, DW11_LD, d.B, KS11, tiles_n);
