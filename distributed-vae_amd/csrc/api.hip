@@ -83,6 +83,7 @@ Layout make_layout(const mmvae_dims& d) {
     L.nblk32 = cdiv(d.B, 32);
     L.nblk64 = cdiv(d.B, 64);
     L.nblkc = cdiv(d.B, CHAIN_ROWS);
+    L.nblkl = cdiv(d.B, LAT_ROWS);
     L.sp = default_splits(d);
     int64_t off = 0;
     auto take = [&](int64_t n) { const int64_t o = off; off += cdiv64(n, 64) * 64; return o; };

@@ -42,6 +42,7 @@ struct Layout {
     // forward, saved for backward
     int64_t R[5];                  // R1..R4 [A,B,H], R5 [A,B,L]
     int nblkc;                       // ceil(B / CHAIN_ROWS)
+    int nblkl;                       // ceil(B / LAT_ROWS)
     int64_t bn_mean[5], bn_rstd[5];  // [A,W]
     int64_t bn_part[5];            // [A][nblk32][2][W]   (block mean, block M2)
     int64_t XLOW, CPROB, CC, YSOFT, CSMP, Y, MS, MU, LV, SS, ZIN;
@@ -273,6 +274,10 @@ constexpr int PART_MAXG = 16;
 constexpr int PART_BATCH = 16;
 // rows per workgroup of the small-layer chain kernels (chain.hip) = rows per statistics partial they emit
 constexpr int CHAIN_ROWS = 64;
+// cells per workgroup of the latent-block kernels (16 waves, one cell per wave at a time).  These kernels are
+// VALU-bound, so what counts is cells per CU: 48 gives 105 workgroups per arm at B = 5000 -- one per CU, three cells
+// per wave -- where 32 gave 314 workgroups on 256 CUs, i.e. 58 CUs with two (four cells per wave slot).
+constexpr int LAT_ROWS = 48;
 
 template <bool VEC, int NT>
 __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int PR, int W,

@@ -85,7 +85,7 @@ __device__ __forceinline__ bool state_keep(const NoiseDev& nz, int arm, int B, i
 }
 
 // Stages fcc (transposed to [L][C]) and the state-head weights in LDS once per workgroup.
-constexpr int LAT_NW = 16;   // waves per workgroup: 2 rows of the 32-row block each
+constexpr int LAT_NW = 16;   // waves per workgroup: LAT_ROWS / 16 cells each, one at a time
 __device__ __forceinline__ void lat_stage_weights(float* WcT, float* Wm, const float* __restrict__ Wc,
                                                   const float* __restrict__ Wms, int L, int C, int S) {
     for (int i = threadIdx.x; i < C * L; i += blockDim.x) {
@@ -96,7 +96,7 @@ __device__ __forceinline__ void lat_stage_weights(float* WcT, float* Wm, const f
     __syncthreads();
 }
 
-// grid (ceil(B/32), A), 1024 threads; wave w handles rows b0 + w, b0 + w + 16
+// grid (ceil(B/LAT_ROWS), A), 1024 threads; wave w handles rows b0 + w, b0 + w + 16, ...
 __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const NoiseDev nz_in,
                                                   const float* __restrict__ params, float* __restrict__ ws,
                                                   float* __restrict__ bn_running, int64_t* __restrict__ nbt) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
     __shared__ float sh_cnt[LAT_NW], sh_red[LAT_NW][2], sh_bn5[2][64];
     float (*sh_mean)[CPL * 64] = sh_stat[0];
     float (*sh_m2)[CPL * 64] = sh_stat[1];
-    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * LAT_ROWS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int B = a.B, L = a.L, C = a.C, S = a.S;
     const float* P = params + (int64_t)arm * a.per_arm;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
     const float rs5 = lane < L ? (a.bn_part5 >= 0 ? sh_bn5[1][lane] : ws[a.rstd5 + arm * L + lane]) : 0.f;
 
     stamp(0);   // weight staging + statistics loads
-    for (int row = wv; row < 32; row += LAT_NW) {
+    for (int row = wv; row < LAT_ROWS; row += LAT_NW) {
         const int b = b0 + row;
         if (b >= B) break;   // wave-uniform
         // ---- x_low = BN5(R5)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 // grid (ceil(B/32)), 256 threads.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_couple(int A, int B, int C, float eps, float lam, const float* __restrict__ CCp,
-                                                const float* __restrict__ CSMPp, const float* __restrict__ c_part,
+                                                const float* __restrict__ CSMPp, const float* __restrict__ c_part, int c_n,
                                                 float* __restrict__ c_mean, float* __restrict__ c_iv,
                                                 float* __restrict__ couple_part, float* __restrict__ T_part) {
     __shared__ __attribute__((aligned(16))) float shT[4][MMVAE_MAX_ARMS][CPL * 64];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_couple(int A, int B, int C, float eps, 
     // from k_lat_fwd's per-row-block partials [A][nblk][2][C]; row block 0 keeps them for the backward
     for (int aa = 0; aa < A; ++aa) {
         float mean, m2;
-        stats_from_partials<256>(c_part + (int64_t)aa * gridDim.x * 2 * C, gridDim.x, B, 32, C, &shT[0][0][0], mean, m2);
+        stats_from_partials<256>(c_part + (int64_t)aa * c_n * 2 * C, c_n, B, LAT_ROWS, C, &shT[0][0][0], mean, m2);
         if (threadIdx.x < C) {
             const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
             sh_iv[aa][threadIdx.x] = ivv;
@@ -451,7 +451,7 @@ __device__ double block_sum_d(double v, double* sh) {
 
 __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int C, float beta, float lam,
                                                        const float* __restrict__ fc11_part, int n11,
-                                                       const float* __restrict__ lat_part, int nblk,
+                                                       const float* __restrict__ lat_part, int nlat, int nblk,
                                                        const float* __restrict__ couple_part,
                                                        const float* __restrict__ T_part, float* __restrict__ T,
                                                        float* __restrict__ out) {
@@ -479,9 +479,9 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
             se += fc11_part[((int64_t)a * n11 + i) * 2];
             mm += fc11_part[((int64_t)a * n11 + i) * 2 + 1];
         }
-        for (int i = tid; i < nblk; i += 256) {
-            kl += lat_part[((int64_t)a * nblk + i) * 2];
-            en += lat_part[((int64_t)a * nblk + i) * 2 + 1];
+        for (int i = tid; i < nlat; i += 256) {
+            kl += lat_part[((int64_t)a * nlat + i) * 2];
+            en += lat_part[((int64_t)a * nlat + i) * 2 + 1];
         }
         se = block_sum_d(se, sh); mm = block_sum_d(mm, sh); kl = block_sum_d(kl, sh); en = block_sum_d(en, sh);
         const double rec = 0.5 * se / B + 0.5 * (100.0 * mm / ((double)B * D));   // nn_model.py:544-546
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward of the latent block.  grid (ceil(B/32), A), 256 threads, one wave per cell.
+// backward of the latent block.  grid (ceil(B/LAT_ROWS), A), 1024 threads, one wave per cell at a time.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const NoiseDev nz_in,
                                                   const float* __restrict__ params, float* __restrict__ ws) {
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const Nois
     const NoiseDev nz = nz_in;
     extern __shared__ __attribute__((aligned(16))) float lat_smem[];
     __shared__ float sh_s[LAT_NW][2][64];
-    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * LAT_ROWS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int A = a.A, B = a.B, L = a.L, C = a.C, S = a.S;
     const float* P = params + (int64_t)arm * a.per_arm;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const Nois
     }
     float s1 = 0.f, s2 = 0.f;   // BN5 backward sums for column `lane` (< L)
 
-    for (int row = wv; row < 32; row += LAT_NW) {
+    for (int row = wv; row < LAT_ROWS; row += LAT_NW) {
         const int b = b0 + row;
         if (b >= B) break;
         // ---- state head backward (lanes < S)
@@ -870,7 +870,7 @@ int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, flo
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblk32, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws,
+    hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblkl, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws,
                        bn_running, nbt);
     HIP_LAUNCH_CHECK("k_lat_fwd");
     return 0;
@@ -880,7 +880,7 @@ int launch_couple(const Ctx& c) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     hipLaunchKernelGGL(k_couple, dim3(L.nblk32), dim3(256), 0, c.stream, d.A, d.B, d.C, c.h.eps, c.h.lam, c.ws + L.CC,
-                       c.ws + L.CSMP, c.ws + L.c_part, c.ws + L.c_mean, c.ws + L.c_iv, c.ws + L.couple_part,
+                       c.ws + L.CSMP, c.ws + L.c_part, L.nblkl, c.ws + L.c_mean, c.ws + L.c_iv, c.ws + L.couple_part,
                        c.ws + L.T_part);
     HIP_LAUNCH_CHECK("k_couple");
     return 0;
@@ -890,7 +890,7 @@ int launch_loss_finalize(const Ctx& c, float* loss_out) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     hipLaunchKernelGGL(k_loss_finalize, dim3(1 + cdiv(d.A * d.C, 32)), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C,
-                       c.h.beta, c.h.lam, c.ws + L.fc11_part, L.n11, c.ws + L.lat_part, L.nblk32, c.ws + L.couple_part,
+                       c.h.beta, c.h.lam, c.ws + L.fc11_part, L.n11, c.ws + L.lat_part, L.nblkl, L.nblk32, c.ws + L.couple_part,
                        c.ws + L.T_part, c.ws + L.T, loss_out);
     HIP_LAUNCH_CHECK("k_loss_finalize");
     return 0;
@@ -900,7 +900,7 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    hipLaunchKernelGGL(k_lat_bwd, dim3(c.lay.nblk32, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws);
+    hipLaunchKernelGGL(k_lat_bwd, dim3(c.lay.nblkl, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws);
     HIP_LAUNCH_CHECK("k_lat_bwd");
     return 0;
 }
