@@ -680,7 +680,7 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.slab_stride = 0;
     // BN_layer's backward sums: per workgroup of the latent backward (layer 5), else of the previous chain launch
     a.bnb_part_off = L.bnb_part[layer];
-    a.bnb_n = (layer == 5) ? L.nblkl : L.nblkc;
+    a.bnb_n = (layer == 5) ? cdiv(d.B, LAT_ROWS_BWD) : L.nblkc;
     a.bn_mean_off = L.bn_mean[i];
     a.bn_rstd_off = L.bn_rstd[i];
     a.gout_off = L.G[layer - 1];

@@ -278,6 +278,9 @@ constexpr int CHAIN_ROWS = 64;
 // VALU-bound, so what counts is cells per CU: 48 gives 105 workgroups per arm at B = 5000 -- one per CU, three cells
 // per wave -- where 32 gave 314 workgroups on 256 CUs, i.e. 58 CUs with two (four cells per wave slot).
 constexpr int LAT_ROWS = 48;
+// The backward kernel runs beside the dW11 GEMM of the side stream, where smaller workgroups spread over all CUs
+// measured faster in the step (61 against 70 us) although slower alone (32 against 24 us).
+constexpr int LAT_ROWS_BWD = 32;
 
 template <bool VEC, int NT>
 __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int PR, int W,
