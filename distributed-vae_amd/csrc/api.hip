@@ -48,7 +48,7 @@ Splits default_splits(const mmvae_dims& d) {
     s.ks_small = g_split[3] > 0 ? g_split[3] : fit(N_SMALL * d.A, 3 * CUS, 32);   // 3 workgroups / CU (136 VGPRs)
     s.ks_small = min(s.ks_small, max(1, cdiv(d.B, 32)));
     s.ks_gd10 = g_split[4] > 0 ? g_split[4] : fit(nb128 * d.A, (fastdims && d.H == 100 ? 2 : 3) * CUS, 16);   // fc_dim 100: k_gd10_v3, 2 / CU
-    s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, 32)));
+    s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, fastdims && d.H == 100 ? 64 : 32)));   // fc_dim 100: also k_fc11_zg's gene split
     return s;
 }
 
@@ -102,7 +102,7 @@ Layout make_layout(const mmvae_dims& d) {
     L.c_part = take(A * nb * 2 * C); L.c_mean = take(A * C); L.c_iv = take(A * C);
     L.lat_part = take(A * nb * 2);
     L.fc1_slab = take((int64_t)L.sp.ks_fc1 * A * B * NP);
-    L.n11 = (L.nblk64 + 2) * (L.sp.ns_fc11 + 1) + cdiv(d.D, 64);
+    L.n11 = (L.nblk64 + 2) * (max(L.sp.ns_fc11, L.sp.ks_gd10) + 1) + cdiv(d.D, 64);
     L.fc11_part = take(A * (int64_t)L.n11 * 2 + 64);   // + diagnostic stamp counters
     L.GD10_slab = take((int64_t)max(L.sp.ns_fc11, L.sp.ks_gd10) * A * B * H);
     L.DZ11 = take(A * B * D);

@@ -1195,6 +1195,308 @@ __global__ __launch_bounds__(512, 2) void k_fc11_zt(const float* __restrict__ d1
 }
 
 // =============================================================================================
+// fc11 forward + reconstruction loss + dZ11 + d(d10), train step at fc_dim = 100.  k_fc11_zt with the d(d10) GEMM of
+// k_gd10_v3 folded in: each wave keeps the dZ11 tile it has just produced in LDS and multiplies it with the W11 tile
+// that is already there (3 MFMA column tiles + 4 VALU columns), accumulating its 32 cells' d(d10) over the gene
+// range in registers.  k_fc11_zt alone leaves the matrix pipe about half idle (it is bound by the CU's memory queue);
+// the fused kernel fills that time instead of launching a second GEMM that re-reads dZ11 (200 MB).  Three W buffers:
+// the late waves multiply tile t-1 while tile t+1 is staged.  Output: d(d10) slabs [NS][A][B][H], summed by the
+// decoder's backward prologue.
+// =============================================================================================
+typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+constexpr int ZG_LD = 68;   // dZ11 tile row stride (ld / 4 odd: conflict-free b128 A-fragment reads)
+
+template <int FZ_KG, bool EXACT, bool BIASK>
+__global__ __launch_bounds__(512, 2) void k_fc11_zg(const float* __restrict__ d10, const float* __restrict__ params,
+                                                    int64_t per_arm, int64_t w_off, int64_t b_off,
+                                                    const float* __restrict__ x, int64_t x_arm_stride,
+                                                    float* __restrict__ x_rec, float* __restrict__ dz11,
+                                                    float* __restrict__ part, int n11, float coef, int need_grad,
+                                                    int A, int B, int D, int H, int ldk, float* __restrict__ gd_slab) {
+    constexpr bool XREC = false;
+    constexpr int ABL = 0;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wbuf = smem;                               // [3][64][ldk]: tiles t-1 (late waves' d(d10)), t, t+1 (being staged)
+    float* DZall = smem + 3 * 64 * ldk;               // [8 waves][32 cells][ZG_LD]: each wave's dZ11 tile
+    float* red = DZall + 8 * 32 * ZG_LD;              // [16]
+    const int arm = blockIdx.z, ns = blockIdx.y, NS = gridDim.y, b0 = blockIdx.x * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const bool lb0 = (lane & 1) != 0, lb1 = (lane & 2) != 0;
+    const int KP = rup(H, 8), kg = KP / 8, nc4 = KP / 4, hc4 = H / 4;
+    const bool late = (ABL & 16) ? wv < 4 : wv >= 4;
+    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
+    const float* bias = params + (int64_t)arm * per_arm + b_off;
+    const float* xa = x + (int64_t)arm * x_arm_stride;
+    float* dza = dz11 + (int64_t)arm * B * D;
+    float* xra = XREC ? x_rec + (int64_t)arm * B * D : nullptr;
+    const bool do_grad = XREC ? (need_grad != 0) : true;
+    const int bw = b0 + 32 * wv;
+    float* DZw = DZall + wv * (32 * ZG_LD);
+    const bool rows_full = b0 + 256 <= B;
+
+    // ---- d10 fragments (MFMA A operand): cell = bw + (lane & 31), k = 8 g + 4 hh .. + 3
+    float4 afr[FZ_KG];
+    {
+        const int row = bw + l31;
+        const float* p = d10 + ((int64_t)arm * B + min(row, B - 1)) * H + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < FZ_KG; ++g) {
+            const int k0 = 8 * g + 4 * hh;
+            const bool ok = row < B && k0 < H;
+            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? 8 * g : 0));
+            afr[g] = sel4(ok, v);
+            if (BIASK && k0 == H) afr[g].x = 1.f;
+        }
+    }
+    const int ntall = cdiv(D, 64);
+    const int t0 = (int)(((int64_t)ns * ntall) / NS), t1 = (int)(((int64_t)(ns + 1) * ntall) / NS);
+    const int srow = tid >> 3, spart = tid & 7;
+    // The W tile for step t+1 is requested one step ahead and lands in registers while the MFMAs / epilogue run;
+    // masking and the bias column are applied when it is written to LDS (touching the loaded values any
+    // earlier makes the compiler wait for the loads where they are issued).
+    float4 wreg[4];
+    float wbias = 0.f;
+    int wj = 0;
+    auto prefetch_w = [&](int t) {
+        wj = t * 64 + srow;
+        const float* p = W + (int64_t)min(wj, D - 1) * H;
+        if (BIASK) wbias = bias[min(wj, D - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = spart + 8 * i;
+            wreg[i] = *reinterpret_cast<const float4*>(p + (c < hc4 ? c * 4 : 0));
+        }
+    };
+    auto store_w = [&](float* Ws) {
+        const bool jok = wj < D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = spart + 8 * i;
+            float4 v = sel4(jok && c < hc4, wreg[i]);
+            if (BIASK && c == hc4) v.x = jok ? wbias : 0.f;
+            if (c < nc4) *reinterpret_cast<float4*>(&Ws[srow * ldk + c * 4]) = v;
+        }
+    };
+    // after the quad transposes: register group q of a lane is cell cq = bw + 8 q + 4 hh + (lane & 3),
+    // genes j0 + 32 c + 4 ((lane & 31) >> 2) .. + 3
+    const int cbase = bw + 4 * hh + (l31 & 3);
+    const int gcol = 4 * (l31 >> 2);
+    // interior accesses: buffer instructions with one 32-bit per-lane byte offset (VGPR) + a wave-uniform byte offset
+    // (SGPR); flat 64-bit addresses cost a VGPR pair per (half, cell group) for loads and again for stores
+    const uint32_t lane_boff = ((uint32_t)cbase * (uint32_t)D + (uint32_t)gcol) * 4u;   // B * D < 2^30
+    const int arm_bytes = (int)((uint32_t)B * (uint32_t)D * 4u);
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa), 0, arm_bytes, 0x00020000);
+    const auto rs_dz = __builtin_amdgcn_make_buffer_rsrc(dza, 0, arm_bytes, 0x00020000);
+    float se = 0.f;
+    int mism = 0;   // per-lane count
+    f32x16 z0 = zero16(), z1 = zero16();
+    float4 xv[2][4];
+
+    // one 16-byte piece (gene half c, cell group q) of tile t's x
+    auto load_x1 = [&](int t, int c, int q, float4& dst, auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        if (ABL & 2) { dst = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+        if (!EDGE) {
+            const uint32_t so = ((uint32_t)(8 * q) * (uint32_t)D + (uint32_t)(t * 64 + 32 * c)) * 4u;   // wave-uniform
+            dst = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)lane_boff, (int)so, 0));
+        } else {
+            const int cellq = min(cbase + 8 * q, B - 1), col = min(t * 64 + 32 * c + gcol, D - 4);
+            dst = *reinterpret_cast<const float4*>(xa + (uint32_t)cellq * (uint32_t)D + (uint32_t)col);
+        }
+    };
+    auto load_x = [&](int t, float4 (&dst)[2][4], auto edge_tag) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_x1(t, c, q, dst[c][q], edge_tag);
+    };
+    auto mfma_tile = [&](const float* Ws) __attribute__((always_inline)) {
+        z0 = zero16();
+        z1 = zero16();
+        const float* pb = Ws + l31 * ldk + 4 * hh;
+        // no register double-buffering of the W fragments here (this kernel sits at the 256-VGPR cap): the partner
+        // wave's MFMAs cover the LDS latency
+#pragma unroll
+        for (int g = 0; g < FZ_KG; ++g) {
+            if (EXACT || g < kg) {
+                const float4 q0 = *reinterpret_cast<const float4*>(pb + 8 * g);
+                const float4 q1 = *reinterpret_cast<const float4*>(pb + 32 * ldk + 8 * g);
+                const float4 a = afr[g];
+                z0 = mfma32(a.x, q0.x, z0); z1 = mfma32(a.x, q1.x, z1);
+                z0 = mfma32(a.y, q0.y, z0); z1 = mfma32(a.y, q1.y, z1);
+                z0 = mfma32(a.z, q0.z, z0); z1 = mfma32(a.z, q1.z, z1);
+                z0 = mfma32(a.w, q0.w, z0); z1 = mfma32(a.w, q1.w, z1);
+            }
+        }
+    };
+    // x_rec = relu(z + b); e = x_rec - x; dZ11 = coef * e where x_rec > 0 (nn_model.py:544-546 + autograd)
+    auto epilogue = [&](int t, const float4 (&xs)[2][4], auto edge_tag) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = t * 64 + 32 * c + gcol;
+            float bq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!BIASK) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + (EDGE ? min(col, D - 4) : col));
+                bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float zz[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zz[e] = (c == 0 ? z0[4 * q + e] : z1[4 * q + e]);
+                quad_transpose4(zz[0], zz[1], zz[2], zz[3], lb0, lb1);
+                const bool ok = !EDGE || ((cbase + 8 * q < B) && (col < D));
+                const float xin[4] = {xs[c][q].x, xs[c][q].y, xs[c][q].z, xs[c][q].w};
+                float xr[4], dzv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xr[e] = fmaxf(zz[e] + bq[e], 0.f);
+                    const float er = xr[e] - xin[e];
+                    dzv[e] = (ok && xr[e] > 0.f) ? coef * er : 0.f;
+                    se += ok ? er * er : 0.f;
+                    // per-lane count (keeping 64 ballot masks alive spills SGPRs into VGPR lanes)
+                    mism += (ok && ((xr[e] > 0.1f) != (xin[e] > 0.1f))) ? 1 : 0;
+                }
+                // the wave's own dZ11 tile, [cell][gene], for its d(d10) MFMAs (zero where the piece is out of range)
+                *reinterpret_cast<float4*>(&DZw[(8 * q + 4 * hh + (l31 & 3)) * ZG_LD + 32 * c + gcol]) =
+                    make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+                if (ok) {
+                    if (!EDGE) {
+                        const uint32_t so = ((uint32_t)(8 * q) * (uint32_t)D + (uint32_t)(t * 64 + 32 * c)) * 4u;   // wave-uniform
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(bu32x4, make_float4(dzv[0], dzv[1], dzv[2], dzv[3])), rs_dz, (int)lane_boff, (int)so, 0);
+                    } else {
+                        const uint32_t off = (uint32_t)(cbase + 8 * q) * (uint32_t)D + (uint32_t)col;
+                        if (XREC) *reinterpret_cast<float4*>(xra + off) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+                        if (do_grad) *reinterpret_cast<float4*>(dza + off) = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+                    }
+                }
+                // piece fence.  The accumulators are pinned here: integer adds are associative, so left alone the
+                // optimiser turns the 32 mismatch increments of a step into one tree at its end and keeps every
+                // compare result (and the x_rec / x values feeding it) alive until then; and the scheduler hoists
+                // all compares to the top and spills their lane masks into VGPR lanes.
+                asm volatile("" : "+v"(mism), "+v"(se));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // d(d10) += dZ11 tile (this wave's 32 cells x 64 genes, from LDS) x W11 tile (64 genes x H): 3 MFMA column tiles
+    // + columns 96..99 by plain FMAs, as k_gd10_v3
+    f32x16 gacc[3] = {zero16(), zero16(), zero16()};
+    float glo[4] = {0.f, 0.f, 0.f, 0.f};
+    auto mfma_gd = [&](const float* Ws) __attribute__((always_inline)) {
+        const float* pa = DZw + l31 * ZG_LD + 4 * hh;
+        const float* pb = Ws + (4 * hh) * ldk + l31;
+        const float* pl = Ws + (4 * hh) * ldk + 96;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(pa + 8 * g);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float* q = pb + (8 * g + e) * ldk;
+                const float q0 = q[0], q1 = q[32], q2 = q[64];
+                const float4 w = *reinterpret_cast<const float4*>(pl + (8 * g + e) * ldk);
+                gacc[0] = mfma32(av[e], q0, gacc[0]);
+                gacc[1] = mfma32(av[e], q1, gacc[1]);
+                gacc[2] = mfma32(av[e], q2, gacc[2]);
+                glo[0] = fmaf(av[e], w.x, glo[0]); glo[1] = fmaf(av[e], w.y, glo[1]);
+                glo[2] = fmaf(av[e], w.z, glo[2]); glo[3] = fmaf(av[e], w.w, glo[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the fragment registers of one k group at a time
+        }
+    };
+
+    if (t0 < t1) {
+        prefetch_w(t0);
+        store_w(Wbuf);
+    }
+    __syncthreads();
+    int cur = 0;   // W buffer of the current tile; (cur + 1) % 3 is being staged, (cur + 2) % 3 holds the previous tile
+    // Every step body is straight-line per role: no condition around a load or a store (a conditional epilogue or
+    // prefetch makes the compiler's vmcnt bookkeeping pessimistic at the join, and it then waits for the previous
+    // step's dZ11 stores before touching the W tile).  The W prefetch of the last step re-reads a clamped row and
+    // its LDS copy is never used; the late waves' first step (no tile behind them yet) is a separate instance.
+    auto step = [&](int t, auto edge_tag, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const float* Ws = Wbuf + cur * 64 * ldk;
+        const int nxt = cur == 2 ? 0 : cur + 1, prv = cur == 0 ? 2 : cur - 1;
+        // phase fences: without them the scheduler hoists epilogue work that only needs x (the mismatch
+        // compares) to the top of the step, where it waits for the loads just issued, and sinks W loads behind
+        // the dZ11 stores
+        if (!late) {
+            load_x(t, xv, edge_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(Ws);
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch_w(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue(t, xv, edge_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_gd(Ws);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // W loads before the epilogue's stores: vmcnt retires in order
+            prefetch_w(t + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!FIRST) {
+                epilogue(t - 1, xv, edge_tag);   // z still holds tile t-1
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_gd(Wbuf + prv * 64 * ldk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_x(t, xv, edge_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(Ws);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // tile t+1 goes where tile t-2 was: its last readers (the late waves' d(d10) of step t-1) are past a barrier
+        store_w(Wbuf + nxt * 64 * ldk);
+        lds_barrier();      // LDS only: the dZ11 stores stay in flight
+        cur = nxt;
+    };
+    // first step (guarded body, valid for any tile), interior steps (all 256 cells and all 64 genes in range),
+    // then the guarded ones
+    const int t_mid = rows_full ? max(t0 + 1, min(t1, D / 64)) : t0 + 1;
+    if (t0 < t1) step(t0, VecTag{}, VecTag{});
+    for (int t = t0 + 1; t < t_mid; ++t) step(t, ScalarTag{}, ScalarTag{});      // ::value == false: interior body
+    for (int t = max(t_mid, t0 + 1); t < t1; ++t) step(t, VecTag{}, ScalarTag{});    // guarded body
+    if (late && t1 > t0) {
+        epilogue(t1 - 1, xv, VecTag{});
+        mfma_gd(Wbuf + (cur == 0 ? 2 : cur - 1) * 64 * ldk);   // cur has moved past the last tile
+    }
+    // ---- d(d10) partial of this gene range: slab [NS][A][B][H]
+    {
+        float* out = gd_slab + (((int64_t)ns * A + arm) * B) * H;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bw + acc_row(r, lane);
+                if (row < B) out[(int64_t)row * H + j * 32 + l31] = gacc[j][r];
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) glo[c] += __shfl_xor(glo[c], 32, 64);   // the two k halves of the same cell
+        const int row = bw + l31;
+        if (hh == 0 && row < B) *reinterpret_cast<float4*>(out + (int64_t)row * H + 96) = make_float4(glo[0], glo[1], glo[2], glo[3]);
+    }
+    se = wave_sum(se);
+    const float mismf = wave_sum((float)mism);
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mismf; }
+    __syncthreads();
+    if (tid == 0) {
+        float* p = part + ((int64_t)arm * n11 + (int64_t)blockIdx.x * NS + ns) * 2;
+        float s0 = 0.f, s1 = 0.f;
+        for (int w = 0; w < 8; ++w) { s0 += red[w * 2]; s1 += red[w * 2 + 1]; }
+        p[0] = s0;
+        p[1] = s1;
+    }
+}
+
+// =============================================================================================
 // d(d10) = dZ11 W11: M = cells, N = H, K = genes.  Tile 128 x 128, K tile 32, wave tile 64 x 64.
 // A = dZ11 (K contiguous, b128 fragment reads), B = W11 rows (h contiguous, b32 reads).
 // grid (ceil(B/128), KS, A) -> slabs [KS][A][B][H]
@@ -1450,6 +1752,28 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         HIP_LAUNCH_CHECK("k_fc11_v2");
         return 0;
     }
+    // train step at fc_dim 100: d(d10) is folded into the fc11 kernel (k_fc11_zg), whose gene split count equals the
+    // d(d10) kernel's so that the decoder backward sums the same number of slabs whichever forward ran
+    static const int zg_off = getenv("MMVAE_FC11_ZG") ? (atoi(getenv("MMVAE_FC11_ZG")) == 0) : 0;   // A/B timing
+    static const int zold_ = getenv("MMVAE_FC11_ZOLD") ? atoi(getenv("MMVAE_FC11_ZOLD")) : 0;
+    const bool use_zg = need_grad && !x_rec && d.H == 100 && !zg_off && zold_ == 0 &&
+                        (int64_t)cdiv(d.B, 256) * L.sp.ks_gd10 <= L.n11;
+    if ((which & 1) && use_zg) {
+        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
+        const size_t shm = (size_t)(3 * 64 * ldk + 8 * 32 * ZG_LD + 16) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {   // more than 64 KB of dynamic LDS needs the opt-in
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fc11_zg<13, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((k_fc11_zg<13, true, true>), dim3(cdiv(d.B, 256), L.sp.ks_gd10, d.A), dim3(512), shm, c.stream,
+                           c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,
+                           c.ws + L.fc11_part, L.n11, coef, need_grad, d.A, d.B, d.D, d.H, ldk, c.ws + L.GD10_slab);
+        HIP_LAUNCH_CHECK("k_fc11_zg");
+    }
+    if (use_zg) return 0;
     if (which & 1) {
         // loss partials: the launch below fills a subset of the reserved slots
         hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
