@@ -218,8 +218,8 @@ STAGES = {
     # as functions of (A,B,D,H).  dW11 runs on a side stream beside the latency-bound backward chain (with fewer,
     # longer workgroups on purpose), so it is timed but never chosen as the roofline kernel.
     14: ("k_fc1_fwd_v3|k_fc1_fwd_v2", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D, True),
-    10: ("k_fc11_zt", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 2 * 4.0 * B * D, True),
-    11: ("k_gd10_v3|k_gd10_v2", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D, True),
+    # fc11 forward + loss + dZ11 + d(d10): one fused kernel at fc_dim 100 (2 GEMMs' worth of FLOPs), two launches otherwise
+    1: ("k_fc11_zg|k_fc11_zt+k_gd10_v2", lambda A, B, D, H: A * 4.0 * B * D * H, lambda A, B, D, H: A * 2 * 4.0 * B * D, True),
     12: ("k_tn_v3m<dW1>|k_tn_v2<dW1>", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D, True),
     13: ("k_tn_v3n<dW11>|k_tn_v2<dW11>", lambda A, B, D, H: A * 2.0 * B * D * H, lambda A, B, D, H: A * 4.0 * B * D, False),
 }
@@ -269,11 +269,11 @@ def pmc_traffic(kernel, A, B, D, H):
     by tools/pmc_summary.py from two separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this
     bench command). PMC counters cannot be read from inside the process, so the number is only reported for
     the shape it was collected on; FETCH_SIZE (KB) is doubled as the gfx950 guide prescribes for 16-byte-per-
-    lane loads -- which is how k_fc11_zt and k_fc1_fwd_v3 read x and the weights -- and WRITE_SIZE (KB) is
+    lane loads -- which is how k_fc11_zg and k_fc1_fwd_v3 read x and the weights -- and WRITE_SIZE (KB) is
     taken as is.  Other kernels: null (their load widths are uncalibrated)."""
     import csv
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_summary.csv")
-    if (A, B, D, H) != (2, 5000, 5000, 100) or kernel not in ("k_fc11_zt", "k_fc1_fwd_v3") or not os.path.exists(path):
+    if (A, B, D, H) != (2, 5000, 5000, 100) or kernel not in ("k_fc11_zg", "k_fc1_fwd_v3") or not os.path.exists(path):
         return None, None
     for r in csv.DictReader(open(path)):
         if r["kernel"].startswith(kernel) and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
