@@ -149,6 +149,46 @@ def test_golden_mid_case():
             assert G.rel_err(v, g["grad/" + k]) < GRAD_TOL, k
 
 
+def test_fused_step_matches_api_path_fc100():
+    """fc_dim = 100 takes the specialised kernels in the fused train step (fc11 + loss + dZ11 + d(d10) in one kernel, the
+    96 + 4 column GEMMs, coupling / loss scalars / dW11 on the side stream, Adam inside the slab reduction).  Its loss
+    vector and gradients must equal what forward() / loss() / backward() give on the same inputs (that path is pinned
+    to the reference by test_golden_mid_case), and its Adam step what torch.optim.Adam does with those gradients."""
+    U = _U()
+    from distributed_vae_amd.cpl_mixvae import FusedAdam
+    g = G.load("mid_a2")
+    h = G.hyper_of(g)
+    B = G.batch_of(g)
+    assert h.fc_dim == 100
+    sd = R.init_state_dict(h, int(g["seed"]))
+    x = R.synthetic_batch(B, h.input_dim).to(U.DEV)
+    noise = R.draw_noise(h, B, seed=int(g["noise_seed"]))
+    m1 = U.build_model(h, sd); m1.train()
+    _, lt, grads = U.run_step(m1, x, noise)
+    # gradients only
+    m2 = U.build_model(h, sd); m2.train()
+    m2.set_explicit_noise(U.noise_to_device(noise))
+    buf = m2.fused_train_step(x.expand(h.n_arm, -1, -1), 1.0, None, do_adam=False)
+    torch.cuda.synchronize()
+    _loss_close(buf[0], lt[0], 1e-6)
+    for (k, _), gv in zip(m2.named_parameters(), m2._grad_views):   # the fused step leaves the gradient in the flat buffer
+        assert G.rel_err(gv.cpu(), grads[k]) < 1e-5, k               # same arithmetic up to the d(d10) slab order
+    # with the Adam update riding on the reduction
+    m3 = U.build_model(h, sd); m3.train()
+    m3.set_explicit_noise(U.noise_to_device(noise))
+    opt = FusedAdam(m3, lr=1e-3)
+    m3.fused_train_step(x.expand(h.n_arm, -1, -1), 1.0, opt, do_adam=True)
+    torch.cuda.synchronize()
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items() if k in grads}
+    topt = torch.optim.Adam(list(ref.values()), lr=1e-3)
+    for k, p in ref.items():
+        p.grad = grads[k].clone()
+    topt.step()
+    for k, p in m3.named_parameters():
+        diff = (p.detach().cpu() - ref[k].detach()).abs()
+        assert float(diff.max()) < 1.1e-3 and float(diff.median()) < 1e-5, (k, float(diff.max()), float(diff.median()))
+
+
 ODD = [
     # A, B, D, H, L, C, S, hard, s_drop, x_drop
     (2, 33, 50, 10, 3, 8, 2, False, 0.0, 0.5),       # D % 4 != 0, ragged batch
@@ -485,6 +525,16 @@ def test_full_size_properties(full):
     # few isolated elements: same two-part bound as test_full_size_against_oracle (typical element tight, worst loose)
     for k in g1:
         e = ((g4[k].double() - g1[k].double()).abs() / (float(g1[k].abs().max()) + 1e-30)).flatten()
+        p90 = float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
+        assert p90 < 1e-4 and float(e.max()) < 5 * GRAD_TOL, (k, p90, float(e.max()))
+    # the fused train step (fused fc11 / d(d10) kernel, side stream) against the separately-called API path
+    m6 = U.build_model(h, sd); m6.train()
+    m6.set_explicit_noise(U.noise_to_device(noise))
+    buf6 = m6.fused_train_step(xs, 1.0, None, do_adam=False)
+    torch.cuda.synchronize()
+    _loss_close(buf6[0], lt1[0], 1e-6)
+    for (k, _), gv in zip(m6.named_parameters(), m6._grad_views):
+        e = ((gv.cpu().double() - g1[k].double()).abs() / (float(g1[k].abs().max()) + 1e-30)).flatten()
         p90 = float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
         assert p90 < 1e-4 and float(e.max()) < 5 * GRAD_TOL, (k, p90, float(e.max()))
     # swapping the two arms (parameters and noise) swaps their gradients
