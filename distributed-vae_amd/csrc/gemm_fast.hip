@@ -1367,6 +1367,13 @@ __global__ __launch_bounds__(512, 2) void k_fc11_zg(const float* __restrict__ d1
                         const uint32_t so = ((uint32_t)(8 * q) * (uint32_t)D + (uint32_t)(t * 64 + 32 * c)) * 4u;   // wave-uniform
                         __builtin_amdgcn_raw_buffer_store_b128(
                             __builtin_bit_cast(bu32x4, make_float4(dzv[0], dzv[1], dzv[2], dzv[3])), rs_dz, (int)lane_boff, (int)so, 0);
+                        // A 128-bit buffer store reads its data registers over more than one cycle.  hipcc pads this
+                        // hazard only for stores WITHOUT an SGPR offset; measured on gfx950 it exists with one too:
+                        // the next piece's first VALU write into the same registers (zero wait states after the
+                        // store in the generated code) corrupted the stored dZ11, nondeterministically and mostly
+                        // under memory-pipe back-pressure (81k of 50M elements at the benchmark shape; 0 with the
+                        // two wait states the compiler gives global stores).
+                        asm volatile("s_nop 1");
                     } else {
                         const uint32_t off = (uint32_t)(cbase + 8 * q) * (uint32_t)D + (uint32_t)col;
                         if (XREC) *reinterpret_cast<float4*>(xra + off) = make_float4(xr[0], xr[1], xr[2], xr[3]);
