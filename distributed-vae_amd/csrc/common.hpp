@@ -454,7 +454,8 @@ struct NoiseDev {
     const uint8_t* s_mask;
     uint32_t k0, k1;       // seed
     uint32_t step_lo, step_hi;
-    uint32_t x_keep_thr;   // input dropout: keep iff u16 < thr, thr = round((1-p) * 65536) in [0, 65536]
+    uint32_t x_mlog2;      // input dropout: m = 1 << x_mlog2 random bits per element (see xmask_keep)
+    uint32_t x_thr;        //   keep iff the element's m-bit field < x_thr, x_thr = round((1-p) 2^16) >> (16 - m) in [0, 2^m]
     uint32_t s_keep_thr;   // state dropout: keep iff u32 < thr (thr = (1-p) * 2^32, saturated)
 };
 
@@ -491,25 +492,24 @@ __device__ __forceinline__ bool noise_keep(const NoiseDev& nz, int arm, int kind
     const uint32_t v = pick(w, (int)(idx & 3));
     return thr == 0xFFFFFFFFu ? true : (v < thr);
 }
-// Input-dropout keep decision for element e of an arm's [B, D] stream: 16 random bits per element, 8
-// elements per Philox call (the B x D mask is the only noise large enough for the generator to cost
-// time: 25 M elements per arm per step).  Resolution of the keep probability: 2^-16.
-__device__ __forceinline__ bool xmask_keep16(const NoiseDev& nz, int arm, uint64_t e) {
-    const u32x4 w = noise_words(nz, arm, STREAM_XMASK, e >> 3);
-    const uint32_t word = pick(w, (int)((e >> 1) & 3));
-    const uint32_t u16 = (e & 1) ? (word >> 16) : (word & 0xFFFFu);
-    return u16 < nz.x_keep_thr;
+// Input-dropout keep decision for gene `col` of cell `row`.  The B x D mask is the only noise large enough for the
+// generator to cost time (25 M elements per arm per step: 21 us of Philox at 16 bits per element), so an element takes
+// only as many random bits as the keep probability needs: m = 1, 2, 4, 8 or 16, the smallest with round((1-p) 2^16)
+// a multiple of 2^(16-m) (p = 0.5: one bit per element; resolution of p: 2^-16).  One Philox call serves the 128/m
+// consecutive genes [cg * 128/m, ...) of one row: counter (cg, row, stream ^ step_hi, step_lo); element i of the
+// group owns bits [i m, (i+1) m) of the 128-bit output (word i m / 32), and is kept iff that field < x_thr.
+__device__ __forceinline__ u32x4 xmask_words(const NoiseDev& nz, int arm, uint32_t row, uint32_t cg) {
+    return philox4x32(cg, row, (uint32_t)(arm * 4 + STREAM_XMASK) ^ (nz.step_hi << 8), nz.step_lo, nz.k0, nz.k1);
 }
-// keep bits of the 8 elements of one Philox group (bit i <-> element 8 g + i)
-__device__ __forceinline__ uint32_t xmask_keep8(const NoiseDev& nz, int arm, uint64_t group) {
-    const u32x4 w = noise_words(nz, arm, STREAM_XMASK, group);
-    const uint32_t t = nz.x_keep_thr;
-    uint32_t b = 0;
-    b |= ((w.x & 0xFFFFu) < t) ? 1u : 0u;   b |= ((w.x >> 16) < t) ? 2u : 0u;
-    b |= ((w.y & 0xFFFFu) < t) ? 4u : 0u;   b |= ((w.y >> 16) < t) ? 8u : 0u;
-    b |= ((w.z & 0xFFFFu) < t) ? 16u : 0u;  b |= ((w.z >> 16) < t) ? 32u : 0u;
-    b |= ((w.w & 0xFFFFu) < t) ? 64u : 0u;  b |= ((w.w >> 16) < t) ? 128u : 0u;
-    return b;
+__device__ __forceinline__ bool xmask_field_keep(const NoiseDev& nz, const u32x4& w, uint32_t i) {
+    const uint32_t bit = i << nz.x_mlog2;
+    const uint32_t f = (pick(w, (int)(bit >> 5)) >> (bit & 31u)) & (0xFFFFFFFFu >> (32 - (1 << nz.x_mlog2)));
+    return f < nz.x_thr;
+}
+__device__ __forceinline__ bool xmask_keep(const NoiseDev& nz, int arm, int row, int col) {
+    const int epg_log2 = 7 - nz.x_mlog2;
+    const u32x4 w = xmask_words(nz, arm, (uint32_t)row, (uint32_t)col >> epg_log2);
+    return xmask_field_keep(nz, w, (uint32_t)col & ((1u << epg_log2) - 1u));
 }
 #endif  // __HIPCC__
 

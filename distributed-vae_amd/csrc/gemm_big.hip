@@ -52,11 +52,13 @@ __device__ __forceinline__ float4 apply_xmask(float4 v, const NoiseDev& nz, int 
             if (col + 3 < D) v.w = m[3] ? v.w : 0.f;
         }
     } else {
-        const int64_t e = (int64_t)row * D + col;   // element index inside this arm's stream
-        v.x = xmask_keep16(nz, arm, (uint64_t)e) ? v.x : 0.f;
-        if (col + 1 < D) v.y = xmask_keep16(nz, arm, (uint64_t)e + 1) ? v.y : 0.f;
-        if (col + 2 < D) v.z = xmask_keep16(nz, arm, (uint64_t)e + 2) ? v.z : 0.f;
-        if (col + 3 < D) v.w = xmask_keep16(nz, arm, (uint64_t)e + 3) ? v.w : 0.f;
+        // col is a multiple of 4 and a Philox group holds >= 8 consecutive genes: one call serves the four
+        const uint32_t epg_log2 = 7u - nz.x_mlog2, i0 = (uint32_t)col & ((1u << epg_log2) - 1u);
+        const u32x4 w = xmask_words(nz, arm, (uint32_t)row, (uint32_t)col >> epg_log2);
+        v.x = xmask_field_keep(nz, w, i0) ? v.x : 0.f;
+        if (col + 1 < D) v.y = xmask_field_keep(nz, w, i0 + 1) ? v.y : 0.f;
+        if (col + 2 < D) v.z = xmask_field_keep(nz, w, i0 + 2) ? v.z : 0.f;
+        if (col + 3 < D) v.w = xmask_field_keep(nz, w, i0 + 3) ? v.w : 0.f;
     }
     return v;
 }

@@ -32,35 +32,63 @@ __device__ __forceinline__ float4 mask4(float4 v, uint32_t nib) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// keep-mask bit image: bits[(arm*B + row) * wpr + w] bit i <-> gene 32 w + i.  One thread per word.
-// Same element -> random-bits mapping as the general kernels and mmvae_dump_noise (xmask_keep16).
+// keep-mask bit image: bits[(arm*B + row) * wpr + w] bit i <-> gene 32 w + i (zero beyond D).  Same element ->
+// random-bits mapping as the general kernels and mmvae_dump_noise (xmask_keep).  One thread per Philox call when a
+// call covers whole words (m <= 4 bits per element: 4 / m words), else one thread per word (m / 4 calls).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_make_xbits(NoiseDev nz, int A, int B, int D, int wpr, uint32_t* __restrict__ bits) {
-    const int64_t n = (int64_t)A * B * wpr;
+    const uint32_t mlog2 = nz.x_mlog2, m = 1u << mlog2;
+    const int wpt = nz.mode != 0 && m <= 4 ? (int)(4u >> mlog2) : 1;      // words per thread
+    const int tpr = (wpr + wpt - 1) / wpt;                // threads per row
+    const int64_t n = (int64_t)A * B * tpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % wpr);
-        const int64_t ar = i / wpr;
+        const int tq = (int)(i % tpr);
+        const int64_t ar = i / tpr;
         const int row = (int)(ar % B), arm = (int)(ar / B);
-        uint32_t word = 0;
+        uint32_t* out = bits + ar * wpr;
         if (nz.mode == 0) {
-            const uint8_t* m = nz.x_mask + ((int64_t)arm * B + row) * D;
-            for (int j = 0; j < 32; ++j) {
-                const int col = 32 * w + j;
-                if (col < D && m[col]) word |= (1u << j);
+            const uint8_t* mk = nz.x_mask + ((int64_t)arm * B + row) * D;
+            for (int k = 0; k < wpt; ++k) {
+                const int w = tq * wpt + k;
+                if (w >= wpr) break;
+                uint32_t word = 0;
+                for (int j = 0; j < 32; ++j) {
+                    const int col = 32 * w + j;
+                    if (col < D && mk[col]) word |= (1u << j);
+                }
+                out[w] = word;
             }
-        } else if ((D & 7) == 0) {
-            // 32 genes = 4 Philox groups of 8 (rows start on a group boundary)
-            for (int j = 0; j < 4; ++j) {
-                const int col = 32 * w + 8 * j;
-                if (col < D) word |= xmask_keep8(nz, arm, (uint64_t)((int64_t)row * D + col) >> 3) << (8 * j);
+            continue;
+        }
+        if (m <= 4) {
+            // one call = genes [tq * 128/m, ...) = words tq * wpt .. + wpt - 1
+            const u32x4 r = xmask_words(nz, arm, (uint32_t)row, (uint32_t)tq);
+            for (int k = 0; k < wpt; ++k) {
+                const int w = tq * wpt + k;
+                if (w >= wpr) break;
+                uint32_t word = 0;
+                if (m == 1) {
+                    const uint32_t f = pick(r, k);   // gene j of the word <-> bit j
+                    word = nz.x_thr >= 2 ? 0xFFFFFFFFu : (nz.x_thr == 1 ? ~f : 0u);
+                } else {
+                    for (int j = 0; j < 32; ++j) word |= xmask_field_keep(nz, r, (uint32_t)(32 * k + j)) ? (1u << j) : 0u;
+                }
+                const int left = D - 32 * w;
+                if (left < 32) word &= (1u << left) - 1u;
+                out[w] = word;
             }
         } else {
-            for (int j = 0; j < 32; ++j) {
-                const int col = 32 * w + j;
-                if (col < D && xmask_keep16(nz, arm, (uint64_t)((int64_t)row * D + col))) word |= (1u << j);
+            // 32 genes = m / 4 calls of 128 / m genes
+            const int w = tq, ncall = (int)(m >> 2), epc = 32 / ncall;
+            uint32_t word = 0;
+            for (int j = 0; j < ncall; ++j) {
+                const u32x4 r = xmask_words(nz, arm, (uint32_t)row, (uint32_t)(w * ncall + j));
+                for (int e = 0; e < epc; ++e) word |= xmask_field_keep(nz, r, (uint32_t)e) ? (1u << (j * epc + e)) : 0u;
             }
+            const int left = D - 32 * w;
+            if (left < 32) word &= (1u << left) - 1u;
+            out[w] = word;
         }
-        bits[i] = word;
     }
 }
 
@@ -1703,7 +1731,8 @@ int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
     const mmvae_dims& d = c.d;
     NoiseDev nd = make_noise_dev(nz, c.h);
     const int wpr = cdiv(d.D, 32);
-    const int64_t n = (int64_t)d.A * d.B * wpr;
+    const int wpt = nd.mode != 0 && nd.x_mlog2 <= 2 ? (int)(4u >> nd.x_mlog2) : 1;   // as in the kernel
+    const int64_t n = (int64_t)d.A * d.B * cdiv(wpr, wpt);
     const int blocks = (int)imin64(4096, cdiv64(n, 256));
     hipLaunchKernelGGL(k_make_xbits, dim3(blocks), dim3(256), 0, c.stream, nd, d.A, d.B, d.D, wpr,
                        reinterpret_cast<uint32_t*>(c.ws + c.lay.xbits));

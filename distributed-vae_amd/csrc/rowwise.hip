@@ -37,7 +37,12 @@ NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h) {
         n.k0 = (uint32_t)nz->seed; n.k1 = (uint32_t)(nz->seed >> 32);
         n.step_lo = (uint32_t)nz->offset; n.step_hi = (uint32_t)(nz->offset >> 32);
     }
-    n.x_keep_thr = keep_threshold16(h.x_drop);
+    // smallest field width that represents the 16-bit keep threshold exactly (0 and 65536: one bit, thr 0 / 2)
+    const uint32_t t16 = keep_threshold16(h.x_drop);
+    uint32_t ml = 0;
+    while (ml < 4 && (t16 & ((65536u >> (1u << ml)) - 1u)) != 0) ++ml;
+    n.x_mlog2 = ml;
+    n.x_thr = t16 >> (16u - (1u << ml));
     n.s_keep_thr = keep_threshold(h.s_drop);
     return n;
 }
@@ -811,7 +816,8 @@ __global__ void k_dump_noise(NoiseDev nz, int A, int B, int D, int C, int S, uin
     if (x_mask)
         for (int64_t i = i0; i < nx; i += stride) {
             const int arm = (int)(i / ((int64_t)B * D));
-            x_mask[i] = xmask_keep16(nz, arm, (uint64_t)(i % ((int64_t)B * D))) ? 1 : 0;
+            const int64_t e = i % ((int64_t)B * D);
+            x_mask[i] = xmask_keep(nz, arm, (int)(e / D), (int)(e % D)) ? 1 : 0;
         }
     if (u_gumbel)
         for (int64_t i = i0; i < ng; i += stride) {

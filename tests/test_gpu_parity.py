@@ -354,6 +354,48 @@ def test_philox_replay_other_paths(D, H):
     assert torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("x_drop,bits", [(0.5, 1), (0.25, 2), (0.8125, 4), (0.98828125, 8), (0.3, 16), (0.0, 1)])
+@pytest.mark.parametrize("D,H", [(1000, 100), (50, 10)])   # bit-image fast path (D % 32 != 0) / general kernels
+def test_philox_mask_field_widths(x_drop, bits, D, H):
+    """The input-dropout mask spends 1, 2, 4, 8 or 16 random bits per element, the fewest that represent the keep
+    probability exactly (csrc/common.hpp xmask_keep).  For every width: keep fraction, no correlation between
+    neighbouring genes / cells / arms, and the Philox step is bit-identical to the explicit replay of its dump."""
+    U = _U()
+    from distributed_vae_amd import _native as N
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=9, state_dim=2, lowD_dim=4, n_arm=2, x_drop=x_drop)
+    B = 300
+    sd = R.init_state_dict(h, 4)
+    x = R.synthetic_batch(B, D).to(U.DEV)
+    res = []
+    noise = None
+    for mode in ("philox", "explicit"):
+        m = U.build_model(h, sd)
+        m.train()
+        if mode == "philox":
+            m._noise_seed, m._noise_offset = 99, 10
+        else:
+            m.set_explicit_noise(noise)
+        out = m(x.expand(2, -1, -1), 1.0, 0.0)
+        lt = m.loss(out[0], [], [], None, out[7], out[8], out[4], out[6], 0.0)
+        lt[0].backward()
+        res.append((float(lt[0]), m.flat_grad().clone()))
+        if mode == "philox":
+            noise = m._engine.dump_noise(m._hyper(1.0, False), N.make_noise(None, 99, 11))
+            k = noise["x_mask"].float()            # [A, B, D]
+            keep = 1.0 - x_drop
+            n = k[0].numel()
+            tol = 5.0 * (keep * (1 - keep) / n) ** 0.5 + 1e-12
+            assert abs(float(k.mean()) - keep) < tol, (float(k.mean()), keep)
+            if 0.0 < keep < 1.0:
+                pair_tol = 6.0 / n ** 0.5
+                assert abs(float((k[:, :, 1:] * k[:, :, :-1]).mean()) - keep * keep) < pair_tol   # neighbouring genes
+                assert abs(float((k[:, 1:] * k[:, :-1]).mean()) - keep * keep) < pair_tol         # neighbouring cells
+                assert abs(float((k[0] * k[1]).mean()) - keep * keep) < pair_tol                  # arms
+                assert abs(float(k.mean(dim=(0, 1)).std()) - (keep * (1 - keep) / (2 * B)) ** 0.5) < 0.01   # per gene
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_adam_kernel_matches_torch():
     U = _U()
     from distributed_vae_amd import _native as N
