@@ -305,10 +305,10 @@ __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ 
         const float* p = part + u * E;
         float sh[E], s1[E], s2[E];
         float n = 0.f;
-        // the group's first block mean is the shift: s2 - s1^2/n then loses nothing to cancellation
+        // the group's first block mean is the shift: s2 - s1^2/n then loses nothing to cancellation.  It is the first
+        // value of the first batch (a separate load for it would cost one more memory latency in front of the batch)
 #pragma unroll
-        for (int e = 0; e < E; ++e) { sh[e] = is_mean ? p[(int64_t)g * 2 * W + e] : 0.f; s1[e] = 0.f; s2[e] = 0.f; }
-        if (st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        for (int e = 0; e < E; ++e) { sh[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
         tick(1);
         // PART_BATCH loads in flight per pass, clamped and weighted instead of branched (a branch around
         // a load makes hipcc wait for every load separately: one memory latency per partial)
@@ -323,6 +323,10 @@ __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ 
                 } else {
                     v[j][0] = p[(int64_t)i * 2 * W];
                 }
+            }
+            if (i0 == g) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) sh[e] = is_mean ? v[0][e] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < PART_BATCH; ++j) {

@@ -101,26 +101,28 @@ __device__ __forceinline__ void lat_stage_weights(float* WcT, float* Wm, const f
     __syncthreads();
 }
 
-// grid (ceil(B/LAT_ROWS), A), 1024 threads; wave w handles rows b0 + w, b0 + w + 16, ...
+// grid (ceil(B/LAT_ROWS), A), 1024 threads; wave w handles cells b0 + w, b0 + w + 16, ... -- all LAT_NR of them side
+// by side: the per-cell work is one long dependency chain (three softmaxes = six wave reductions, the Gumbel
+// transform, four state-head dot products), and a wave that walks its cells one after the other spends most of its
+// time waiting on that chain (measured: 15 k cycles per cell with 4 waves per SIMD).
+constexpr int LAT_NR = LAT_ROWS / LAT_NW;
+static_assert(LAT_NR * LAT_NW == LAT_ROWS, "LAT_ROWS must be a multiple of the wave count");
 __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const NoiseDev nz_in,
                                                   const float* __restrict__ params, float* __restrict__ ws,
                                                   float* __restrict__ bn_running, int64_t* __restrict__ nbt) {
     const LatArgs a = a_in;      // argument blocks into registers once (see k_chain_fwd)
     const NoiseDev nz = nz_in;
     extern __shared__ __attribute__((aligned(16))) float lat_smem[];
-    __shared__ __attribute__((aligned(16))) float sh_stat[2][LAT_NW][CPL * 64];
-    __shared__ float sh_cnt[LAT_NW], sh_red[LAT_NW][2], sh_bn5[2][64];
-    float (*sh_mean)[CPL * 64] = sh_stat[0];
-    float (*sh_m2)[CPL * 64] = sh_stat[1];
+    // statistics scratch of the prologue, then the workgroup's c tile [LAT_ROWS][128] for the block statistics
+    __shared__ __attribute__((aligned(16))) float sh_buf[LAT_ROWS * CPL * 64];
+    __shared__ float sh_ps[8][CPL * 64];
+    __shared__ float sh_red[LAT_NW][2], sh_bn5[2][64];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * LAT_ROWS;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int B = a.B, L = a.L, C = a.C, S = a.S;
     const float* P = params + (int64_t)arm * a.per_arm;
     float* WcT = lat_smem;            // [L][C]
     float* Wms = lat_smem + C * L;    // [2S][L+C]
-    lat_stage_weights(WcT, Wms, P + a.o_wc, P + a.o_wms, L, C, S);
-    const float* bc = P + a.o_bc;
-    const float* bms = P + a.o_bms;   // [2S]
     const int64_t ab = (int64_t)arm * B;
     const float eps = a.eps;
 
@@ -137,12 +139,29 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
         }
     };
     if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-    float cnt = 0.f, cm[CPL] = {0.f, 0.f}, cM2[CPL] = {0.f, 0.f};
-    float kl_acc = 0.f, ent_acc = 0.f;
+
+    // this wave's cells; their fc5 outputs are requested first, so that this latency, the weight staging and the
+    // statistics partials all overlap
+    int bb[LAT_NR];
+    bool okr[LAT_NR];
+    float r5[LAT_NR];
+#pragma unroll
+    for (int r = 0; r < LAT_NR; ++r) {
+        bb[r] = b0 + wv + LAT_NW * r;
+        okr[r] = bb[r] < B;   // wave-uniform
+        r5[r] = lane < L ? ws[a.R5 + (ab + min(bb[r], B - 1)) * L + lane] : 0.f;
+    }
+    const bool vcol[CPL] = {lane < C, lane + 64 < C};
+    float bcv[CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) bcv[t] = vcol[t] ? P[a.o_bc + lane + 64 * t] : 0.f;
+    lat_stage_weights(WcT, Wms, P + a.o_wc, P + a.o_wms, L, C, S);
+    const float* bms = P + a.o_bms;   // [2S]
+
     if (a.bn_part5 >= 0) {   // training: BN5 batch statistics from fc5's per-row-block partials
         float mean, m2;
         stats_from_partials<64 * LAT_NW>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L,
-                                         &sh_stat[0][0][0], mean, m2);
+                                         sh_buf, mean, m2);
         if (threadIdx.x < L) {
             const int t = threadIdx.x;
             const float rstd = 1.0f / sqrtf(m2 / (float)B + eps);
@@ -164,131 +183,173 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
     }
     const float mu5 = lane < L ? (a.bn_part5 >= 0 ? sh_bn5[0][lane] : ws[a.mean5 + arm * L + lane]) : 0.f;
     const float rs5 = lane < L ? (a.bn_part5 >= 0 ? sh_bn5[1][lane] : ws[a.rstd5 + arm * L + lane]) : 0.f;
-
     stamp(0);   // weight staging + statistics loads
-    for (int row = wv; row < LAT_ROWS; row += LAT_NW) {
-        const int b = b0 + row;
-        if (b >= B) break;   // wave-uniform
-        // ---- x_low = BN5(R5)
-        float xl = 0.f;
-        if (lane < L) {
-            xl = (ws[a.R5 + (ab + b) * L + lane] - mu5) * rs5;
-            ws[a.XLOW + (ab + b) * L + lane] = xl;
-            ws[a.Y + (ab + b) * (L + C) + lane] = xl;
+
+    // ---- x_low = BN5(R5)
+    float xl[LAT_NR];
+#pragma unroll
+    for (int r = 0; r < LAT_NR; ++r) {
+        xl[r] = lane < L ? (r5[r] - mu5) * rs5 : 0.f;
+        if (okr[r] && lane < L) {
+            ws[a.XLOW + (ab + bb[r]) * L + lane] = xl[r];
+            ws[a.Y + (ab + bb[r]) * (L + C) + lane] = xl[r];
         }
-        // ---- zc = fcc(x_low); c_prob = softmax(zc)
-        float z[CPL];
+    }
+    // ---- zc = fcc(x_low); c_prob = softmax(zc)
+    float z[LAT_NR][CPL];
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; z[t] = col < C ? bc[col] : 0.f; }
-        for (int k = 0; k < L; ++k) {
-            const float xk = __shfl(xl, k, 64);
+    for (int r = 0; r < LAT_NR; ++r)
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) z[t] += xk * WcT[k * C + col]; }
+        for (int t = 0; t < CPL; ++t) z[r][t] = bcv[t];
+    for (int k = 0; k < L; ++k) {
+        float w[CPL];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) w[t] = vcol[t] ? WcT[k * C + lane + 64 * t] : 0.f;
+#pragma unroll
+        for (int r = 0; r < LAT_NR; ++r) {
+            const float xk = __shfl(xl[r], k, 64);
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) z[r][t] += xk * w[t];
         }
-        float m = -INFINITY;
+    }
+    float m[LAT_NR], ssum[LAT_NR], e[LAT_NR][CPL];
+    float cp[LAT_NR][CPL], cc[LAT_NR][CPL], lc[LAT_NR][CPL], ys[LAT_NR][CPL], cs[LAT_NR][CPL];
+    // softmax over the valid columns of v (in place in e, sum in ssum)
+    auto softmax_rows = [&](float (&v)[LAT_NR][CPL], float (&out)[LAT_NR][CPL]) {
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) m = fmaxf(m, z[t]);
-        m = wave_max(m);
-        float e[CPL], ssum = 0.f;
+        for (int r = 0; r < LAT_NR; ++r) {
+            m[r] = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) { e[t] = (lane + 64 * t < C) ? expf(z[t] - m) : 0.f; ssum += e[t]; }
-        ssum = wave_sum(ssum);
-        float cp[CPL], cc[CPL], lc[CPL], ys[CPL], cs[CPL];
+            for (int t = 0; t < CPL; ++t) if (vcol[t]) m[r] = fmaxf(m[r], v[r][t]);
+        }
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) cp[t] = e[t] / ssum;
-        stamp(1);   // x_low, fcc, first softmax
-        // ---- c = softmax(c_prob / tau)
-        m = -INFINITY;
+        for (int r = 0; r < LAT_NR; ++r) m[r] = wave_max(m[r]);
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) m = fmaxf(m, cp[t] / a.tau);
-        m = wave_max(m);
-        ssum = 0.f;
+        for (int r = 0; r < LAT_NR; ++r) {
+            ssum[r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) { e[t] = (lane + 64 * t < C) ? expf(cp[t] / a.tau - m) : 0.f; ssum += e[t]; }
-        ssum = wave_sum(ssum);
+            for (int t = 0; t < CPL; ++t) { e[r][t] = vcol[t] ? expf(v[r][t] - m[r]) : 0.f; ssum[r] += e[r][t]; }
+        }
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) { cc[t] = e[t] / ssum; lc[t] = logf(cc[t] + eps); }
-        // ---- Gumbel-softmax sample
-        bool hard = a.hard != 0;
-        if (a.eval_flag) {
-            hard = true;
+        for (int r = 0; r < LAT_NR; ++r) ssum[r] = wave_sum(ssum[r]);
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) ys[t] = cc[t];
-        } else {
-            float lg[CPL];
-            m = -INFINITY;
+        for (int r = 0; r < LAT_NR; ++r) {
+            const float inv = 1.f / ssum[r];   // one division per cell, not per element: the kernel is VALU-bound
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) out[r][t] = e[r][t] * inv;
+        }
+    };
+    softmax_rows(z, cp);
+    stamp(1);   // x_low, fcc, first softmax
+    // ---- c = softmax(c_prob / tau)
+    const float inv_tau = 1.f / a.tau, inv_temp = 1.f / a.temp;
+    float tmp[LAT_NR][CPL];
+#pragma unroll
+    for (int r = 0; r < LAT_NR; ++r)
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) tmp[r][t] = cp[r][t] * inv_tau;
+    softmax_rows(tmp, cc);
+#pragma unroll
+    for (int r = 0; r < LAT_NR; ++r)
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) lc[r][t] = logf(cc[r][t] + eps);
+    // ---- Gumbel-softmax sample
+    bool hard = a.hard != 0;
+    if (a.eval_flag) {
+        hard = true;
+#pragma unroll
+        for (int r = 0; r < LAT_NR; ++r)
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) ys[r][t] = cc[r][t];
+    } else {
+#pragma unroll
+        for (int r = 0; r < LAT_NR; ++r)
 #pragma unroll
             for (int t = 0; t < CPL; ++t) {
-                const int col = lane + 64 * t;
-                lg[t] = 0.f;
-                if (col < C) {
-                    const float U = gumbel_u(nz, arm, B, C, b, col);
+                tmp[r][t] = 0.f;
+                if (vcol[t]) {
+                    const float U = gumbel_u(nz, arm, B, C, min(bb[r], B - 1), lane + 64 * t);
                     const float g = -logf(-logf(U + eps) + eps);
-                    lg[t] = (lc[t] + g) / a.temp;
-                    m = fmaxf(m, lg[t]);
+                    tmp[r][t] = (lc[r][t] + g) * inv_temp;
                 }
             }
-            m = wave_max(m);
-            ssum = 0.f;
+        softmax_rows(tmp, ys);
+    }
+    if (hard) {
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { e[t] = (lane + 64 * t < C) ? expf(lg[t] - m) : 0.f; ssum += e[t]; }
-            ssum = wave_sum(ssum);
-#pragma unroll
-            for (int t = 0; t < CPL; ++t) ys[t] = e[t] / ssum;
-        }
-        if (hard) {
+        for (int r = 0; r < LAT_NR; ++r) {
             float mv = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C) mv = fmaxf(mv, ys[t]);
+            for (int t = 0; t < CPL; ++t) if (vcol[t]) mv = fmaxf(mv, ys[r][t]);
             mv = wave_max(mv);
             int cand = 1 << 30;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) if (lane + 64 * t < C && ys[t] == mv) cand = min(cand, lane + 64 * t);
+            for (int t = 0; t < CPL; ++t) if (vcol[t] && ys[r][t] == mv) cand = min(cand, lane + 64 * t);
             cand = wave_min_i(cand);
 #pragma unroll
             for (int t = 0; t < CPL; ++t) {
                 const float hv = (lane + 64 * t == cand) ? 1.f : 0.f;
-                cs[t] = (hv - ys[t]) + ys[t];   // (y_hard - y).detach() + y, nn_model.py:492
+                cs[r][t] = (hv - ys[r][t]) + ys[r][t];   // (y_hard - y).detach() + y, nn_model.py:492
             }
-        } else {
-#pragma unroll
-            for (int t = 0; t < CPL; ++t) cs[t] = ys[t];
         }
-        stamp(2);   // second softmax, Gumbel sample (noise)
-        // ---- store, accumulate statistics
-        cnt += 1.f;
+    } else {
+#pragma unroll
+        for (int r = 0; r < LAT_NR; ++r)
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) cs[r][t] = ys[r][t];
+    }
+    stamp(2);   // second softmax, Gumbel sample (noise)
+    // ---- store; c goes to the workgroup tile for the block statistics (zero rows beyond the batch)
+    float kl_acc = 0.f, ent_acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < LAT_NR; ++r) {
 #pragma unroll
         for (int t = 0; t < CPL; ++t) {
             const int col = lane + 64 * t;
-            if (col < C) {
-                const int64_t o = (ab + b) * C + col;
-                ws[a.CPROB + o] = cp[t];
-                ws[a.CC + o] = cc[t];
-                ws[a.YSOFT + o] = ys[t];
-                ws[a.CSMP + o] = cs[t];
-                ws[a.Y + (ab + b) * (L + C) + L + col] = cs[t];
-                ws[a.ZIN + (ab + b) * (C + S) + col] = cs[t];
-                ent_acc += cc[t] * lc[t];
-                const float dl = cc[t] - cm[t];
-                cm[t] += dl / cnt;
-                cM2[t] += dl * (cc[t] - cm[t]);
+            sh_buf[(wv + LAT_NW * r) * (CPL * 64) + col] = (okr[r] && vcol[t]) ? cc[r][t] : 0.f;
+            if (okr[r] && vcol[t]) {
+                const int64_t o = (ab + bb[r]) * C + col;
+                ws[a.CPROB + o] = cp[r][t];
+                ws[a.CC + o] = cc[r][t];
+                ws[a.YSOFT + o] = ys[r][t];
+                ws[a.CSMP + o] = cs[r][t];
+                ws[a.Y + (ab + bb[r]) * (L + C) + L + col] = cs[r][t];
+                ws[a.ZIN + (ab + bb[r]) * (C + S) + col] = cs[r][t];
+                ent_acc += cc[r][t] * lc[r][t];
             }
         }
-        stamp(3);   // stores + statistics
-        // ---- state head: [mu | sigma_pre] = y [Wmu; Wsigma]^T + b
-        float mso = 0.f;
-        for (int o = 0; o < 2 * S; ++o) {
-            const float* w = Wms + (int64_t)o * (L + C);
-            float p = lane < L ? xl * w[lane] : 0.f;
+    }
+    stamp(3);   // stores
+    // ---- state head: [mu | sigma_pre] = y [Wmu; Wsigma]^T + b
+    float mso[LAT_NR];
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) p += cs[t] * w[L + col]; }
-            p = wave_sum(p) + bms[o];
-            if (lane == o) mso = p;
+    for (int r = 0; r < LAT_NR; ++r) mso[r] = 0.f;
+    for (int o = 0; o < 2 * S; ++o) {
+        const float* w = Wms + (int64_t)o * (L + C);
+        const float wl = lane < L ? w[lane] : 0.f;
+        float wc[CPL], pr[LAT_NR];
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) wc[t] = vcol[t] ? w[L + lane + 64 * t] : 0.f;
+#pragma unroll
+        for (int r = 0; r < LAT_NR; ++r) {
+            pr[r] = xl[r] * wl;
+#pragma unroll
+            for (int t = 0; t < CPL; ++t) pr[r] += cs[r][t] * wc[t];
         }
-        if (lane < 2 * S) ws[a.MS + (ab + b) * 2 * S + lane] = mso;
-        const float sg = __shfl(mso, (lane + S) & 63, 64);
-        if (lane < S) {
-            const float mu = mso;
+        const float bo = bms[o];
+#pragma unroll
+        for (int r = 0; r < LAT_NR; ++r) {
+            const float pv = wave_sum(pr[r]) + bo;
+            if (lane == o) mso[r] = pv;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < LAT_NR; ++r) {
+        if (okr[r] && lane < 2 * S) ws[a.MS + (ab + bb[r]) * 2 * S + lane] = mso[r];
+        const float sg = __shfl(mso[r], (lane + S) & 63, 64);
+        if (okr[r] && lane < S) {
+            const int b = bb[r];
+            const float mu = mso[r];
             const float var = 1.f / (1.f + expf(-sg));
             const float lv = logf(var + eps);
             const float sd = sqrtf(expf(lv));
@@ -302,34 +363,45 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
             ws[a.ZIN + (ab + b) * (C + S) + C + lane] = sin_;
             kl_acc += 1.f + lv - mu * mu - expf(lv);
         }
-        stamp(4);   // state head
     }
-    // ---- block partials
+    stamp(4);   // state head
+    // ---- block partials: mean and M2 of c over the workgroup's cells, two passes over the LDS tile, 8 row groups
     kl_acc = wave_sum(kl_acc);
     ent_acc = wave_sum(ent_acc);
-#pragma unroll
-    for (int t = 0; t < CPL; ++t) { sh_mean[wv][lane + 64 * t] = cm[t]; sh_m2[wv][lane + 64 * t] = cM2[t]; }
-    if (lane == 0) { sh_cnt[wv] = cnt; sh_red[wv][0] = kl_acc; sh_red[wv][1] = ent_acc; }
+    if (lane == 0) { sh_red[wv][0] = kl_acc; sh_red[wv][1] = ent_acc; }
     lds_barrier();
-    const int col = threadIdx.x;
-    if (col < C) {
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int w = 0; w < LAT_NW; ++w) {
-            const float nb = sh_cnt[w];
-            if (nb > 0.f) {
-                const float nn = n + nb, dl = sh_mean[w][col] - mean;
-                mean += dl * (nb / nn);
-                m2 += sh_m2[w][col] + dl * dl * (n * nb / nn);
-                n = nn;
-            }
+    {
+        const int col = threadIdx.x & (CPL * 64 - 1), g = threadIdx.x >> 7;   // 1024 threads = 8 groups x 128 columns
+        const int nv = min(LAT_ROWS, B - b0);
+        float v[LAT_ROWS / 8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LAT_ROWS / 8; ++i) { v[i] = sh_buf[(g + 8 * i) * (CPL * 64) + col]; s1 += v[i]; }   // rows beyond nv are 0
+        sh_ps[g][col] = s1;
+        lds_barrier();
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += sh_ps[k][col];
+        const float mean = tot / (float)nv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LAT_ROWS / 8; ++i) { const float d = v[i] - mean; q += (g + 8 * i < nv) ? d * d : 0.f; }
+        lds_barrier();   // every thread has read sh_ps
+        sh_ps[g][col] = q;
+        lds_barrier();
+        if (g == 0 && col < C) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m2 += sh_ps[k][col];
+            float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
+            p[col] = mean;
+            p[C + col] = m2;
         }
-        float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
-        p[col] = mean;
-        p[C + col] = m2;
     }
     if (threadIdx.x == 0) {
         float* p = ws + a.lat_part + ((int64_t)arm * gridDim.x + blk) * 2;
         float k0 = 0.f, k1 = 0.f;
+#pragma unroll
         for (int w = 0; w < LAT_NW; ++w) { k0 += sh_red[w][0]; k1 += sh_red[w][1]; }
         p[0] = k0;
         p[1] = k1;
