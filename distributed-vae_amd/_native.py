@@ -99,8 +99,13 @@ def lib():
     L.mmvae_debug_stage.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), i32, vp, vp, i64, vp,
                                     C.c_size_t, vp, vp]
     L.mmvae_dump_noise.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, vp]
+    L.mmvae_eval_classify.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp]
+    L.mmvae_classify.argtypes = [vp, i64, i32, vp, vp]
+    L.mmvae_confmat_accumulate.argtypes = [vp, i32, i64, i32, vp, vp]
+    L.mmvae_consensus.argtypes = [vp, i32, i32, vp, vp, vp]
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_set_split", "mmvae_forward", "mmvae_loss",
-               "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage"):
+               "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",
+               "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus"):
         getattr(L, fn).restype = C.c_int
     if L.mmvae_abi_version() != 1:
         raise NativeError("libmmvae_hip.so ABI version mismatch")
@@ -210,6 +215,13 @@ class Engine:
               "mmvae_train_step")
         return self.loss_buf
 
+    def eval_classify(self, hyper: Hyper, params, bn_running, x, x_arm_stride, labels, counts=None):
+        """Encoder + latent block in eval mode, labels[a, b] = argmax c; counts (int64 [pairs, C, C]) accumulate."""
+        check(lib().mmvae_eval_classify(C.byref(self.dims), C.byref(hyper), _ptr(params), _ptr(bn_running), _ptr(x),
+                                        x_arm_stride, _ptr(self.ws), self.ws_bytes, _ptr(labels), _ptr(counts),
+                                        _stream()), "mmvae_eval_classify")
+        return labels
+
     def debug_stage(self, stage: int, hyper: Hyper, noise: Noise, params, x, x_arm_stride, grads=None):
         check(lib().mmvae_debug_stage(C.byref(self.dims), C.byref(hyper), C.byref(noise), int(stage), _ptr(params),
                                       _ptr(x), x_arm_stride, _ptr(self.ws), self.ws_bytes, _ptr(grads), _stream()),
@@ -229,3 +241,38 @@ class Engine:
 def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, decoupled=False):
     check(lib().mmvae_adam_step(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), int(step),
                                 lr, b1, b2, eps, wd, int(decoupled), _stream()), "mmvae_adam_step")
+
+
+def classify(probs: torch.Tensor) -> torch.Tensor:
+    """argmax over the last axis of a float32 CUDA tensor -> int32 labels (first maximum on ties)."""
+    if probs.device.type != "cuda":
+        raise NativeError("classify needs a CUDA tensor (no CPU fallback)")
+    p = probs.contiguous().float()
+    n, Cc = p.numel() // p.shape[-1], p.shape[-1]
+    out = torch.empty(p.shape[:-1], dtype=torch.int32, device=p.device)
+    check(lib().mmvae_classify(_ptr(p), n, Cc, _ptr(out), _stream()), "mmvae_classify")
+    return out
+
+
+def confmat_accumulate(labels: torch.Tensor, Cc: int, counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """labels int32 [A, n] on the GPU -> counts int64 [A(A-1)/2, C, C] (+= when given)."""
+    if labels.device.type != "cuda":
+        raise NativeError("confmat_accumulate needs CUDA tensors (no CPU fallback)")
+    lab = labels.contiguous().to(torch.int32)
+    A, n = lab.shape
+    if counts is None:
+        counts = torch.zeros(max(A * (A - 1) // 2, 1), Cc, Cc, dtype=torch.int64, device=lab.device)
+    check(lib().mmvae_confmat_accumulate(_ptr(lab), A, n, Cc, _ptr(counts), _stream()), "mmvae_confmat_accumulate")
+    return counts
+
+
+def consensus(counts: torch.Tensor, want_norm: bool = False):
+    """counts int64 [pairs, C, C] -> consensus float64 [pairs] (and the normalised matrices when want_norm)."""
+    if counts.device.type != "cuda":
+        raise NativeError("consensus needs CUDA tensors (no CPU fallback)")
+    cnt = counts.contiguous()
+    P, Cc, _ = cnt.shape
+    out = torch.empty(P, dtype=torch.float64, device=cnt.device)
+    norm = torch.empty(P, Cc, Cc, dtype=torch.float64, device=cnt.device) if want_norm else None
+    check(lib().mmvae_consensus(_ptr(cnt), P, Cc, _ptr(norm), _ptr(out), _stream()), "mmvae_consensus")
+    return (out, norm) if want_norm else out

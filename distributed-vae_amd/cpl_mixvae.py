@@ -192,7 +192,7 @@ class cpl_mixVAE:
         if D.is_dist():
             D.broadcast_flat(self.model.flat_parameters())
         hist = {"losses": [], "loss_joints": [], "loss_recs": [[] for _ in range(A)], "c_ents": [], "c_l2_dists": [],
-                "c_dists": [], "validation_loss": [], "epoch_times": []}
+                "c_dists": [], "validation_loss": [], "consensus_train": [], "epoch_times": []}
         self.current_time = time.strftime("%Y-%m-%d-%H-%M-%S")
         for e in range(n_epoch):
             t0 = time.time()
@@ -216,6 +216,9 @@ class cpl_mixVAE:
             hist["c_dists"].append(red[N.LOSS_CDIST] / nsteps)
             for a in range(A):
                 hist["loss_recs"][a].append(red[N.LOSS_REC0 + a] / Dm / nsteps)   # :475, :491
+            # consensus between the arms on the training set (cpl_mixvae.py:563-657), on the device
+            cons = self.consensus(train_loader)
+            hist["consensus_train"].append(cons)
             # validation loss (cpl_mixvae.py:665-775): eval mode, no Gumbel noise, hard sample
             val = self.validate(test_loader) if test_loader is not None else float("nan")
             hist["validation_loss"].append(val)
@@ -229,7 +232,7 @@ class cpl_mixVAE:
                 run.log({"train/total-loss": hist["losses"][-1], "train/joint-loss": hist["loss_joints"][-1],
                          "train/negative-joint-entropy": hist["c_ents"][-1],
                          "train/simplex-distance": hist["c_dists"][-1], "train/l2-distance": hist["c_l2_dists"][-1],
-                         "train/time": dt, "validation/rec-loss": val})
+                         "train/time": dt, "train/consensus": cons, "validation/rec-loss": val})
             if self.save and self.folder and (e > 0) and (e % 10 == 0):    # :777-788
                 os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
                 self.save_checkpoint(os.path.join(self.folder, "model", f"cpl_mixVAE_model_epoch_{e}.pth"))
@@ -238,6 +241,31 @@ class cpl_mixVAE:
             self.save_checkpoint(os.path.join(self.folder, "model",
                                               f"cpl_mixVAE_model_before_pruning_A{A}_{self.current_time}.pth"))
         return hist
+
+    @torch.no_grad()
+    def consensus(self, loader) -> float:
+        """Mean over arm pairs of ``confmat_mean(confmat_normalize(compute_confmat(labels_a, labels_b, C)))`` with
+        ``labels = classify(c)`` of the eval-mode forward over the whole loader (cpl_mixvae.py:563-657).  Labels,
+        counts and the normalisation stay on the device: one host read of A(A-1)/2 doubles per epoch.  Under data
+        parallelism every rank counts its own shard and the integer counts are summed (the reference, never run
+        distributed, would report rank-local values)."""
+        from ._utils import confmat_counts, consensus_from_counts
+        was_training = self.model.training
+        self.model.eval()
+        counts = confmat_counts(self.n_arm, self.n_categories, self.device)
+        seen = 0
+        for batch in loader:
+            x = (batch[0] if isinstance(batch, (tuple, list)) else batch).to(self.device)
+            if x.shape[0] < 1:
+                continue
+            self.model.eval_labels(x.expand(self.n_arm, -1, -1), self.temp, counts)
+            seen += x.shape[0]
+        if D.is_dist():
+            D.allreduce_sum_(counts)
+        self.model.train(was_training)
+        if seen == 0:
+            return float("nan")
+        return float(np.mean(consensus_from_counts(counts).cpu().numpy()))   # np.mean(np.array(consensus)), :654
 
     @torch.no_grad()
     def validate(self, loader) -> float:

@@ -187,7 +187,7 @@ static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_la
 // caller that the loss is on its way (event g_ev_couple) and do_loss must not launch anything.
 static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
                       const float* x, int64_t xs, float* x_rec, int need_grad, bool* couple_done = nullptr,
-                      float* loss_out = nullptr) {
+                      float* loss_out = nullptr, bool latent_only = false) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
     if (fast) {
@@ -204,6 +204,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     for (int layer = 2; layer <= 5; ++layer)
         if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt))) return rc;
+    if (latent_only) return 0;   // evaluation labels need c only: no decoder, no fc11
     if (couple_done && g_side) {
         if (!g_ev_lat && (hipEventCreateWithFlags(&g_ev_lat, hipEventDisableTiming) != hipSuccess ||
                           hipEventCreateWithFlags(&g_ev_couple, hipEventDisableTiming) != hipSuccess)) {
@@ -439,6 +440,45 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
         return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, &ah, loss_on_side);
     }
     return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, nullptr, loss_on_side);
+}
+
+int mmvae_eval_classify(const mmvae_dims* d, const mmvae_hyper* h, const float* params, const float* bn_running,
+                        const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes, int32_t* labels,
+                        int64_t* counts, void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (!params || !x || !bn_running || !labels) { set_error("null params / x / bn_running / labels"); return MMVAE_E_BADARG; }
+    if (h->training || !h->eval_flag) { set_error("eval_classify needs training = 0 and eval_flag = 1"); return MMVAE_E_UNSUPPORTED; }
+    int rc;
+    // eval mode reads the running statistics (nothing is written to bn_running) and draws no Gumbel noise; the state
+    // sample the latent kernel also produces does not enter c: it takes the Philox stream of seed 0
+    mmvae_noise nzp{};
+    nzp.mode = 1;
+    if ((rc = do_forward(c, &nzp, params, const_cast<float*>(bn_running), nullptr, x, x_arm_stride, nullptr, 0, nullptr,
+                         nullptr, true)))
+        return rc;
+    if ((rc = launch_classify(c.ws + c.lay.CC, (int64_t)d->A * d->B, d->C, labels, c.stream))) return rc;
+    if (counts) return launch_confmat(labels, d->A, d->B, d->C, counts, c.stream);
+    return 0;
+}
+
+int mmvae_classify(const float* c_probs, int64_t n_cells, int C, int32_t* labels, void* stream) {
+    if (!c_probs || !labels || n_cells <= 0 || C <= 0) { set_error("classify: bad argument"); return MMVAE_E_BADARG; }
+    return launch_classify(c_probs, n_cells, C, labels, reinterpret_cast<hipStream_t>(stream));
+}
+
+int mmvae_confmat_accumulate(const int32_t* labels, int A, int64_t n, int C, int64_t* counts, void* stream) {
+    if (!labels || !counts || A < 1 || A > MMVAE_MAX_ARMS || n <= 0 || C <= 0) {
+        set_error("confmat_accumulate: bad argument");
+        return MMVAE_E_BADARG;
+    }
+    return launch_confmat(labels, A, n, C, counts, reinterpret_cast<hipStream_t>(stream));
+}
+
+int mmvae_consensus(const int64_t* counts, int npairs, int C, double* cm_norm, double* consensus, void* stream) {
+    if (!counts || !consensus || npairs < 1 || C < 1) { set_error("consensus: bad argument"); return MMVAE_E_BADARG; }
+    if (C > 128) { set_error("consensus: C > 128 unsupported"); return MMVAE_E_UNSUPPORTED; }
+    return launch_consensus(counts, npairs, C, cm_norm, consensus, reinterpret_cast<hipStream_t>(stream));
 }
 
 int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, int stage,

@@ -561,6 +561,10 @@ int launch_fc1_epi(const Ctx& c, const float* params);
 int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad,
                      int which = 3);
 int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit0 dW1, bit1 dW11*/);
+// evaluation labels / consensus (consensus.hip)
+int launch_classify(const float* cc, int64_t n_cells, int C, int32_t* labels, hipStream_t s);
+int launch_confmat(const int32_t* labels, int A, int64_t n, int C, int64_t* counts, hipStream_t s);
+int launch_consensus(const int64_t* counts, int npairs, int C, double* cm_norm, double* consensus, hipStream_t s);
 int launch_dump_noise(const mmvae_dims& d, const mmvae_hyper& h, const mmvae_noise* nz, uint8_t* x_mask,
                       float* u_gumbel, float* u_state, uint8_t* s_mask, hipStream_t s);
 

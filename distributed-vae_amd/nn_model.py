@@ -297,6 +297,25 @@ class mixVAE_model(nn.Module):
         return (total, rec.clone(), vals[N.LOSS_JOINT], vals[N.LOSS_CENT], vals[N.LOSS_CDIST], vals[N.LOSS_CL2],
                 list(kl.unbind(0)), [], list(ll.unbind(0)))
 
+    # ------------------------------------------------------------------ evaluation labels (consensus path)
+    @torch.no_grad()
+    def eval_labels(self, x, temp=1.0, counts=None) -> torch.Tensor:
+        """``classify(cs[a])`` of ``self(x, temp, eval=True)`` for every arm without leaving the device
+        (cpl_mixvae.py:596-611): int32 [n_arm, batch].  Runs the encoder and the latent block only (BatchNorm running
+        statistics, no Gumbel noise); ``counts`` (int64 [pairs, C, C], see ``_utils.confmat_counts``) also receives
+        this batch's between-arm confusion counts.  The module must be in eval mode, as in the reference's loop."""
+        if self.training:
+            raise RuntimeError("eval_labels() needs model.eval(): the reference classifies in eval mode "
+                               "(cpl_mixvae.py:563)")
+        xt, xs = self._prep_x(x)
+        if xt.device.type != "cuda":
+            raise N.NativeError("mixVAE_model.eval_labels needs GPU tensors: the model runs only on the HIP engine")
+        eng = self._ensure(xt.shape[-2])
+        labels = torch.empty(self.n_arm, xt.shape[-2], dtype=torch.int32, device=xt.device)
+        eng.eval_classify(self._hyper(temp, True), self._flat, self._bn_flat, xt, xs, labels, counts)
+        self._ctx = None
+        return labels
+
     # ------------------------------------------------------------------ fused step (trainer path)
     def fused_train_step(self, x, temp, opt=None, do_adam=True):
         """forward + loss + backward (+ Adam) in one C-ABI call: cpl_mixvae.py:434-463.

@@ -12,6 +12,8 @@
  *   mmvae_backward     _loss.backward()              mmidas/cpl_mixvae.py:462 (autograd of the above)
  *   mmvae_adam_step    optimizer.step()              mmidas/cpl_mixvae.py:274,:463; train.py:144-147
  *   mmvae_train_step   the per-batch driver          mmidas/cpl_mixvae.py:434-463
+ *   mmvae_eval_classify / mmvae_confmat_accumulate / mmvae_consensus
+ *                      the per-epoch consensus loop  mmidas/cpl_mixvae.py:563-657, _utils.py:79-129
  *
  * Conventions
  *   - plain pointers and sizes only; every buffer is caller-owned DEVICE memory (fp32 unless
@@ -186,6 +188,31 @@ int mmvae_train_step(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
                      float *grads, float *loss_out, int do_adam, float *exp_avg,
                      float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2,
                      float adam_eps, float weight_decay, int decoupled, void *stream);
+
+/* ---- evaluation labels and between-arm consensus ----------------
+ * Replaces the per-epoch host loop of mmidas/cpl_mixvae.py:563-657: eval-mode forward of every batch,
+ * `classify` = argmax of c (mmidas/_utils.py:79-80), `compute_confmat` per arm pair (:84-95),
+ * `confmat_normalize` (:98-100), `confmat_mean` (:128-129).
+ *
+ * mmvae_eval_classify: encoder + latent block of forward(eval=True) with the BatchNorm running statistics
+ *   (h->training == 0, h->eval_flag == 1; no decoder, no fc11: the labels need c only), then
+ *   labels[a*B + b] = argmax_k c[a][b][k] (first maximum on ties, as np.argmax).  labels: int32 [A,B].
+ *   counts != NULL: additionally counts[pair][labels[a][b]][labels[a'][b]] += 1 for every arm pair a < a'
+ *   in the order (0,1), (0,2) ... (A-2,A-1); counts: int64 [A(A-1)/2, C, C], zeroed by the caller before
+ *   the first batch of an epoch.
+ * mmvae_classify: the argmax alone on any [n_cells, C] fp32 matrix.
+ * mmvae_confmat_accumulate: the counting alone, labels int32 [A, n].
+ * mmvae_consensus: cm_norm[pair][i][j] = counts[pair][i][j] / max(rowsum_j, colsum_j) (0 where that is 0),
+ *   consensus[pair] = mean_k cm_norm[pair][k][k]; fp64, numpy's summation order, C <= 128.
+ *   cm_norm (double [npairs, C, C]) may be NULL; consensus: double [npairs]. */
+int mmvae_eval_classify(const mmvae_dims *d, const mmvae_hyper *h, const float *params,
+                        const float *bn_running, const float *x, int64_t x_arm_stride, void *ws,
+                        size_t ws_bytes, int32_t *labels, int64_t *counts, void *stream);
+int mmvae_classify(const float *c_probs, int64_t n_cells, int C, int32_t *labels, void *stream);
+int mmvae_confmat_accumulate(const int32_t *labels, int A, int64_t n, int C, int64_t *counts,
+                             void *stream);
+int mmvae_consensus(const int64_t *counts, int npairs, int C, double *cm_norm, double *consensus,
+                    void *stream);
 
 /* Writes the noise the Philox mode (nz->mode == 1) would use, in explicit-buffer form, so a test
  * can replay a Philox step through mode 0.  Any output pointer may be NULL. */

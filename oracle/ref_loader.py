@@ -148,3 +148,23 @@ def reference_step(model, xs, temp, noise=None, eval_flag=False):
     x_recs, _, _, x_lows, cs, s_smps, c_smps, s_means, s_logvars, c_probs = out
     loss_out = model.loss(x_recs, [], [], xs, s_means, s_logvars, cs, c_smps, 0.0)
     return out, loss_out, rec
+
+
+_UTILS = os.path.join(REFERENCE_ROOT, "mmidas", "_utils.py")
+_CONSENSUS_FUNCS = ("classify", "compute_confmat", "confmat_normalize", "compute_confmat_naive",
+                    "confmat_normalize_naive", "confmat_mean")
+
+
+def load_reference_consensus_utils() -> types.SimpleNamespace:
+    """The reference's own ``classify`` / ``compute_confmat`` / ``confmat_normalize`` / ``confmat_mean``
+    (mmidas/_utils.py:79-129), compiled in memory from the reference file where it lies.  Only these function
+    definitions are taken (the module's top level imports packages this image lacks); nothing is copied into the repo."""
+    import ast
+    import numpy as np
+    with open(_UTILS, "r") as fh:
+        tree = ast.parse(fh.read(), filename=_UTILS)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in _CONSENSUS_FUNCS]
+    mod = ast.Module(body=keep, type_ignores=[])
+    ns: Dict[str, Any] = {"np": np}
+    exec(compile(mod, _UTILS, "exec"), ns)
+    return types.SimpleNamespace(**{k: ns[k] for k in _CONSENSUS_FUNCS})
