@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (before HIP init)
@@ -105,6 +107,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,10 +210,64 @@ def main():
         out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, D, H, L, C, S, A, B)
+    if rank == 0 and world == 1 and not args.no_eval:
+        out["eval_consensus"] = eval_consensus(args, model, batches, A, B, D, H, L, C, S, not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def eval_consensus(args, model, batches, A, B, D, H, L, C, S, with_cpu):
+    """Scope row (f)-1 beside the headline metric: one pass of the per-epoch consensus loop (cpl_mixvae.py:563-657)
+    over the resident cells -- eval-mode encoder + latent block, argmax labels, per-pair confusion counts -- then the
+    normalisation and mean; HIP events on torch's current stream (the one the C ABI is called on)."""
+    from distributed_vae_amd._utils import confmat_counts, consensus_from_counts
+    model.eval()
+    counts = confmat_counts(A, C, batches[0].device)
+    for b in batches[:2]:
+        model.eval_labels(b.expand(A, -1, -1), 1.0, counts)
+    counts.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        counts.zero_()
+        for b in batches:
+            model.eval_labels(b.expand(A, -1, -1), 1.0, counts)
+        cons = consensus_from_counts(counts)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    n = len(batches) * B
+    model.train()
+    out = {"value": n / ms * 1e3, "unit": "cells/s", "ms_per_pass": ms, "cells": n, "batch": B,
+           "consensus": float(cons.mean()),
+           "workload": "eval forward (encoder + latent block) + argmax labels + confusion counts per batch, "
+                       "normalise + mean once per pass",
+           "flop_per_cell": A * 2.0 * (D * H + 3 * H * H + H * L + L * C)}
+    out["frac_of_fp32_mfma_peak"] = out["value"] * out["flop_per_cell"] / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+    if with_cpu:
+        # the oracle's eval forward + numpy consensus on ONE batch (bounded), same host threads as cpu_baseline
+        from oracle import consensus as OC
+        from oracle import restatement as R
+        h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, n_arm=A)
+        sd = R.init_state_dict(h, 546)
+        x = R.synthetic_batch(B, D)
+        noise = R.draw_noise(h, B, seed=1)
+        ts = []
+        for _ in range(3):
+            t0 = time.time()
+            with torch.no_grad():
+                o = R.forward(sd, [x] * A, h, noise, training=False, eval_flag=True, update_running=False)
+            lab = np.stack([OC.classify(c.numpy()) for c in o[4]]).astype(np.int64)
+            OC.epoch_consensus(lab, C)
+            ts.append(time.time() - t0)
+        ts.sort()
+        out["cpu_baseline"] = {"value": B / ts[1], "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "3 batches of the same shape through the oracle's full eval forward (as the "
+                                         "reference does) + numpy consensus, median"}
+    return out
 
 
 STAGES = {
