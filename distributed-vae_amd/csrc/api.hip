@@ -179,7 +179,7 @@ static int check_noise(const Ctx& c, const mmvae_noise* nz) {
 
 static thread_local hipStream_t g_side = nullptr;
 static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_lat = nullptr, g_ev_couple = nullptr,
-                               g_ev_fc11 = nullptr;
+                               g_ev_fc11 = nullptr, g_ev_dec = nullptr, g_ev_enc = nullptr;
 
 // Train step with a side stream (couple_done != null): the coupling kernel needs only the latent block's outputs
 // and the loss scalars only the coupling and fc11 partials, so both run on the side stream -- the coupling beside
@@ -277,18 +277,46 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     }
     const int nslab = fc11_split_path(c, params, x, xs) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11;
     if ((rc = launch_chain_bwd_dec(c, params, nslab))) return rc;
+    // Experiment kept behind a switch (default off): the small-layer dW GEMMs (occupancy-bound, 34 TF) on the side
+    // stream behind dW11 -- decoder layers beside the encoder backward chain, encoder side beside the dW1 GEMM.
+    // Measured at the benchmark shape: 1.010 ms per step against 1.006 ms with them after dW1 on the main stream
+    // (A/B/A/B on one box): what they would hide behind is itself short of CUs.
+    static const int side_small = getenv("MMVAE_SIDE_SMALL") ? atoi(getenv("MMVAE_SIDE_SMALL")) : 0;
+    const bool small_on_side = forked && side_small;
+    Ctx cs = c;
+    cs.stream = g_side;
+    if (small_on_side) {
+        if (!g_ev_dec && (hipEventCreateWithFlags(&g_ev_dec, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&g_ev_enc, hipEventDisableTiming) != hipSuccess)) {
+            set_error("event creation failed");
+            return MMVAE_E_LAUNCH;
+        }
+        if (hipEventRecord(g_ev_dec, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_dec, 0) != hipSuccess) {
+            set_error("stream fork failed");
+            return MMVAE_E_LAUNCH;
+        }
+        if ((rc = launch_dw_small(cs, 1))) return rc;
+    }
     // T (sum of G log c, from the loss finalisation) is first needed here
     if (wait_loss && hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
     for (int layer = 5; layer >= 2; --layer)
         if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
+    if (small_on_side) {
+        if (hipEventRecord(g_ev_enc, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_enc, 0) != hipSuccess) {
+            set_error("stream fork failed");
+            return MMVAE_E_LAUNCH;
+        }
+        if ((rc = launch_dw_small(cs, 2))) return rc;
+        if (hipEventRecord(g_ev_join, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+    }
     if (fast) {
         if ((rc = launch_dw_big_fast(c, x, xs, forked ? 1 : 3))) return rc;
     } else if ((rc = launch_dw_big(c, nz, x, xs))) {
         return rc;
     }
-    if ((rc = launch_dw_small(c))) return rc;
+    if (!small_on_side && (rc = launch_dw_small(c))) return rc;
     if (forked && hipStreamWaitEvent(c.stream, g_ev_join, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
     return launch_reduce_grads(c, grads, grad_scale, adam, fast);
 }

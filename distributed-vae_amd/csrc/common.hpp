@@ -548,7 +548,7 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params);
 int launch_chain_bwd_enc(const Ctx& c, int layer /*5..2*/, const float* params);
 int launch_bn_bwd_apply1(const Ctx& c);
 int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t xs);
-int launch_dw_small(const Ctx& c);
+int launch_dw_small(const Ctx& c, int which = 3 /*bit0 decoder layers, bit1 encoder side*/);
 struct AdamHost { float* p; float* m; float* v; int64_t step; float lr, b1, b2, eps, wd; int decoupled; };
 // slabs -> grads; with `adam` (p != null) the Adam update is fused into the same pass
 int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale, const AdamHost* adam, bool dw11_fast);

@@ -652,13 +652,16 @@ int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t x
     return 0;
 }
 
-int launch_dw_small(const Ctx& c) {
+// which: bit 0 = decoder layers fc6..fc10 (their dZ exist once the decoder backward chain has run), bit 1 = encoder
+// side (fc2..fc5, fcc, state head, fc1.bias: after the encoder backward chain).  The slab of a layer does not depend
+// on the grouping, so the two halves can be launched separately (side stream) or together.
+int launch_dw_small(const Ctx& c, int which) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int A = d.A, B = d.B, H = d.H, Ld = d.L, C = d.C, S = d.S;
     const int KS = L.sp.ks_small;
-    TnDescs ts{};
-    TnDesc* hd = ts.d;
+    TnDescs ts{}, all{};
+    TnDesc* hd = all.d;
     NoiseDev nd{};   // unused
     const int64_t slab_ks = (int64_t)A * N_SMALL * NP * SMALL_LD;
     auto mk = [&](int i, int64_t dz, int N, int64_t xin, int K, int64_t mean, int64_t rstd) {
@@ -680,10 +683,16 @@ int launch_dw_small(const Ctx& c) {
     mk(10, L.DZ[10], H, L.Dk[3], H, -1, -1);
     mk(11, L.DZ[1], H, L.R[0], 0, -1, -1);                       // fc1.bias: only the ones column
     // N <= 128 rows; K + 1 <= 256 columns (one or two column tiles), see mmvae_check_dims
-    int tiles = 1;
-    for (int i = 0; i < N_SMALL; ++i) tiles = max(tiles, cdiv(hd[i].Mv, 128) * cdiv(hd[i].Nv + 1, 128));
-    dim3 grid(tiles, KS, A * N_SMALL);
-    hipLaunchKernelGGL((k_gemm_tn<128, 128>), grid, dim3(256), 0, c.stream, ts, N_SMALL, nd, B, KS, 3);
+    int nsel = 0, tiles = 1;
+    for (int i = 0; i < N_SMALL; ++i) {
+        const bool dec = i >= 6 && i <= 10;
+        if (!(which & (dec ? 1 : 2))) continue;
+        ts.d[nsel++] = hd[i];
+        tiles = max(tiles, cdiv(hd[i].Mv, 128) * cdiv(hd[i].Nv + 1, 128));
+    }
+    if (nsel == 0) return 0;
+    dim3 grid(tiles, KS, A * nsel);
+    hipLaunchKernelGGL((k_gemm_tn<128, 128>), grid, dim3(256), 0, c.stream, ts, nsel, nd, B, KS, 3);
     HIP_LAUNCH_CHECK("k_gemm_tn<small>");
     return 0;
 }
