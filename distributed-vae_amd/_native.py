@@ -58,6 +58,17 @@ class ParamLayout(C.Structure):
                 ("bn_var_offset", C.c_int64 * N_BN), ("bn_dim", C.c_int64 * N_BN)]
 
 
+class AugDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("A", "B", "D", "N1", "N3", "N5", "Z", "NZ")]
+
+
+class AugTensors(C.Structure):
+    _fields_ = [("w", C.c_void_p * 11), ("b", C.c_void_p * 11), ("bn_mean", C.c_void_p * 10), ("bn_var", C.c_void_p * 10),
+                ("w_mu", C.c_void_p), ("b_mu", C.c_void_p), ("w_sigma", C.c_void_p), ("b_sigma", C.c_void_p),
+                ("bn_mu_mean", C.c_void_p), ("bn_mu_var", C.c_void_p), ("noise_w", C.c_void_p),
+                ("bnz_weight", C.c_void_p), ("bnz_bias", C.c_void_p), ("bnz_mean", C.c_void_p), ("bnz_var", C.c_void_p)]
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -103,9 +114,16 @@ def lib():
     L.mmvae_classify.argtypes = [vp, i64, i32, vp, vp]
     L.mmvae_confmat_accumulate.argtypes = [vp, i32, i64, i32, vp, vp]
     L.mmvae_consensus.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.mmvae_aug_packed_floats.argtypes = [C.POINTER(AugDims)]
+    L.mmvae_aug_packed_floats.restype = C.c_size_t
+    L.mmvae_aug_workspace_bytes.argtypes = [C.POINTER(AugDims), i32]
+    L.mmvae_aug_workspace_bytes.restype = C.c_size_t
+    L.mmvae_aug_pack.argtypes = [C.POINTER(AugDims), C.POINTER(AugTensors), vp, vp]
+    L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, vp]
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_set_split", "mmvae_forward", "mmvae_loss",
                "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",
-               "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus"):
+               "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus", "mmvae_aug_pack",
+               "mmvae_augment"):
         getattr(L, fn).restype = C.c_int
     if L.mmvae_abi_version() != 1:
         raise NativeError("libmmvae_hip.so ABI version mismatch")

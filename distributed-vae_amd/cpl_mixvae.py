@@ -3,7 +3,8 @@
 Mirrors ``__init__`` (:153-186), ``init_model`` (:193-286), ``load_model`` (:317-321) and the
 training loop of ``train`` (:323-492: per-batch driver :415-478, epoch reductions :480-492,
 checkpoints :777-788) on top of the fused HIP train step.  Out of the hot path and therefore not
-here: augmenter, pruning phase, wandb/matplotlib reporting.
+here: pruning phase, wandb/matplotlib reporting.  The augmenter in front of the step
+(:182-186, :422-423) is ``distributed_vae_amd.augmentation``.
 """
 from __future__ import annotations
 
@@ -121,10 +122,16 @@ class cpl_mixVAE:
         self.aug_file = aug_file
         self.models = []
         self.device = get_device(device)
-        if aug_file:
-            raise NotImplementedError("the pre-trained augmenter (cpl_mixvae.py:128-150, :422-423) is outside the "
-                                      "HIP hot path; train on raw x.expand (cpl_mixvae.py:425)")
         self.aug_model, self.aug_param, self.netA = None, None, None
+        if aug_file:                                            # cpl_mixvae.py:182-186
+            from .augmentation import mk_augmenter
+            self.aug_model, self.aug_param, netA = mk_augmenter(aug_file, load_weights)
+            self.set_augmenter(netA)
+
+    def set_augmenter(self, netA):
+        """Install an ``Augmenter_smartseq`` (distributed_vae_amd.augmentation) in eval mode on the trainer's device,
+        as cpl_mixvae.py:184; ``None`` returns to raw ``x.expand``."""
+        self.netA = None if netA is None else netA.to(self.device).eval()
 
     def init_model(self, n_categories, state_dim, input_dim, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.2,
                    lr=0.001, lam=1, lam_pc=1, n_arm=2, temp=1.0, tau=0.005, beta=1.0, hard=False, variational=True,
@@ -172,6 +179,8 @@ class cpl_mixVAE:
         loss, backward, optimizer step).  Returns the device loss vector; no host synchronisation."""
         x = x.to(self.device, non_blocking=True)
         xs = x.expand(self.n_arm, -1, -1)
+        if self.netA is not None:
+            xs = self.netA(xs, True, 0.1)[1]                    # cpl_mixvae.py:422-423
         if D.is_dist():
             buf = self.model.fused_train_step(xs, self.temp, self.optimizer, do_adam=False)
             D.allreduce_mean_(self.model.flat_grad())

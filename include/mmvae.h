@@ -14,6 +14,7 @@
  *   mmvae_train_step   the per-batch driver          mmidas/cpl_mixvae.py:434-463
  *   mmvae_eval_classify / mmvae_confmat_accumulate / mmvae_consensus
  *                      the per-epoch consensus loop  mmidas/cpl_mixvae.py:563-657, _utils.py:79-129
+ *   mmvae_augment      netA(x.expand(A,-1,-1), True, 0.1)  mmidas/cpl_mixvae.py:422-423, augmentation/udagan.py:281-329
  *
  * Conventions
  *   - plain pointers and sizes only; every buffer is caller-owned DEVICE memory (fp32 unless
@@ -213,6 +214,38 @@ int mmvae_confmat_accumulate(const int32_t *labels, int A, int64_t n, int C, int
                              void *stream);
 int mmvae_consensus(const int64_t *counts, int npairs, int C, double *cm_norm, double *consensus,
                     void *stream);
+
+/* ---- augmenter forward in the training loop ----------------------
+ * Replaces `self.netA(x.expand(A,-1,-1), True, 0.1)[1]` (mmidas/cpl_mixvae.py:422-423; netA.eval(), :184), i.e.
+ * Augmenter_smartseq.forward in eval mode (mmidas/augmentation/udagan.py:281-329, reparam_trick
+ * mmidas/augmentation/aug_utils.py:51-65): Linear + BatchNorm1d(running statistics) + ReLU stacks around a
+ * noise-conditioned Gaussian bottleneck.  D input_dim, N1 = D / 5, N3 = n_dim, N5 = n_dim / 5, Z latent_dim,
+ * NZ noise_dim (udagan.py:218-279); A arms x B cells per call. */
+typedef struct mmvae_aug_dims {
+    int32_t A, B, D, N1, N3, N5, Z, NZ;
+} mmvae_aug_dims;
+
+/* Device pointers to the module's tensors, PyTorch layouts ([out, in] weights, contiguous). */
+typedef struct mmvae_aug_tensors {
+    const float *w[11], *b[11];            /* fc1 .. fc11 (fc5.weight is [N5, N3 + NZ])                   */
+    const float *bn_mean[10], *bn_var[10]; /* batch_fc1 .. batch_fc10 running_mean / running_var          */
+    const float *w_mu, *b_mu, *w_sigma, *b_sigma, *bn_mu_mean, *bn_mu_var; /* fc_mu, fc_sigma, batch_fc_mu */
+    const float *noise_w;                  /* noise.weight [NZ, NZ] (no bias)                             */
+    const float *bnz_weight, *bnz_bias, *bnz_mean, *bnz_var; /* bnz: affine BatchNorm1d, eps 1e-5        */
+} mmvae_aug_tensors;
+
+/* floats of the packed-weights buffer / bytes of workspace (shared_x: the arms share x) */
+size_t mmvae_aug_packed_floats(const mmvae_aug_dims *d);
+size_t mmvae_aug_workspace_bytes(const mmvae_aug_dims *d, int shared_x);
+/* Once per set of weights: rows padded to 16 bytes, BatchNorm folded into per-column (scale, shift). */
+int mmvae_aug_pack(const mmvae_aug_dims *d, const mmvae_aug_tensors *t, float *packed, void *stream);
+/* x: [B,D] shared by the arms (x_arm_stride == 0, as x.expand) or [A,B,D] contiguous (x_arm_stride == B*D).
+ * z0: [A,B,NZ] and eps: [A,B,Z] standard-normal draws (the reference's torch.randn / randn_like); scale: the
+ * noise scale (0.1 in the trainer).  Outputs: s_out [A,B,Z] (forward out 0), x_aug [A,B,D] (forward out 1),
+ * ready as the per-arm input of mmvae_train_step (x_arm_stride = B*D). */
+int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, int64_t x_arm_stride,
+                  const float *z0, const float *eps, float scale, void *ws, size_t ws_bytes, float *s_out,
+                  float *x_aug, void *stream);
 
 /* Writes the noise the Philox mode (nz->mode == 1) would use, in explicit-buffer form, so a test
  * can replay a Philox step through mode 0.  Any output pointer may be NULL. */

@@ -168,3 +168,25 @@ def load_reference_consensus_utils() -> types.SimpleNamespace:
     ns: Dict[str, Any] = {"np": np}
     exec(compile(mod, _UTILS, "exec"), ns)
     return types.SimpleNamespace(**{k: ns[k] for k in _CONSENSUS_FUNCS})
+
+
+_UDAGAN = os.path.join(REFERENCE_ROOT, "mmidas", "augmentation", "udagan.py")
+_AUG_UTILS = os.path.join(REFERENCE_ROOT, "mmidas", "augmentation", "aug_utils.py")
+
+
+def load_reference_augmenter():
+    """The reference's own ``Augmenter_smartseq`` class (mmidas/augmentation/udagan.py:217-329) and ``reparam_trick``
+    (aug_utils.py:51-65), compiled in memory from the reference files where they lie (only these two definitions: the
+    modules' top levels import the whole package).  Nothing is copied into the repo."""
+    import ast
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ns: Dict[str, Any] = {"torch": torch, "nn": nn, "F": F}
+    for path, names, kind in ((_AUG_UTILS, ("reparam_trick",), ast.FunctionDef), (_UDAGAN, ("Augmenter_smartseq",), ast.ClassDef)):
+        with open(path, "r") as fh:
+            tree = ast.parse(fh.read(), filename=path)
+        keep = [n for n in tree.body if isinstance(n, kind) and n.name in names]
+        assert len(keep) == len(names), (path, names)
+        exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns["Augmenter_smartseq"]

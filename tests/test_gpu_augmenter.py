@@ -1,0 +1,136 @@
+"""GPU parity of the augmenter forward against oracle/augmenter.py (CPU restatement of
+mmidas/augmentation/udagan.py:281-329, pinned to the live reference class) and the reference-generated fixture.
+fp32 tolerance: 1e-4 of the largest magnitude of the compared tensor (twelve chained fp32 GEMMs; BatchNorm folded
+into (scale, shift) rounds differently from the reference's subtract-then-divide)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augmenter as OA
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "aug_small.npz")
+DEV = "cuda:0"
+
+
+def _model(NZ, Z, D, ND, sd):
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    m = Augmenter_smartseq(noise_dim=NZ, latent_dim=Z, input_dim=D, n_dim=ND)
+    m.load_state_dict(sd)
+    return m.to(DEV).eval()
+
+
+def _rel(a, b):
+    return float((a.cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_reference_fixture():
+    g = np.load(GOLD)
+    NZ, Z, D, ND, A, B = (int(v) for v in g["dims"])
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd/")}
+    m = _model(NZ, Z, D, ND, sd)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    m.set_explicit_noise(torch.from_numpy(g["b/z0"]), torch.from_numpy(g["b/eps"]))
+    s, xa = m(x.expand(A, -1, -1), True, float(g["scale"]))
+    assert s.shape == (A, B, Z) and xa.shape == (A, B, D)
+    assert _rel(s, torch.from_numpy(g["b/s"])) < TOL and _rel(xa, torch.from_numpy(g["b/x_aug"])) < TOL
+    m.set_explicit_noise(torch.from_numpy(g["u/z0"])[None], torch.from_numpy(g["u/eps"])[None])
+    s, xa = m(x, False, 1.0)
+    assert s.shape == (B, Z) and xa.shape == (B, D)
+    assert _rel(s, torch.from_numpy(g["u/s"])) < TOL and _rel(xa, torch.from_numpy(g["u/x_aug"])) < TOL
+
+
+@pytest.mark.parametrize("cfg", [
+    # NZ, Z, D, n_dim, A, B
+    (6, 3, 52, 20, 3, 21),          # D/5 = 10, n/5 = 4: padded rows everywhere, single partial tiles
+    (50, 10, 1000, 500, 2, 300),    # several row and column tiles, K tails (200 = 6.25 K tiles)
+    (16, 10, 640, 320, 5, 257),     # exact 128 multiples next to ragged rows
+    (64, 32, 400, 640, 1, 130),     # a large latent block (n/5 = 128 columns, 104 KB of weights in LDS)
+])
+def test_against_oracle_shared_and_per_arm_input(cfg):
+    NZ, Z, D, ND, A, B = cfg
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=NZ + D)
+    m = _model(NZ, Z, D, ND, sd)
+    g = torch.Generator().manual_seed(B)
+    x = (torch.rand(B, D, generator=g) < 0.3).float() * torch.randn(B, D, generator=g).abs() * 3
+    z0, eps = torch.randn(A, B, NZ, generator=g), torch.randn(A, B, Z, generator=g)
+    s_ref, x_ref = OA.forward_eval(sd, x.expand(A, -1, -1), z0, eps, 0.1)
+    m.set_explicit_noise(z0, eps)
+    s, xa = m(x.to(DEV).expand(A, -1, -1), True, 0.1)                  # arms share x: trunk once per cell
+    assert _rel(s, s_ref) < TOL and _rel(xa, x_ref) < TOL
+    assert float((x_ref > 0).float().mean()) > 0.02
+    xs = torch.stack([x * (1 + 0.1 * a) for a in range(A)])            # distinct per-arm inputs
+    s_ref2, x_ref2 = OA.forward_eval(sd, xs, z0, eps, 0.1)
+    s2, xa2 = m(xs.to(DEV), True, 0.1)
+    assert _rel(s2, s_ref2) < TOL and _rel(xa2, x_ref2) < TOL
+    # the packed copy follows the parameters
+    sd2 = OA.random_state_dict(NZ, Z, D, ND, seed=NZ + D + 1)
+    m.load_state_dict(sd2)
+    s3, xa3 = m(x.to(DEV).expand(A, -1, -1), True, 0.1)
+    s_ref3, x_ref3 = OA.forward_eval(sd2, x.expand(A, -1, -1), z0, eps, 0.1)
+    assert _rel(s3, s_ref3) < TOL and _rel(xa3, x_ref3) < TOL
+
+
+def test_device_noise_statistics_and_determinism():
+    """Without the explicit hook the module draws torch.randn on the device like the reference: same seed, same
+    output; different arms differ; s has the spread the noise implies."""
+    NZ, Z, D, ND, A, B = 16, 10, 200, 100, 2, 400
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=4)
+    m = _model(NZ, Z, D, ND, sd)
+    x = torch.rand(B, D, device=DEV)
+    torch.manual_seed(3)
+    s1, x1 = m(x.expand(A, -1, -1), True, 0.1)
+    torch.manual_seed(3)
+    s2, x2 = m(x.expand(A, -1, -1), True, 0.1)
+    assert torch.equal(s1, s2) and torch.equal(x1, x2)
+    assert float((x1[0] - x1[1]).abs().max()) > 0
+    assert float((s1[0] - s1[1]).std()) > 0.05
+
+
+def test_unsupported_shapes_fail_loudly():
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    m = Augmenter_smartseq(noise_dim=4, latent_dim=2, input_dim=50, n_dim=20).to(DEV).eval()     # 50 % 4 != 0
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 8, 50, device=DEV), True, 0.1)
+    m = Augmenter_smartseq(noise_dim=128, latent_dim=64, input_dim=400, n_dim=640).to(DEV).eval()  # 235 KB of LDS
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 8, 400, device=DEV), True, 0.1)
+
+
+def test_trainer_step_with_augmenter_matches_manual_composition():
+    """cpl_mixVAE with an augmenter: the batch goes through netA (eval, scale 0.1) and the per-arm outputs feed the
+    fused train step (cpl_mixvae.py:422-423): same loss as composing the two by hand on the same noise."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    A, D, C = 2, 64, 6
+    NZ, Z, ND = 8, 4, 40
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=8)
+    t = cpl_mixVAE(saving_folder="", device=DEV, save_flag=False)
+    t.init_model(n_categories=C, state_dim=2, input_dim=D, fc_dim=16, lowD_dim=4, x_drop=0.5, s_drop=0.0, n_arm=A)
+    netA = Augmenter_smartseq(NZ, Z, D, ND)
+    netA.load_state_dict(sd)
+    t.set_augmenter(netA)
+    assert not t.netA.training
+    x = torch.rand(48, D)
+    g = torch.Generator().manual_seed(1)
+    z0, eps = torch.randn(A, 48, NZ, generator=g), torch.randn(A, 48, Z, generator=g)
+    t.netA.set_explicit_noise(z0, eps)
+    t.model._noise_seed, t.model._noise_offset = 5, 0
+    state0 = {k: v.clone() for k, v in t.model.state_dict().items()}
+    buf = t.train_step(x).clone()
+    # by hand
+    _, xa = t.netA(x.to(DEV).expand(A, -1, -1), True, 0.1)
+    _, xa_ref = OA.forward_eval(sd, x.expand(A, -1, -1), z0, eps, 0.1)
+    assert _rel(xa, xa_ref) < TOL
+    t.model.load_state_dict(state0)
+    t.model._noise_seed, t.model._noise_offset = 5, 0
+    from distributed_vae_amd.cpl_mixvae import FusedAdam
+    opt = FusedAdam(t.model, lr=1e-3)
+    buf2 = t.model.fused_train_step(xa, t.temp, opt, do_adam=True)
+    assert torch.equal(buf, buf2)

@@ -97,8 +97,8 @@ def test_unsupported_paths_raise():
     m = mk_vae(7, 2, 64, "cpu", fc_dim=16, latent_dim=5, mode="ZINB")
     with pytest.raises(AssertionError):
         m([torch.zeros(4, 64)] * 2, 1.0)                     # ZINB rejected, nn_model.py:315
-    with pytest.raises(NotImplementedError):
-        cpl_mixVAE(aug_file="some.pth", device="cpu")
+    with pytest.raises(FileNotFoundError):
+        cpl_mixVAE(aug_file="some.pth", device="cpu")           # the augmenter checkpoint is loaded (cpl_mixvae.py:183)
     with pytest.raises(NotImplementedError):
         N.Engine(2, 32, 64, 300, 5, 7, 2, "cuda:0") if False else N.check(-2, "x")
 
