@@ -212,6 +212,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, D, H, L, C, S, A, B)
     if rank == 0 and world == 1 and not args.no_eval:
         out["eval_consensus"] = eval_consensus(args, model, batches, A, B, D, H, L, C, S, not args.no_cpu_baseline)
+        out["augmenter"] = augmenter_forward(args, batches, A, B, D, not args.no_cpu_baseline)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -267,6 +268,53 @@ def eval_consensus(args, model, batches, A, B, D, H, L, C, S, with_cpu):
         out["cpu_baseline"] = {"value": B / ts[1], "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": "3 batches of the same shape through the oracle's full eval forward (as the "
                                          "reference does) + numpy consensus, median"}
+    return out
+
+
+def augmenter_forward(args, batches, A, B, D, with_cpu):
+    """Scope row (f)-2 beside the headline metric: the eval-mode augmenter forward the reference trainer runs in front
+    of every step (cpl_mixvae.py:422-423), random-init weights of the Augmenter_smartseq architecture (n_dim 500,
+    noise 50, latent 10; the pretrained file is not shipped), x shared by the arms; HIP events on the call stream."""
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    ND, NZ, Z = 500, 50, 10
+    torch.manual_seed(546)
+    net = Augmenter_smartseq(NZ, Z, D, ND).to(batches[0].device).eval()
+    for b in batches[:2]:
+        net(b.expand(A, -1, -1), True, 0.1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 2
+    e0.record()
+    for _ in range(reps):
+        for b in batches:
+            net(b.expand(A, -1, -1), True, 0.1)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / (reps * len(batches))
+    n1, n5 = D // 5, ND // 5
+    trunk = D * n1 + n1 * n1 + n1 * ND + ND * ND + ND * n5
+    tail = n5 * ND + ND * ND + ND * n1 + n1 * n1 + n1 * D
+    fl_exec = 2.0 * B * (trunk + A * tail)          # the trunk once per cell (the arms share x)
+    fl_ref = 2.0 * A * B * (trunk + tail)           # the reference runs it once per cell-arm
+    out = {"value": B / ms * 1e3, "unit": "cells/s", "ms_per_batch": ms, "batch": B, "arms": A,
+           "workload": f"Augmenter_smartseq eval forward, D={D}, n_dim={ND}, noise {NZ}, latent {Z}, x shared by {A} arms",
+           "gflop_executed": fl_exec / 1e9, "gflop_reference_pattern": fl_ref / 1e9,
+           "tflops": fl_exec / ms / 1e9, "frac_of_fp32_mfma_peak": fl_exec / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+    if with_cpu:
+        from oracle import augmenter as OA
+        sd = OA.random_state_dict(NZ, Z, D, ND, seed=1)
+        nb = 500                                       # bounded sample: 500 cells x A arms
+        x = torch.rand(nb, D)
+        z0, eps = torch.randn(A, nb, NZ), torch.randn(A, nb, Z)
+        ts = []
+        for _ in range(3):
+            t0 = time.time()
+            with torch.no_grad():
+                OA.forward_eval(sd, x.expand(A, -1, -1), z0, eps, 0.1)
+            ts.append(time.time() - t0)
+        ts.sort()
+        out["cpu_baseline"] = {"value": nb / ts[1], "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{nb} cells x {A} arms through the oracle (torch CPU, reference call pattern), "
+                                         f"median of 3"}
     return out
 
 

@@ -21,6 +21,7 @@
 // (four accumulators per wave, one ds_read_b128 per operand per four MFMAs), register prefetch of the next K tile,
 // workgroup ids remapped so that an XCD walks a contiguous range of tiles (its L2 then sees one A panel at a time).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace mmvae {
 
@@ -37,104 +38,116 @@ static inline int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
 
 constexpr int AG_LD = 36;   // LDS row stride of a 32-wide K tile (+4: conflict-free b128 fragment reads)
 
-// grid (tiles_n * tiles_m), 256 threads.  lda, ldw, ldc multiples of 4; rows of A beyond M are clamped (recomputed,
-// never stored); columns N <= col < ldc of C are written as zeros (they are the K padding of the next layer).
-template <bool RELU, bool AFFINE>
-__global__ __launch_bounds__(256, 2) void k_aug_gemm(const float* __restrict__ Ain, int lda, int M,
+// grid (tiles_n * tiles_m), 256 threads = 2 x 2 waves of (BM/2) x (BN/2).  lda, ldw, ldc multiples of 4; rows of A
+// beyond M are clamped (recomputed, never stored); columns N <= col < ldc of C are written as zeros (they are the K
+// padding of the next layer).  BM, BN in {64, 128}: the launcher takes the largest tile that still gives every CU two
+// workgroups (a 128 x 128 grid of the 5000 x 1000 layers is 320 workgroups for 256 CUs: 74 TF against 91-106 TF for
+// the layers with thousands of tiles).
+template <int BM, int BN, bool RELU, bool AFFINE>
+__global__ __launch_bounds__(256, 3) void k_aug_gemm(const float* __restrict__ Ain, int lda, int M,
                                                      const float* __restrict__ W, int ldw, int N, int K,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      float* __restrict__ Cout, int ldc, int tiles_n, int tiles_m) {
-    __shared__ __attribute__((aligned(16))) float As[128 * AG_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[128 * AG_LD];
+    constexpr int TI = BM / 64, TJ = BN / 64;      // 32 x 32 accumulators per wave
+    constexpr int LA = BM / 32, LB = BN / 32;      // float4 loads per thread and K tile
+    __shared__ __attribute__((aligned(16))) float As[BM * AG_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * AG_LD];
     // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x the tiles [x * per, (x + 1) * per)
     const int nwg = tiles_n * tiles_m;
     int wg = blockIdx.x;
-    {
-        const int per = (nwg + 7) / 8, x = wg & 7, j = wg >> 3;
-        const int t = x * per + j;
-        // when nwg is not a multiple of 8 some (x, j) fall beyond nwg: those ids take the leftover slots in order
-        wg = (nwg % 8 == 0) ? t : wg;
-    }
+    if (nwg % 8 == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
     const int tn = wg % tiles_n, tm = wg / tiles_n;
-    const int m0 = tm * 128, n0 = tn * 128;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     const int r0 = tid >> 3, c4 = tid & 7;
     const int nkt = cdiv(K, 32);
 
-    const float* pa[4];
-    const float* pb[4];
-    bool okb[4];
+    const float* pa[LA];
+    const float* pb[LB];
+    bool okb[LB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = min(m0 + r0 + 32 * i, M - 1);
-        pa[i] = Ain + (int64_t)ra * lda + c4 * 4;
+    for (int i = 0; i < LA; ++i) pa[i] = Ain + (int64_t)min(m0 + r0 + 32 * i, M - 1) * lda + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
         const int rb = n0 + r0 + 32 * i;
         okb[i] = rb < N;
         pb[i] = W + (int64_t)min(rb, N - 1) * ldw + c4 * 4;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+        for (int j = 0; j < TJ; ++j) acc[i][j] = zero16();
 
-    float4 ra4[4], rb4[4];
+    float4 ra4[LA], rb4[LB];
     auto load_tiles = [&](int kt) {
         const bool colok = kt * 32 + c4 * 4 < K;     // K padded to 4: a float4 is all in or all out
         const int koff = colok ? kt * 32 : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra4[i] = *reinterpret_cast<const float4*>(pa[i] + koff);
+        for (int i = 0; i < LA; ++i) ra4[i] = *reinterpret_cast<const float4*>(pa[i] + koff);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb4[i] = *reinterpret_cast<const float4*>(pb[i] + koff);
+        for (int i = 0; i < LB; ++i) rb4[i] = *reinterpret_cast<const float4*>(pb[i] + koff);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < LA; ++i)
             if (!colok) ra4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
             if (!(colok && okb[i])) rb4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
     };
+    // One LDS buffer per operand and two barriers per K tile.  Double-buffering the LDS tiles (one barrier) measured
+    // slower at the benchmark shape (2.67 ms against 2.22 ms per call): twice the LDS per workgroup for no gain, the
+    // second resident workgroup already covers the barrier.
     load_tiles(0);
     for (int kt = 0; kt < nkt; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * AG_LD + c4 * 4]) = ra4[i];
-            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * AG_LD + c4 * 4]) = rb4[i];
-        }
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * AG_LD + c4 * 4]) = ra4[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * AG_LD + c4 * 4]) = rb4[i];
         __syncthreads();
         if (kt + 1 < nkt) load_tiles(kt + 1);
-        const float* la = As + (wm * 64 + l31) * AG_LD + 4 * hh;
-        const float* lb = Bs + (wn * 64 + l31) * AG_LD + 4 * hh;
+        const float* la = As + (wm * (BM / 2) + l31) * AG_LD + 4 * hh;
+        const float* lb = Bs + (wn * (BN / 2) + l31) * AG_LD + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 a0 = *reinterpret_cast<const float4*>(la + 8 * g);
-            const float4 a1 = *reinterpret_cast<const float4*>(la + 32 * AG_LD + 8 * g);
-            const float4 q0 = *reinterpret_cast<const float4*>(lb + 8 * g);
-            const float4 q1 = *reinterpret_cast<const float4*>(lb + 32 * AG_LD + 8 * g);
-            acc[0][0] = mfma32(a0.x, q0.x, acc[0][0]); acc[0][1] = mfma32(a0.x, q1.x, acc[0][1]);
-            acc[1][0] = mfma32(a1.x, q0.x, acc[1][0]); acc[1][1] = mfma32(a1.x, q1.x, acc[1][1]);
-            acc[0][0] = mfma32(a0.y, q0.y, acc[0][0]); acc[0][1] = mfma32(a0.y, q1.y, acc[0][1]);
-            acc[1][0] = mfma32(a1.y, q0.y, acc[1][0]); acc[1][1] = mfma32(a1.y, q1.y, acc[1][1]);
-            acc[0][0] = mfma32(a0.z, q0.z, acc[0][0]); acc[0][1] = mfma32(a0.z, q1.z, acc[0][1]);
-            acc[1][0] = mfma32(a1.z, q0.z, acc[1][0]); acc[1][1] = mfma32(a1.z, q1.z, acc[1][1]);
-            acc[0][0] = mfma32(a0.w, q0.w, acc[0][0]); acc[0][1] = mfma32(a0.w, q1.w, acc[0][1]);
-            acc[1][0] = mfma32(a1.w, q0.w, acc[1][0]); acc[1][1] = mfma32(a1.w, q1.w, acc[1][1]);
+            float4 a[TI], q[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) a[i] = *reinterpret_cast<const float4*>(la + 32 * i * AG_LD + 8 * g);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) q[j] = *reinterpret_cast<const float4*>(lb + 32 * j * AG_LD + 8 * g);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(a[i].x, q[j].x, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(a[i].y, q[j].y, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(a[i].z, q[j].z, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = mfma32(a[i].w, q[j].w, acc[i][j]);
         }
         __syncthreads();
     }
     // epilogue: lane l31 owns one column of each 32-wide tile
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + l31;
         if (col >= ldc) continue;
         const bool real = col < N;
         const float sc = (AFFINE && real) ? scale[col] : 1.f;
         const float sh = (AFFINE && real) ? shift[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                const int row = m0 + wm * (BM / 2) + i * 32 + acc_row(r, lane);
                 if (row < M) {
                     float v = acc[i][j][r] * sc + sh;
                     if (RELU) v = fmaxf(v, 0.f);
@@ -347,17 +360,36 @@ __global__ __launch_bounds__(64 * AL_NW) void k_aug_latent(const float* __restri
     }
 }
 
+template <int BM, int BN>
+static void aug_gemm_launch(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw,
+                            int N, int K, const float* sc, const float* sh, float* C, int ldc, int ncols) {
+    const int tiles_n = cdiv(ncols, BN), tiles_m = cdiv(M, BM);
+    dim3 grid(tiles_n * tiles_m), block(256);
+    if (relu) hipLaunchKernelGGL((k_aug_gemm<BM, BN, true, true>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
+    else if (affine) hipLaunchKernelGGL((k_aug_gemm<BM, BN, false, true>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
+    else hipLaunchKernelGGL((k_aug_gemm<BM, BN, false, false>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
+}
+
 static int aug_gemm(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* pk,
                     const AugLayer& g, float* C, int ldc) {
     const int ncols = ldc < (int)pad4(g.N) ? ldc : (int)pad4(g.N);   // the K padding of the next layer is written too (zeros)
-    const int tiles_n = cdiv(ncols, 128), tiles_m = cdiv(M, 128);
-    dim3 grid(tiles_n * tiles_m), block(256);
     const float* W = pk + g.w;
     const float* sc = pk + g.sc;
     const float* sh = pk + g.sh;
-    if (relu) hipLaunchKernelGGL((k_aug_gemm<true, true>), grid, block, 0, s, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, tiles_n, tiles_m);
-    else if (affine) hipLaunchKernelGGL((k_aug_gemm<false, true>), grid, block, 0, s, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, tiles_n, tiles_m);
-    else hipLaunchKernelGGL((k_aug_gemm<false, false>), grid, block, 0, s, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, tiles_n, tiles_m);
+    // the largest tile that still leaves two workgroups per CU (256 CUs); MMVAE_AUG_TILE=<BM><BN> code forces one
+    static const int force = getenv("MMVAE_AUG_TILE") ? atoi(getenv("MMVAE_AUG_TILE")) : 0;   // 11 12 21 22 (1 = 64, 2 = 128)
+    auto count = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(ncols, bn); };
+    int pick = 11;
+    if (count(128, 128) >= 512) pick = 22;
+    else if (count(64, 128) >= 512) pick = 12;
+    else if (count(128, 64) >= 512) pick = 21;
+    if (force) pick = force;
+    switch (pick) {
+        case 22: aug_gemm_launch<128, 128>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
+        case 12: aug_gemm_launch<64, 128>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
+        case 21: aug_gemm_launch<128, 64>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
+        default: aug_gemm_launch<64, 64>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
+    }
     HIP_LAUNCH_CHECK("k_aug_gemm");
     return 0;
 }
