@@ -113,7 +113,7 @@ Layout make_layout(const mmvae_dims& d) {
     for (int i = 1; i <= 5; ++i) {
         const int64_t W = (i == 5) ? Ld : H;
         L.G[i] = take(A * B * W);
-        L.bnb_part[i] = take(A * nb * 2 * W);
+        L.bnb_part[i] = take(A * (i == 5 ? (nb > cdiv(B, LAT_ROWS_BWD) ? nb : (int64_t)cdiv(B, LAT_ROWS_BWD)) : nb) * 2 * W);   // layer 5: the latent backward's partials
         L.bnb_sum[i] = take(A * 2 * W);
     }
     L.dw1_slab = take((int64_t)L.sp.ks_dw * A * H * D);

@@ -280,7 +280,8 @@ constexpr int CHAIN_ROWS = 64;
 constexpr int LAT_ROWS = 48;
 // The backward kernel runs beside the dW11 GEMM of the side stream, where smaller workgroups spread over all CUs
 // measured faster in the step (61 against 70 us) although slower alone (32 against 24 us).
-constexpr int LAT_ROWS_BWD = 32;
+constexpr int LAT_ROWS_BWD = 16;
+constexpr int LATB_NW = 8;    // waves per workgroup of the latent backward kernel
 
 template <bool VEC, int NT>
 __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int PR, int W,

@@ -590,14 +590,14 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward of the latent block.  grid (ceil(B/LAT_ROWS_BWD), A), 1024 threads, one wave per cell at a time.
+// backward of the latent block.  grid (ceil(B/LAT_ROWS_BWD), A), 64 * LATB_NW threads, one wave per cell at a time.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const NoiseDev nz_in,
+__global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, const NoiseDev nz_in,
                                                   const float* __restrict__ params, float* __restrict__ ws) {
     const LatArgs a = a_in;
     const NoiseDev nz = nz_in;
     extern __shared__ __attribute__((aligned(16))) float lat_smem[];
-    __shared__ float sh_s[LAT_NW][2][64];
+    __shared__ float sh_s[LATB_NW][2][64];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * LAT_ROWS_BWD;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int A = a.A, B = a.B, L = a.L, C = a.C, S = a.S;
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const Nois
     }
     float s1 = 0.f, s2 = 0.f;   // BN5 backward sums for column `lane` (< L)
 
-    for (int row = wv; row < LAT_ROWS_BWD; row += LAT_NW) {
+    for (int row = wv; row < LAT_ROWS_BWD; row += LATB_NW) {
         const int b = b0 + row;
         if (b >= B) break;
         // ---- state head backward (lanes < S)
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(1024) void k_lat_bwd(const LatArgs a_in, const Nois
         const int k = threadIdx.x;
         float* p = ws + a.bnb_part5 + (((int64_t)arm * gridDim.x + blk) * 2) * L;
         float k0 = 0.f, k1 = 0.f;
-        for (int w = 0; w < LAT_NW; ++w) { k0 += sh_s[w][0][k]; k1 += sh_s[w][1][k]; }
+        for (int w = 0; w < LATB_NW; ++w) { k0 += sh_s[w][0][k]; k1 += sh_s[w][1][k]; }
         p[k] = k0;
         p[L + k] = k1;
     }
@@ -978,7 +978,7 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    hipLaunchKernelGGL(k_lat_bwd, dim3(cdiv(c.d.B, LAT_ROWS_BWD), c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws);
+    hipLaunchKernelGGL(k_lat_bwd, dim3(cdiv(c.d.B, LAT_ROWS_BWD), c.d.A), dim3(64 * LATB_NW), shm, c.stream, a, nd, params, c.ws);
     HIP_LAUNCH_CHECK("k_lat_bwd");
     return 0;
 }
