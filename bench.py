@@ -213,6 +213,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_eval:
         out["eval_consensus"] = eval_consensus(args, model, batches, A, B, D, H, L, C, S, not args.no_cpu_baseline)
         out["augmenter"] = augmenter_forward(args, batches, A, B, D, not args.no_cpu_baseline)
+        out["data_path"] = data_path(data, B, D)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -269,6 +270,28 @@ def eval_consensus(args, model, batches, A, B, D, H, L, C, S, with_cpu):
                                "sample": "3 batches of the same shape through the oracle's full eval forward (as the "
                                          "reference does) + numpy consensus, median"}
     return out
+
+
+def data_path(data, B, D):
+    """Scope row (f)-3: assembling a shuffled batch from the HBM-resident matrix (mmvae_gather_rows) -- what replaces
+    DataLoader workers + pinned memory + the H2D copy of the reference (utils/dataloader.py:114-132)."""
+    from distributed_vae_amd import _native as N
+    idx = torch.randperm(data.shape[0], device=data.device)[:B]
+    out = torch.empty(B, D, device=data.device)
+    for _ in range(3):
+        N.gather_rows(data, idx, out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        N.gather_rows(data, idx, out)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    by = 2.0 * B * D * 4
+    return {"kernel": "k_gather_rows", "us_per_batch": ms * 1e3, "algorithmic_GBs": by / ms / 1e6,
+            "frac_of_hbm_peak": by / ms / 1e6 / PEAK_HBM_GBS, "bytes_per_batch": by,
+            "note": "a host-resident batch would cost B*D*4 bytes over PCIe (~1.6 ms at 63 GB/s) per step instead"}
 
 
 def augmenter_forward(args, batches, A, B, D, with_cpu):

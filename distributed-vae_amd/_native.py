@@ -120,10 +120,11 @@ def lib():
     L.mmvae_aug_workspace_bytes.restype = C.c_size_t
     L.mmvae_aug_pack.argtypes = [C.POINTER(AugDims), C.POINTER(AugTensors), vp, vp]
     L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, vp]
+    L.mmvae_gather_rows.argtypes = [vp, i64, i64, vp, i64, i32, vp, vp]
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_set_split", "mmvae_forward", "mmvae_loss",
                "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",
                "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus", "mmvae_aug_pack",
-               "mmvae_augment"):
+               "mmvae_augment", "mmvae_gather_rows"):
         getattr(L, fn).restype = C.c_int
     if L.mmvae_abi_version() != 1:
         raise NativeError("libmmvae_hip.so ABI version mismatch")
@@ -294,3 +295,18 @@ def consensus(counts: torch.Tensor, want_norm: bool = False):
     norm = torch.empty(P, Cc, Cc, dtype=torch.float64, device=cnt.device) if want_norm else None
     check(lib().mmvae_consensus(_ptr(cnt), P, Cc, _ptr(norm), _ptr(out), _stream()), "mmvae_consensus")
     return (out, norm) if want_norm else out
+
+
+def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = data[idx[i]] for a 2-D float32 CUDA matrix (rows may be strided) and int64 CUDA indices."""
+    if data.device.type != "cuda" or idx.device.type != "cuda":
+        raise NativeError("gather_rows needs CUDA tensors (no CPU fallback)")
+    assert data.dim() == 2 and data.dtype == torch.float32 and data.stride(1) == 1
+    idx = idx.to(torch.int64).contiguous()
+    n, Dm = idx.numel(), data.shape[1]
+    if out is None:
+        out = torch.empty(n, Dm, dtype=torch.float32, device=data.device)
+    if n:
+        check(lib().mmvae_gather_rows(_ptr(data), data.stride(0), data.shape[0], _ptr(idx), n, Dm, _ptr(out), _stream()),
+              "mmvae_gather_rows")
+    return out

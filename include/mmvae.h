@@ -247,6 +247,14 @@ int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, 
                   const float *z0, const float *eps, float scale, void *ws, size_t ws_bytes, float *s_out,
                   float *x_aug, void *stream);
 
+/* ---- device-resident data path ------------------------------------
+ * out[i, :] = data[idx[i], :], i < n: the batch assembly of the reference's DataLoader
+ * (mmidas/utils/dataloader.py:114-132: shuffled index batches collated from a host TensorDataset, pinned, copied to
+ * the device) as one row gather in HBM.  data: [n_rows, ld] fp32 with ld >= D; idx: int64 [n] on the device
+ * (out-of-range indices are clamped; the host loader validates them); out: [n, D] contiguous. */
+int mmvae_gather_rows(const float *data, int64_t ld, int64_t n_rows, const int64_t *idx, int64_t n, int32_t D,
+                      float *out, void *stream);
+
 /* Writes the noise the Philox mode (nz->mode == 1) would use, in explicit-buffer form, so a test
  * can replay a Philox step through mode 0.  Any output pointer may be NULL. */
 int mmvae_dump_noise(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,
