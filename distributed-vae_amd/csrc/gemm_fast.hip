@@ -600,346 +600,12 @@ __global__ __launch_bounds__(256, 2) void k_tn_v3m(const float* __restrict__ P, 
 }
 
 // =============================================================================================
-// fused fc11, fast.  Same tiling as k_fc11_fused (64 cells x 64 genes per step, waves 2 x 2), with the
-// next weight tile prefetched into registers and this tile's x values requested before the first
-// GEMM, so HBM / L2 latency hides under the MFMAs.
-// =============================================================================================
-constexpr int F11_LDZ2 = 68;
-
-__global__ __launch_bounds__(256, 2) void k_fc11_v2(const float* __restrict__ d10, const float* __restrict__ params,
-                                                 int64_t per_arm, int64_t w_off, int64_t b_off,
-                                                 const float* __restrict__ x, int64_t x_arm_stride,
-                                                 float* __restrict__ x_rec, float* __restrict__ dz11,
-                                                 float* __restrict__ gd10_slab, float* __restrict__ part, float coef,
-                                                 int need_grad, int A, int B, int D, int H, int NS, int ldk,
-                                                 int ablate, int n11) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ds = smem;                 // [64][ldk]
-    float* Ws = Ds + 64 * ldk;        // [64][ldk]
-    float* Zs = Ws + 64 * ldk;        // [64][68]
-    float* red = Zs + 64 * F11_LDZ2;  // [8]
-    const int arm = blockIdx.z, ns = blockIdx.y, b0 = blockIdx.x * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-    const int l31 = lane & 31;
-    const int KP = rup(H, 8), nc4 = KP / 4, hc4 = H / 4;
-    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
-    const float* bias = params + (int64_t)arm * per_arm + b_off;
-    const float* xa = x + (int64_t)arm * x_arm_stride;
-    const float* d10a = d10 + (int64_t)arm * B * H;
-    const int srow = tid >> 2, spart = tid & 3;     // staging: 4 threads per row, float4 chunks spart + 4 i
-
-    {   // d10 tile (rows past B: zero)
-        const int row = b0 + srow;
-        const float* p = d10a + (int64_t)min(row, B - 1) * H;
-        for (int c = spart; c < nc4; c += 4) {
-            const bool ok = (row < B) && (c < hc4);
-            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? c * 4 : 0));
-            *reinterpret_cast<float4*>(&Ds[srow * ldk + c * 4]) = sel4(ok, v);
-        }
-    }
-    const int ntile = cdiv(D, 64);
-    const int t0 = (int)(((int64_t)ns * ntile) / NS), t1 = (int)(((int64_t)(ns + 1) * ntile) / NS);
-    constexpr int WR = 8;                        // up to 32 float4 chunks per row: H <= 128
-    float4 wreg[WR];
-    auto prefetch_w = [&](int t) {
-        const int j = t * 64 + srow;
-        const float* p = W + (int64_t)min(j, D - 1) * H;
-#pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const int c = spart + 4 * i;
-            const bool ok = (j < D) && (c < hc4);
-            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? c * 4 : 0));
-            wreg[i] = sel4(ok, v);
-        }
-    };
-    f32x16 g0 = zero16(), g1 = zero16();
-    float se = 0.f, mism = 0.f;
-    // per-lane bases of this wave's 32x32 tile (row of register 0, column of this lane)
-    const uint32_t lane_off = (uint32_t)(b0 + wm * 32 + 4 * (lane >> 5)) * (uint32_t)D + (uint32_t)(wn * 32 + l31);
-    float* dza = dz11 + (int64_t)arm * B * D;
-    float* xra = x_rec ? x_rec + (int64_t)arm * B * D : nullptr;
-    if (t0 < t1) prefetch_w(t0);
-    for (int t = t0; t < t1; ++t) {
-        const int j0 = t * 64;
-        __syncthreads();                           // previous step's readers of Ws / Zs are done
-#pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            const int c = spart + 4 * i;
-            if (c < nc4) *reinterpret_cast<float4*>(&Ws[srow * ldk + c * 4]) = wreg[i];
-        }
-        __syncthreads();
-        // request this step's x values (C layout of the 32x32 tile of this wave) and the next W tile.
-        // Interior tiles (all 64 rows and 64 genes valid) use per-lane base pointers + wave-uniform
-        // offsets (no clamps, no predicates: few address registers); edge tiles take the guarded path.
-        const bool edge = (b0 + 64 > B) || (j0 + 64 > D);
-        const int col = j0 + wn * 32 + l31;
-        float xv[16];
-        float bj;
-        // 32-bit element offsets from wave-uniform bases (B*D < 2^30 checked by the launcher): one
-        // address VGPR per access instead of hoisted 64-bit pointers per register row
-        uint32_t off[16];
-        if (!edge) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) off[r] = lane_off + (uint32_t)(((r & 3) + 8 * (r >> 2)) * D + j0);
-            bj = bias[col];
-        } else {
-            const int colc = min(col, D - 1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                off[r] = (uint32_t)min(b0 + wm * 32 + acc_row(r, lane), B - 1) * (uint32_t)D + (uint32_t)colc;
-            bj = bias[colc];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xv[r] = (ablate & 1) ? 0.f : xa[off[r]];
-        f32x16 z = zero16();
-        if (!(ablate & 4)) mma_nt(z, Ds, ldk, wm * 32, Ws, ldk, wn * 32, KP / 8);
-        float* zs = Zs + (wm * 32 + 4 * (lane >> 5)) * F11_LDZ2 + wn * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = (r & 3) + 8 * (r >> 2);
-            const bool ok = !edge || ((b0 + wm * 32 + acc_row(r, lane) < B) && (col < D));
-            const float xr = fmaxf(z[r] + bj, 0.f);
-            const float e = xr - xv[r];
-            const float dzv = (ok && xr > 0.f) ? coef * e : 0.f;
-            if (ok) {
-                se += e * e;
-                mism += ((xr > 0.1f) != (xv[r] > 0.1f)) ? 1.f : 0.f;
-                if (x_rec) xra[off[r]] = xr;
-                if (need_grad && !(ablate & 2)) dza[off[r]] = dzv;
-            }
-            zs[rr * F11_LDZ2] = dzv;
-        }
-        if (t + 1 < t1 && !(ablate & 16)) prefetch_w(t + 1);     // in flight during the second GEMM
-        if (need_grad && !(ablate & 8)) {
-            __syncthreads();
-            mma_nn2(g0, g1, wn * 64 + 32 < H, Zs, F11_LDZ2, wm * 32, Ws, ldk, wn * 64, 8);
-        }
-    }
-    if (need_grad) {
-        float* o = gd10_slab + (((int64_t)ns * A + arm) * B) * H;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = b0 + wm * 32 + acc_row(r, lane);
-            const int c0 = wn * 64 + l31;
-            if (row < B) {
-                if (c0 < H) o[(int64_t)row * H + c0] = g0[r];
-                if (c0 + 32 < H) o[(int64_t)row * H + c0 + 32] = g1[r];
-            }
-        }
-    }
-    se = wave_sum(se);
-    mism = wave_sum(mism);
-    __syncthreads();
-    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mism; }
-    __syncthreads();
-    if (tid == 0) {
-        float* p = part + ((int64_t)arm * n11 + (int64_t)blockIdx.x * NS + ns) * 2;
-        p[0] = red[0] + red[2] + red[4] + red[6];
-        p[1] = red[1] + red[3] + red[5] + red[7];
-    }
-}
-
-// =============================================================================================
-// fc11 forward + reconstruction loss + dZ11, fast ("A-stationary"): every wave keeps the d10 rows of
-// its 32 cells in registers for the whole kernel (13 float4 at H = 100) and only the W11 tile moves
-// through LDS (double buffered, one barrier per 64-gene step).  grid (ceil(B/128), NS, A).
-// HBM-shaped: per step a wave reads 32x64 x values and writes 32x64 dZ11 values.
-// =============================================================================================
-// FZ_KG: K groups of 8 held in registers.  EXACT: rup(H,8)/8 == FZ_KG, so the MFMA stream has no
-// per-group branch (a runtime bound splits it into 8-MFMA pieces each waiting on its own LDS reads).
-template <int FZ_KG, bool EXACT>
-__global__ __launch_bounds__(256, 2) void k_fc11_z(const float* __restrict__ d10, const float* __restrict__ params,
-                                                   int64_t per_arm, int64_t w_off, int64_t b_off,
-                                                   const float* __restrict__ x, int64_t x_arm_stride,
-                                                   float* __restrict__ x_rec, float* __restrict__ dz11,
-                                                   float* __restrict__ part, int n11, int slot_base, float coef,
-                                                   int need_grad, int A, int B, int D, int H, int ldk, int rb0, int tbeg,
-                                                   int tend, int ablate) {
-    // grid (row blocks, column splits, A).  Each 64-gene step runs one of two bodies: interior (every
-    // cell row and gene column in range: no clamps, no predicates, wave-uniform address bases) or edge
-    // (last row block / last partial gene tile: guarded).
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wbuf = smem;                     // [2][64][ldk]
-    float* red = smem + 2 * 64 * ldk;       // [8]
-    const int arm = blockIdx.z, ns = blockIdx.y, NS = gridDim.y, b0 = (rb0 + blockIdx.x) * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int KP = rup(H, 8), kg = KP / 8, nc4 = KP / 4, hc4 = H / 4;
-    const float* W = params + (int64_t)arm * per_arm + w_off;     // [D, H]
-    const float* bias = params + (int64_t)arm * per_arm + b_off;
-    const float* xa = x + (int64_t)arm * x_arm_stride;
-    float* dza = dz11 + (int64_t)arm * B * D;
-    float* xra = x_rec ? x_rec + (int64_t)arm * B * D : nullptr;
-    const int srow = tid >> 2, spart = tid & 3;
-
-    // ---- A fragments: row b0 + 32 wv + l31 of d10, k = 8 g + 4 hh .. + 3
-    float4 afr[FZ_KG];
-    {
-        const int row = b0 + wv * 32 + l31;
-        const float* p = d10 + ((int64_t)arm * B + min(row, B - 1)) * H + 4 * hh;
-#pragma unroll
-        for (int g = 0; g < FZ_KG; ++g) {
-            const bool ok = (g < kg) && (row < B) && (8 * g + 4 * hh < H);
-            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? 8 * g : 0));
-            afr[g] = sel4(ok, v);
-        }
-    }
-    const int ntile = tend - tbeg;
-    const int t0 = tbeg + (int)(((int64_t)ns * ntile) / NS), t1 = tbeg + (int)(((int64_t)(ns + 1) * ntile) / NS);
-    float4 wreg[8];
-    auto prefetch_w = [&](int t) {
-        const int j = t * 64 + srow;
-        const float* p = W + (int64_t)min(j, D - 1) * H;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = spart + 4 * i;
-            const bool ok = (j < D) && (c < hc4);
-            const float4 v = *reinterpret_cast<const float4*>(p + (ok ? c * 4 : 0));
-            wreg[i] = sel4(ok, v);
-        }
-    };
-    auto store_w = [&](float* Ws) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = spart + 4 * i;
-            if (c < nc4) *reinterpret_cast<float4*>(&Ws[srow * ldk + c * 4]) = wreg[i];
-        }
-    };
-    float se = 0.f, mism = 0.f;
-    const int rbase = b0 + wv * 32 + 4 * hh;                      // row of accumulator register 0
-    const uint32_t lane_off = (uint32_t)rbase * (uint32_t)D + (uint32_t)l31;
-    if (t0 < t1) {
-        prefetch_w(t0);
-        store_w(Wbuf);
-    }
-    __syncthreads();
-    int cur = 0;
-    // diagnostic stamps (ablate bit 3): shader-clock cycles per phase, summed over all waves, added to
-    // a counter block that nothing else reads (tail of the loss scratch region)
-    const bool stamps = (ablate & 8) != 0;
-    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int i) {
-        if (stamps) {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            ph[i] += now - tprev;
-            tprev = now;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-    auto tile_step = [&](int t, auto edge_tag) __attribute__((always_inline)) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
-        const int j0 = t * 64;
-        const float* Ws = Wbuf + cur * 64 * ldk;
-        // ---- request x for both 32-gene halves (C layout: lane = gene, register = cell)
-        float xv[2][16];
-        float bj[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = j0 + 32 * c + l31;
-            const int colc = EDGE ? min(col, D - 1) : col;
-            bj[c] = bias[colc];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                if (!EDGE) {
-                    const float* xr = xa + ((int64_t)rr * D + j0 + 32 * c);     // wave-uniform base
-                    xv[c][r] = (ablate & 2) ? 0.f : xr[lane_off];
-                } else {
-                    xv[c][r] = xa[(uint32_t)min(rbase + rr, B - 1) * (uint32_t)D + (uint32_t)colc];
-                }
-            }
-        }
-        stamp(0);
-        // ---- z = d10 W^T for 32 cells x 64 genes
-        f32x16 z0 = zero16(), z1 = zero16();
-        {
-            const float* pb = Ws + l31 * ldk + 4 * hh;
-            float4 q0 = *reinterpret_cast<const float4*>(pb);
-            float4 q1 = *reinterpret_cast<const float4*>(pb + 32 * ldk);
-            if (!(ablate & 1))
-#pragma unroll
-            for (int g = 0; g < FZ_KG; ++g) {
-                if (EXACT || g < kg) {
-                    const int gn = EXACT ? ((g + 1 < FZ_KG) ? g + 1 : g) : ((g + 1 < kg) ? g + 1 : g);
-                    const float4 n0 = *reinterpret_cast<const float4*>(pb + 8 * gn);
-                    const float4 n1 = *reinterpret_cast<const float4*>(pb + 32 * ldk + 8 * gn);
-                    const float4 a = afr[g];
-                    z0 = mfma32(a.x, q0.x, z0); z1 = mfma32(a.x, q1.x, z1);
-                    z0 = mfma32(a.y, q0.y, z0); z1 = mfma32(a.y, q1.y, z1);
-                    z0 = mfma32(a.z, q0.z, z0); z1 = mfma32(a.z, q1.z, z1);
-                    z0 = mfma32(a.w, q0.w, z0); z1 = mfma32(a.w, q1.w, z1);
-                    q0 = n0; q1 = n1;
-                }
-            }
-        }
-        if (stamps) { asm volatile("" :: "v"(z0[0]), "v"(z1[15])); }
-        stamp(1);
-        // ---- next weight tile: requested now, lands while the epilogue runs
-        if (t + 1 < t1) prefetch_w(t + 1);
-        stamp(2);
-        // ---- epilogue
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = j0 + 32 * c + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2);
-                const bool ok = !EDGE || ((rbase + rr < B) && (col < D));
-                const float zz = c == 0 ? z0[r] : z1[r];
-                const float xr = fmaxf(zz + bj[c], 0.f);
-                const float e = xr - xv[c][r];
-                const float dzv = (xr > 0.f) ? coef * e : 0.f;
-                if (ok) {
-                    se += e * e;
-                    mism += ((xr > 0.1f) != (xv[c][r] > 0.1f)) ? 1.f : 0.f;
-                    if (!EDGE) {
-                        const int64_t uo = (int64_t)rr * D + j0 + 32 * c;       // wave-uniform
-                        if (xra) (xra + uo)[lane_off] = xr;
-                        if (need_grad && !(ablate & 4)) (dza + uo)[lane_off] = dzv;
-                    } else {
-                        const uint32_t off = (uint32_t)(rbase + rr) * (uint32_t)D + (uint32_t)col;
-                        if (xra) xra[off] = xr;
-                        if (need_grad) dza[off] = dzv;
-                    }
-                }
-            }
-        }
-        stamp(3);
-        if (t + 1 < t1) store_w(Wbuf + (cur ^ 1) * 64 * ldk);
-        lds_barrier();      // LDS only: the dZ11 / x_rec stores of this step stay in flight
-        stamp(4);
-        cur ^= 1;
-    };
-    // interior steps first, then the guarded ones (two loops: the bodies' live ranges do not overlap)
-    const int t_mid = (b0 + 128 > B) ? t0 : max(t0, min(t1, D / 64));
-    for (int t = t0; t < t_mid; ++t) tile_step(t, ScalarTag{});      // ScalarTag::value == false: interior body
-    for (int t = t_mid; t < t1; ++t) tile_step(t, VecTag{});         // VecTag::value == true: edge body
-    if (stamps && lane == 0) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(part + 2 * (size_t)A * n11) ;
-        for (int i = 0; i < 5; ++i) atomicAdd(dbg + i, ph[i]);
-        atomicAdd(dbg + 5, 1ull);
-    }
-    se = wave_sum(se);
-    mism = wave_sum(mism);
-    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mism; }
-    __syncthreads();
-    if (tid == 0) {
-        float* p = part + ((int64_t)arm * n11 + slot_base + (int64_t)blockIdx.x * NS + ns) * 2;
-        p[0] = red[0] + red[2] + red[4] + red[6];
-        p[1] = red[1] + red[3] + red[5] + red[7];
-    }
-}
-
-// =============================================================================================
 // fc11 forward + reconstruction loss + dZ11, staggered with 16-byte global accesses (the default fast path).
-//   z = d10 W11^T by MFMA as in k_fc11_z (d10 fragments stationary in registers, W11 tile double buffered in
-//   LDS), but every 4 x 4 block of the accumulator is transposed inside its lane quad (DPP), after which a lane
+//   z = d10 W11^T by MFMA, "A-stationary": every wave keeps the d10 rows of its 32 cells in registers for the whole
+//   kernel (13 float4 at H = 100) and only the W11 tile moves through LDS (double buffered).  Every 4 x 4 block of the accumulator is transposed inside its lane quad (DPP), after which a lane
 //   holds FOUR CONSECUTIVE GENES of one cell: x is read and dZ11 written 16 B per lane and every instruction
 //   covers whole 128-byte lines (8 cells x 32 genes) -- 8 + 8 vector memory instructions per 64-gene step
-//   instead of 32 + 32 (more than the 63 the vmcnt counter can track, so k_fc11_z's loads stalled at issue).
+//   instead of the 32 + 32 of 4-byte accesses (more than the 63 the vmcnt counter can track: those loads stalled at issue).
 //   A 512-thread workgroup covers 256 cells.  Waves 4-7 run one epilogue behind waves 0-3: on every SIMD one
 //   wave's epilogue (VALU + stores) runs beside its partner's MFMAs instead of both leaving the matrix pipe
 //   idle together.  One barrier per step.
@@ -1720,10 +1386,9 @@ bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs)
            (int64_t)d.B * d.D < ((int64_t)1 << 30);
 }
 
-// true when forward used k_fc11_z + k_gd10_v2 (slab count ks_gd10) rather than a fused kernel (ns_fc11)
+// true when forward used the fast fc11 kernels (d(d10) slab count ks_gd10) rather than the general fused kernel (ns_fc11)
 bool fc11_split_path(const Ctx& c, const float* params, const float* x, int64_t xs) {
-    static const int fused = getenv("MMVAE_FC11_FUSED") ? atoi(getenv("MMVAE_FC11_FUSED")) : 0;
-    return fast_path_ok(c, params, x, xs) && !fused;
+    return fast_path_ok(c, params, x, xs);
 }
 
 int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
@@ -1776,23 +1441,10 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
     const int ldk = rup(d.H, 8) + 4;
     const float coef = (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B;
     const int NS = L.sp.ns_fc11;
-    static const int fused = getenv("MMVAE_FC11_FUSED") ? atoi(getenv("MMVAE_FC11_FUSED")) : 0;   // A/B timing
-    if (fused) {
-        hipError_t e0 = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
-        if (e0 != hipSuccess) { set_error("memset: %s", hipGetErrorString(e0)); return MMVAE_E_LAUNCH; }
-        const size_t shm = (size_t)(64 * ldk * 2 + 64 * F11_LDZ2 + 8) * sizeof(float);
-        static const int ablate = getenv("MMVAE_ABLATE") ? atoi(getenv("MMVAE_ABLATE")) : 0;
-        hipLaunchKernelGGL(k_fc11_v2, dim3(L.nblk64, NS, d.A), dim3(256), shm, c.stream, c.ws + L.Dk[4], params,
-                           c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11, c.ws + L.GD10_slab,
-                           c.ws + L.fc11_part, coef, need_grad, d.A, d.B, d.D, d.H, NS, ldk, ablate, L.n11);
-        HIP_LAUNCH_CHECK("k_fc11_v2");
-        return 0;
-    }
     // train step at fc_dim 100: d(d10) is folded into the fc11 kernel (k_fc11_zg), whose gene split count equals the
     // d(d10) kernel's so that the decoder backward sums the same number of slabs whichever forward ran
     static const int zg_off = getenv("MMVAE_FC11_ZG") ? (atoi(getenv("MMVAE_FC11_ZG")) == 0) : 0;   // A/B timing
-    static const int zold_ = getenv("MMVAE_FC11_ZOLD") ? atoi(getenv("MMVAE_FC11_ZOLD")) : 0;
-    const bool use_zg = need_grad && !x_rec && d.H == 100 && !zg_off && zold_ == 0 &&
+    const bool use_zg = need_grad && !x_rec && d.H == 100 && !zg_off &&
                         (int64_t)cdiv(d.B, 256) * L.sp.ks_gd10 <= L.n11;
     if ((which & 1) && use_zg) {
         hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
@@ -1817,8 +1469,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         const int ntall = cdiv(d.D, 64);
         const int kgv = rup(d.H, 8) / 8;
         static const int ablz = getenv("MMVAE_ABLATE_Z") ? atoi(getenv("MMVAE_ABLATE_Z")) : 0;   // timing experiments
-        static const int zold = getenv("MMVAE_FC11_ZOLD") ? atoi(getenv("MMVAE_FC11_ZOLD")) : 0;  // A/B timing
-        if (zold != 1) {
+        {
             // one 512-thread workgroup per CU: split the gene range so that the grid fills the chip once
             const int nb = cdiv(d.B, 256);
             int nsz = max(1, min(min(256 / max(nb * d.A, 1), 16), ntall));
@@ -1855,18 +1506,6 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
 #undef FZT_LAUNCH
 #undef FZT_ARGS
             HIP_LAUNCH_CHECK("k_fc11_zt");
-        } else {
-            const size_t shm = (size_t)(2 * 64 * ldk + 8) * sizeof(float);
-            const int nball = cdiv(d.B, 128);
-            const int nsplit = max(1, min(NS, ntall));
-            dim3 grid(nball, nsplit, d.A);
-#define FZ_ARGS c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,        \
-                c.ws + L.fc11_part, L.n11, 0, coef, need_grad, d.A, d.B, d.D, d.H, ldk, 0, 0, ntall, ablz
-            if (kgv == 13) hipLaunchKernelGGL((k_fc11_z<13, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-            else if (kgv == 16) hipLaunchKernelGGL((k_fc11_z<16, true>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-            else hipLaunchKernelGGL((k_fc11_z<16, false>), grid, dim3(256), shm, c.stream, FZ_ARGS);
-#undef FZ_ARGS
-            HIP_LAUNCH_CHECK("k_fc11_z");
         }
     }
     if (need_grad && (which & 2)) {

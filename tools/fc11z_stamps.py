@@ -22,12 +22,8 @@ dbg.zero_(); torch.cuda.synchronize()
 eng.debug_stage(10, hyper, noise, m._flat, x, 0, m._flat_grad)
 torch.cuda.synchronize()
 v = dbg.cpu().numpy()
-ws = os.environ.get("MMVAE_FC11_ZOLD", "0") == "0"
 names = ["x-load issue", "MFMA tile (104)", "W prefetch issue", "epilogue", "W->LDS", "barrier wait"]
-cnames = ["MFMA tile (104)", "z -> LDS issue", "LDS drain + barrier", "-", "-", "-"]
-mnames = ["W prefetch issue", "x load issue", "epilogue", "W -> LDS", "barrier wait", "-"]
-for label, o in ((("compute waves 0-3" if ws else "early waves 0-3"), 0), (("memory waves 4-7" if ws else "late waves 4-7"), 8)):
-    if ws: names = cnames if o == 0 else mnames
+for label, o in (("early waves 0-3", 0), ("late waves 4-7", 8)):
     nw = max(int(v[o + 6]), 1); tot = v[o:o + 6].sum()
     print(label, "waves", nw)
     for n_, c_ in zip(names, v[o:o + 6]):
