@@ -36,22 +36,23 @@ namespace mmvae {
 
 static inline int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
 
-constexpr int AG_LD = 36;   // LDS row stride of a 32-wide K tile (+4: conflict-free b128 fragment reads)
 
 // grid (tiles_n * tiles_m), 256 threads = 2 x 2 waves of (BM/2) x (BN/2).  lda, ldw, ldc multiples of 4; rows of A
 // beyond M are clamped (recomputed, never stored); columns N <= col < ldc of C are written as zeros (they are the K
 // padding of the next layer).  BM, BN in {64, 128}: the launcher takes the largest tile that still gives every CU two
 // workgroups (a 128 x 128 grid of the 5000 x 1000 layers is 320 workgroups for 256 CUs: 74 TF against 91-106 TF for
 // the layers with thousands of tiles).
-template <int BM, int BN, bool RELU, bool AFFINE>
+template <int BM, int BN, int BK, bool RELU, bool AFFINE>
 __global__ __launch_bounds__(256, 3) void k_aug_gemm(const float* __restrict__ Ain, int lda, int M,
                                                      const float* __restrict__ W, int ldw, int N, int K,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      float* __restrict__ Cout, int ldc, int tiles_n, int tiles_m) {
     constexpr int TI = BM / 64, TJ = BN / 64;      // 32 x 32 accumulators per wave
-    constexpr int LA = BM / 32, LB = BN / 32;      // float4 loads per thread and K tile
-    __shared__ __attribute__((aligned(16))) float As[BM * AG_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * AG_LD];
+    constexpr int TPR = BK / 4, RPP = 256 / TPR;   // threads per tile row (one float4 each), rows per pass
+    constexpr int LA = BM / RPP, LB = BN / RPP;    // float4 loads per thread and K tile
+    constexpr int LD = BK + 4;                     // LDS row stride: LD / 4 odd, conflict-free b128 fragment reads
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
     // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x the tiles [x * per, (x + 1) * per)
     const int nwg = tiles_n * tiles_m;
     int wg = blockIdx.x;
@@ -61,17 +62,17 @@ __global__ __launch_bounds__(256, 3) void k_aug_gemm(const float* __restrict__ A
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
-    const int r0 = tid >> 3, c4 = tid & 7;
-    const int nkt = cdiv(K, 32);
+    const int r0 = tid / TPR, c4 = tid % TPR;
+    const int nkt = cdiv(K, BK);
 
     const float* pa[LA];
     const float* pb[LB];
     bool okb[LB];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) pa[i] = Ain + (int64_t)min(m0 + r0 + 32 * i, M - 1) * lda + c4 * 4;
+    for (int i = 0; i < LA; ++i) pa[i] = Ain + (int64_t)min(m0 + r0 + RPP * i, M - 1) * lda + c4 * 4;
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int rb = n0 + r0 + 32 * i;
+        const int rb = n0 + r0 + RPP * i;
         okb[i] = rb < N;
         pb[i] = W + (int64_t)min(rb, N - 1) * ldw + c4 * 4;
     }
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(256, 3) void k_aug_gemm(const float* __restrict__ A
 
     float4 ra4[LA], rb4[LB];
     auto load_tiles = [&](int kt) {
-        const bool colok = kt * 32 + c4 * 4 < K;     // K padded to 4: a float4 is all in or all out
-        const int koff = colok ? kt * 32 : 0;
+        const bool colok = kt * BK + c4 * 4 < K;     // K padded to 4: a float4 is all in or all out
+        const int koff = colok ? kt * BK : 0;
 #pragma unroll
         for (int i = 0; i < LA; ++i) ra4[i] = *reinterpret_cast<const float4*>(pa[i] + koff);
 #pragma unroll
@@ -102,20 +103,20 @@ __global__ __launch_bounds__(256, 3) void k_aug_gemm(const float* __restrict__ A
     load_tiles(0);
     for (int kt = 0; kt < nkt; ++kt) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(r0 + 32 * i) * AG_LD + c4 * 4]) = ra4[i];
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(r0 + RPP * i) * LD + c4 * 4]) = ra4[i];
 #pragma unroll
-        for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * i) * AG_LD + c4 * 4]) = rb4[i];
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + RPP * i) * LD + c4 * 4]) = rb4[i];
         __syncthreads();
         if (kt + 1 < nkt) load_tiles(kt + 1);
-        const float* la = As + (wm * (BM / 2) + l31) * AG_LD + 4 * hh;
-        const float* lb = Bs + (wn * (BN / 2) + l31) * AG_LD + 4 * hh;
+        const float* la = As + (wm * (BM / 2) + l31) * LD + 4 * hh;
+        const float* lb = Bs + (wn * (BN / 2) + l31) * LD + 4 * hh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < BK / 8; ++g) {
             float4 a[TI], q[TJ];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) a[i] = *reinterpret_cast<const float4*>(la + 32 * i * AG_LD + 8 * g);
+            for (int i = 0; i < TI; ++i) a[i] = *reinterpret_cast<const float4*>(la + 32 * i * LD + 8 * g);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) q[j] = *reinterpret_cast<const float4*>(lb + 32 * j * AG_LD + 8 * g);
+            for (int j = 0; j < TJ; ++j) q[j] = *reinterpret_cast<const float4*>(lb + 32 * j * LD + 8 * g);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -360,14 +361,14 @@ __global__ __launch_bounds__(64 * AL_NW) void k_aug_latent(const float* __restri
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static void aug_gemm_launch(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw,
                             int N, int K, const float* sc, const float* sh, float* C, int ldc, int ncols) {
     const int tiles_n = cdiv(ncols, BN), tiles_m = cdiv(M, BM);
     dim3 grid(tiles_n * tiles_m), block(256);
-    if (relu) hipLaunchKernelGGL((k_aug_gemm<BM, BN, true, true>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
-    else if (affine) hipLaunchKernelGGL((k_aug_gemm<BM, BN, false, true>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
-    else hipLaunchKernelGGL((k_aug_gemm<BM, BN, false, false>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
+    if (relu) hipLaunchKernelGGL((k_aug_gemm<BM, BN, BK, true, true>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
+    else if (affine) hipLaunchKernelGGL((k_aug_gemm<BM, BN, BK, false, true>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
+    else hipLaunchKernelGGL((k_aug_gemm<BM, BN, BK, false, false>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
 }
 
 static int aug_gemm(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* pk,
@@ -384,12 +385,16 @@ static int aug_gemm(hipStream_t s, bool relu, bool affine, const float* A, int l
     else if (count(64, 128) >= 512) pick = 12;
     else if (count(128, 64) >= 512) pick = 21;
     if (force) pick = force;
+    // K tile 32.  BK = 64 (half the barriers, twice the LDS and prefetch registers) measured slower: 2.36 against 2.23 ms
+    // per call at the benchmark shape; so did double-buffered LDS tiles.  The barrier is not what limits this kernel.
+#define AG_ARGS s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols
     switch (pick) {
-        case 22: aug_gemm_launch<128, 128>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
-        case 12: aug_gemm_launch<64, 128>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
-        case 21: aug_gemm_launch<128, 64>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
-        default: aug_gemm_launch<64, 64>(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.K, sc, sh, C, ldc, ncols); break;
+        case 22: aug_gemm_launch<128, 128, 32>(AG_ARGS); break;
+        case 12: aug_gemm_launch<64, 128, 32>(AG_ARGS); break;
+        case 21: aug_gemm_launch<128, 64, 32>(AG_ARGS); break;
+        default: aug_gemm_launch<64, 64, 32>(AG_ARGS); break;
     }
+#undef AG_ARGS
     HIP_LAUNCH_CHECK("k_aug_gemm");
     return 0;
 }
