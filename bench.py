@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="one rank, but through the data-parallel step (RCCL init, all-reduce(AVG) of the flat gradients, "
+                         "separate Adam launch): exercises the N > 1 code path on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,9 +123,22 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.zeros(8, device=dev)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import distributed_vae_amd  # noqa: F401
     from distributed_vae_amd import _native as N
@@ -147,9 +163,12 @@ def main():
 
     def step(i):
         xs = batches[i % nb].expand(A, -1, -1)
-        if world > 1:
+        if world > 1 or args.rehearse_dp:
             buf = model.fused_train_step(xs, 1.0, opt, do_adam=False)
-            DD.allreduce_mean_(model.flat_grad())
+            if world > 1:
+                DD.allreduce_mean_(model.flat_grad())
+            else:
+                dist.all_reduce(model.flat_grad(), op=dist.ReduceOp.AVG)
             opt.step()
             return buf
         return model.fused_train_step(xs, 1.0, opt, do_adam=True)
@@ -216,7 +235,7 @@ def main():
         out["data_path"] = data_path(data, B, D)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.rehearse_dp:
         dist.destroy_process_group()
 
 
