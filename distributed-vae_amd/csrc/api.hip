@@ -255,9 +255,13 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
                        float grad_scale, float* grads, const AdamHost* adam = nullptr, bool wait_loss = false) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
-    // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain
+    // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain.  Where it is
+    // forked matters: beside it the latent backward takes 82 us instead of 28 and the decoder chain 70 instead of 55.
+    // MMVAE_DW11_AT: 0 = fork at the start of backward, 1 = after the decoder chain, 2 = after the latent backward.
+    static const int dw11_at = getenv("MMVAE_DW11_AT") ? atoi(getenv("MMVAE_DW11_AT")) : 0;
     bool forked = false;
-    if (fast && g_side) {
+    const bool use_side = fast && g_side;
+    auto fork_dw11 = [&]() -> int {
         if (!g_ev_fork) {
             if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -265,18 +269,21 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
                 return MMVAE_E_LAUNCH;
             }
         }
-        Ctx cs = c;
-        cs.stream = g_side;
+        Ctx cs2 = c;
+        cs2.stream = g_side;
         if (hipEventRecord(g_ev_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess) {
             set_error("stream fork failed");
             return MMVAE_E_LAUNCH;
         }
-        if ((rc = launch_dw_big_fast(cs, x, xs, 2))) return rc;
+        if (int r = launch_dw_big_fast(cs2, x, xs, 2)) return r;
         if (hipEventRecord(g_ev_join, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
         forked = true;
-    }
+        return 0;
+    };
+    if (use_side && dw11_at == 0 && (rc = fork_dw11())) return rc;
     const int nslab = fc11_split_path(c, params, x, xs) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11;
     if ((rc = launch_chain_bwd_dec(c, params, nslab))) return rc;
+    if (use_side && dw11_at == 1 && (rc = fork_dw11())) return rc;
     // Experiment kept behind a switch (default off): the small-layer dW GEMMs (occupancy-bound, 34 TF) on the side
     // stream behind dW11 -- decoder layers beside the encoder backward chain, encoder side beside the dW1 GEMM.
     // Measured at the benchmark shape: 1.010 ms per step against 1.006 ms with them after dW1 on the main stream
@@ -300,6 +307,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     // T (sum of G log c, from the loss finalisation) is first needed here
     if (wait_loss && hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
+    if (use_side && dw11_at >= 2 && (rc = fork_dw11())) return rc;
     for (int layer = 5; layer >= 2; --layer)
         if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
