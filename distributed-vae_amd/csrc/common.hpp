@@ -282,6 +282,7 @@ constexpr int LAT_ROWS = 48;
 // measured faster in the step (61 against 70 us) although slower alone (32 against 24 us).
 constexpr int LAT_ROWS_BWD = 16;
 constexpr int LATB_NW = 8;    // waves per workgroup of the latent backward kernel
+constexpr int LATB_NR = LAT_ROWS_BWD / LATB_NW;   // cells per wave, processed side by side
 
 template <bool VEC, int NT>
 __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int PR, int W,

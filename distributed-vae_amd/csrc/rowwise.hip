@@ -621,20 +621,51 @@ __global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, co
     }
     float s1 = 0.f, s2 = 0.f;   // BN5 backward sums for column `lane` (< L)
 
-    for (int row = wv; row < LAT_ROWS_BWD; row += LATB_NW) {
-        const int b = b0 + row;
-        if (b >= B) break;
+    // The wave's LATB_NR cells side by side, every global load of both issued before the first use: beside the dW11
+    // GEMM of the side stream this kernel's 4-byte loads queue behind the GEMM's in the CU's in-order memory pipe
+    // (82 us in the step against 28 us alone when each cell's loads were issued and awaited one after the other).
+    constexpr int NR = LATB_NR;
+    int bb[NR];
+    bool okr[NR];
+    float gs_l[NR], mu_l[NR], lv_l[NR], sg_l[NR], xlow_l[NR];
+    float cc[NR][CPL], ys[NR][CPL], gz[NR][CPL], cp[NR][CPL], call[NR][MMVAE_MAX_ARMS][CPL];
+    const bool vcol[CPL] = {lane < C, lane + 64 < C};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        bb[r] = b0 + wv + LATB_NW * r;
+        okr[r] = bb[r] < B;                         // wave-uniform
+        const int64_t b = min(bb[r], B - 1);        // cells beyond the batch recompute the last cell; nothing is stored
+        gs_l[r] = lane < S ? ws[a.GZIN + (ab + b) * (C + S) + C + lane] : 0.f;
+        mu_l[r] = lane < S ? ws[a.MU + (ab + b) * S + lane] : 0.f;
+        lv_l[r] = lane < S ? ws[a.LV + (ab + b) * S + lane] : 0.f;
+        sg_l[r] = lane < S ? ws[a.MS + (ab + b) * 2 * S + S + lane] : 0.f;
+        xlow_l[r] = lane < L ? ws[a.XLOW + (ab + b) * L + lane] : 0.f;
+#pragma unroll
+        for (int t = 0; t < CPL; ++t) {
+            const int col = lane + 64 * t;
+            const int64_t o = (ab + b) * C + col;
+            cc[r][t] = vcol[t] ? ws[a.CC + o] : 0.f;
+            ys[r][t] = vcol[t] ? ws[a.YSOFT + o] : 0.f;
+            cp[r][t] = vcol[t] ? ws[a.CPROB + o] : 0.f;
+            gz[r][t] = vcol[t] ? ws[a.GZIN + (ab + b) * (C + S) + col] : 0.f;
+#pragma unroll
+            for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+                call[r][aa][t] = (aa < A && vcol[t]) ? ws[a.CC + ((int64_t)aa * B + b) * C + col] : 1.f;
+        }
+    }
+    const float inv_temp = 1.f / a.temp, inv_tau = 1.f / a.tau, inv_bm1 = 1.f / (float)(B - 1);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int b = min(bb[r], B - 1);
         // ---- state head backward (lanes < S)
         float gms = 0.f;   // lane o < 2S: d loss / d MS[o]
         {
             float gmu = 0.f, gsig = 0.f;
             if (lane < S) {
-                float gs = ws[a.GZIN + (ab + b) * (C + S) + C + lane];
+                float gs = gs_l[r];
                 if (a.training && a.s_drop > 0.f)
                     gs = state_keep(nz, arm, B, S, b, lane) ? gs / (1.f - a.s_drop) : 0.f;
-                const float mu = ws[a.MU + (ab + b) * S + lane];
-                const float lv = ws[a.LV + (ab + b) * S + lane];
-                const float sg = ws[a.MS + (ab + b) * 2 * S + S + lane];
+                const float mu = mu_l[r], lv = lv_l[r], sg = sg_l[r];
                 const float var = 1.f / (1.f + expf(-sg));
                 const float U = state_u(nz, arm, B, S, b, lane);
                 const float elv = expf(lv);
@@ -646,7 +677,7 @@ __global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, co
             const float gsig_sh = __shfl(gsig, (lane - S) & 63, 64);   // lane S+s takes lane s's gsig
             if (lane < S) gms = gmu;
             else if (lane < 2 * S) gms = gsig_sh;
-            if (lane < 2 * S) ws[a.GMS + (ab + b) * 2 * S + lane] = gms;
+            if (okr[r] && lane < 2 * S) ws[a.GMS + (ab + b) * 2 * S + lane] = gms;
         }
         // ---- gy = gms [Wmu; Wsigma]
         float gxl = 0.f, gcs[CPL] = {0.f, 0.f};
@@ -655,25 +686,25 @@ __global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, co
             const float* w = Wms + (int64_t)o * (L + C);
             if (lane < L) gxl += go * w[lane];
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) gcs[t] += go * w[L + col]; }
+            for (int t = 0; t < CPL; ++t) if (vcol[t]) gcs[t] += go * w[L + lane + 64 * t];
         }
         // ---- gradient w.r.t. the sample, through the Gumbel softmax to c
-        float cc[CPL], lc[CPL], gc[CPL], ys[CPL], usum[CPL] = {0.f, 0.f};
+        float lc[CPL], gc[CPL], usum[CPL] = {0.f, 0.f}, rcc[CPL];
         float dot = 0.f;
 #pragma unroll
         for (int t = 0; t < CPL; ++t) {
-            const int col = lane + 64 * t;
-            cc[t] = lc[t] = gc[t] = ys[t] = 0.f;
-            if (col < C) {
-                const int64_t o = (ab + b) * C + col;
-                cc[t] = ws[a.CC + o];
-                lc[t] = logf(cc[t] + eps);
-                ys[t] = ws[a.YSOFT + o];
-                gcs[t] += ws[a.GZIN + (ab + b) * (C + S) + col];
-                dot += ys[t] * gcs[t];
+            lc[t] = gc[t] = 0.f;
+            rcc[t] = 1.f / (cc[r][t] + eps);
+            if (vcol[t]) {
+                gcs[t] += gz[r][t];
+                dot += ys[r][t] * gcs[t];
 #pragma unroll
                 for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
-                    if (aa < A) usum[t] += logf(ws[a.CC + ((int64_t)aa * B + b) * C + col] + eps) * ivall[aa][t];
+                    if (aa < A) {
+                        const float l_aa = logf(call[r][aa][t] + eps);
+                        usum[t] += l_aa * ivall[aa][t];
+                        if (aa == arm) lc[t] = l_aa;      // this arm's own log c: the same value, computed once
+                    }
             }
         }
         if (a.eval_flag) {
@@ -682,54 +713,50 @@ __global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, co
         } else {
             dot = wave_sum(dot);
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) gc[t] = (ys[t] * (gcs[t] - dot) / a.temp) / (cc[t] + eps);
+            for (int t = 0; t < CPL; ++t) gc[t] = (ys[r][t] * (gcs[t] - dot) * inv_temp) * rcc[t];
         }
         // ---- coupling / entropy terms on c (nn_model.py:558-569)
         float dot2 = 0.f;
 #pragma unroll
         for (int t = 0; t < CPL; ++t) {
-            const int col = lane + 64 * t;
-            if (col < C) {
+            if (vcol[t]) {
                 const float G = coefG * ((float)A * lc[t] * ivm[t] - usum[t]);
-                gc[t] += (float)(A - 1) * (lc[t] + cc[t] / (cc[t] + eps)) * invB;
-                gc[t] += G * ivm[t] / (cc[t] + eps);
-                gc[t] += (Tk[t] * (-0.5f) * ivm[t] * ivm[t] * ivm[t]) * 2.f * (cc[t] - cmean[t]) / (float)(B - 1);
-                dot2 += cc[t] * gc[t];
+                gc[t] += (float)(A - 1) * (lc[t] + cc[r][t] * rcc[t]) * invB;
+                gc[t] += G * ivm[t] * rcc[t];
+                gc[t] += (Tk[t] * (-0.5f) * ivm[t] * ivm[t] * ivm[t]) * 2.f * (cc[r][t] - cmean[t]) * inv_bm1;
+                dot2 += cc[r][t] * gc[t];
             } else {
                 gc[t] = 0.f;
             }
         }
         dot2 = wave_sum(dot2);
         // ---- double softmax backward
-        float gq[CPL], cp[CPL], dot3 = 0.f;
+        float gq[CPL], dot3 = 0.f;
 #pragma unroll
         for (int t = 0; t < CPL; ++t) {
-            const int col = lane + 64 * t;
-            gq[t] = cc[t] * (gc[t] - dot2) / a.tau;
-            cp[t] = col < C ? ws[a.CPROB + (ab + b) * C + col] : 0.f;
-            dot3 += cp[t] * gq[t];
+            gq[t] = cc[r][t] * (gc[t] - dot2) * inv_tau;
+            dot3 += cp[r][t] * gq[t];
         }
         dot3 = wave_sum(dot3);
         float gzc[CPL];
 #pragma unroll
         for (int t = 0; t < CPL; ++t) {
-            const int col = lane + 64 * t;
-            gzc[t] = cp[t] * (gq[t] - dot3);
-            if (col < C) ws[a.GZC + (ab + b) * C + col] = gzc[t];
+            gzc[t] = cp[r][t] * (gq[t] - dot3);
+            if (okr[r] && vcol[t]) ws[a.GZC + (ab + b) * C + lane + 64 * t] = gzc[t];
         }
         // ---- g5 = gy[:, :L] + gzc Wc
         float g5 = 0.f;
         for (int k = 0; k < L; ++k) {
             float p = 0.f;
 #pragma unroll
-            for (int t = 0; t < CPL; ++t) { const int col = lane + 64 * t; if (col < C) p += gzc[t] * WcT[k * C + col]; }
+            for (int t = 0; t < CPL; ++t) if (vcol[t]) p += gzc[t] * WcT[k * C + lane + 64 * t];
             p = wave_sum(p);
             if (lane == k) g5 = gxl + p;
         }
-        if (lane < L) {
+        if (okr[r] && lane < L) {
             ws[a.G5 + (ab + b) * L + lane] = g5;
             s1 += g5;
-            s2 += g5 * ws[a.XLOW + (ab + b) * L + lane];
+            s2 += g5 * xlow_l[r];
         }
     }
     sh_s[wv][0][lane] = s1;
