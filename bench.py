@@ -341,6 +341,24 @@ def augmenter_forward(args, batches, A, B, D, with_cpu):
            "workload": f"Augmenter_smartseq eval forward, D={D}, n_dim={ND}, noise {NZ}, latent {Z}, x shared by {A} arms",
            "gflop_executed": fl_exec / 1e9, "gflop_reference_pattern": fl_ref / 1e9,
            "tflops": fl_exec / ms / 1e9, "frac_of_fp32_mfma_peak": fl_exec / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+    # the production loop with augmentation: augmenter of batch i+1 on a side stream beside train step i
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    tr = cpl_mixVAE(saving_folder="", device=batches[0].device, save_flag=False)
+    tr.init_model(n_categories=92, state_dim=2, input_dim=D, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A)
+    tr.set_augmenter(net)
+    for pipe in (False, True):
+        tr.pipeline_augmenter = pipe
+        for _ in tr.epoch_steps(batches[:3]):
+            pass
+        e0.record()
+        n = 0
+        for _ in range(2):
+            for _b in tr.epoch_steps(batches):
+                n += 1
+        e1.record()
+        e1.synchronize()
+        out["augmented_step_ms_pipelined" if pipe else "augmented_step_ms_back_to_back"] = e0.elapsed_time(e1) / n
+    out["augmented_cells_per_s"] = B / out["augmented_step_ms_pipelined"] * 1e3
     if with_cpu:
         from oracle import augmenter as OA
         sd = OA.random_state_dict(NZ, Z, D, ND, seed=1)

@@ -134,3 +134,32 @@ def test_trainer_step_with_augmenter_matches_manual_composition():
     opt = FusedAdam(t.model, lr=1e-3)
     buf2 = t.model.fused_train_step(xa, t.temp, opt, do_adam=True)
     assert torch.equal(buf, buf2)
+
+
+def test_pipelined_epoch_equals_unpipelined():
+    """cpl_mixVAE.epoch_steps with an augmenter runs the augmenter of batch i+1 on a side stream beside step i: the loss
+    vectors and the final parameters are bit-identical to the back-to-back loop (same draws in the same order)."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    A, D, C = 2, 128, 6
+    NZ, Z, ND = 8, 4, 40
+    sd_aug = OA.random_state_dict(NZ, Z, D, ND, seed=2)
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.rand(64, D, generator=g),) for _ in range(5)]
+    res = []
+    for pipe in (True, False):
+        torch.manual_seed(123)
+        t = cpl_mixVAE(saving_folder="", device=DEV, save_flag=False)
+        t.init_model(n_categories=C, state_dim=2, input_dim=D, fc_dim=16, lowD_dim=4, x_drop=0.5, s_drop=0.0, n_arm=A)
+        netA = Augmenter_smartseq(NZ, Z, D, ND)
+        netA.load_state_dict(sd_aug)
+        t.set_augmenter(netA)
+        t.pipeline_augmenter = pipe
+        t.model._noise_seed, t.model._noise_offset = 9, 0
+        torch.manual_seed(77)                                   # the augmenter's torch.randn draws
+        bufs = [b.clone() for b in t.epoch_steps(batches)]
+        torch.cuda.synchronize()
+        res.append((torch.stack(bufs).cpu(), t.model.flat_parameters().clone().cpu()))
+    assert res[0][0].shape[0] == 5
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])

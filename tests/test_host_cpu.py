@@ -146,3 +146,33 @@ def test_philox_host_reference_vector():
     assert philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_widened_entry_points_validate_arguments_on_the_host():
+    """The consensus / augmenter / data-path entry points reject bad arguments before touching the GPU (so this runs
+    without one), with the documented codes."""
+    L = N.lib()
+    # consensus
+    assert L.mmvae_consensus(None, 1, 4, None, None, None) == -1
+    buf = (C.c_int64 * 4)()
+    out = (C.c_double * 1)()
+    assert L.mmvae_consensus(buf, 1, 200, None, out, None) == -2          # C > 128
+    assert b"128" in L.mmvae_last_error_string()
+    assert L.mmvae_confmat_accumulate(None, 2, 10, 4, buf, None) == -1
+    assert L.mmvae_classify(None, 10, 4, None, None) == -1
+    # augmenter
+    ok = N.AugDims(2, 100, 5000, 1000, 500, 100, 10, 50)
+    assert L.mmvae_aug_packed_floats(C.byref(ok)) > 5000 * 1000 * 2
+    assert L.mmvae_aug_workspace_bytes(C.byref(ok), 1) < L.mmvae_aug_workspace_bytes(C.byref(ok), 0)
+    assert L.mmvae_aug_packed_floats(C.byref(N.AugDims(2, 100, 5002, 1000, 500, 100, 10, 50))) == 0      # D % 4
+    assert L.mmvae_aug_packed_floats(C.byref(N.AugDims(2, 100, 5000, 1000, 1000, 200, 10, 50))) == 0     # n/5 > 128
+    assert L.mmvae_aug_packed_floats(C.byref(N.AugDims(2, 100, 400, 80, 640, 128, 64, 128))) == 0        # LDS
+    assert L.mmvae_aug_pack(C.byref(ok), None, None, None) == -1
+    assert L.mmvae_augment(C.byref(ok), None, None, 0, None, None, 0.1, None, 0, None, None, None) == -1
+    # data path
+    assert L.mmvae_gather_rows(None, 8, 4, None, 2, 8, None, None) == -1
+    # eval labels: needs eval mode
+    d = N.Dims(2, 32, 64, 16, 4, 6, 2)
+    h = N.Hyper(0.005, 1.0, 1.0, 1.0, 1e-8, 0.01, 0.5, 0.0, 0, 1, 0)     # training = 1
+    one = (C.c_float * 4)()
+    assert L.mmvae_eval_classify(C.byref(d), C.byref(h), one, one, one, 0, one, 16, one, None, None) in (-2, -4)
