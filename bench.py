@@ -232,7 +232,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_eval:
         out["eval_consensus"] = eval_consensus(args, model, batches, A, B, D, H, L, C, S, not args.no_cpu_baseline)
         out["augmenter"] = augmenter_forward(args, batches, A, B, D, not args.no_cpu_baseline)
-        out["data_path"] = data_path(data, B, D)
+        out["data_path"] = data_path(data, A, B, D)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or args.rehearse_dp:
@@ -291,7 +291,7 @@ def eval_consensus(args, model, batches, A, B, D, H, L, C, S, with_cpu):
     return out
 
 
-def data_path(data, B, D):
+def data_path(data, A, B, D):
     """Scope row (f)-3: assembling a shuffled batch from the HBM-resident matrix (mmvae_gather_rows) -- what replaces
     DataLoader workers + pinned memory + the H2D copy of the reference (utils/dataloader.py:114-132)."""
     from distributed_vae_amd import _native as N
@@ -308,9 +308,29 @@ def data_path(data, B, D):
     e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     by = 2.0 * B * D * 4
-    return {"kernel": "k_gather_rows", "us_per_batch": ms * 1e3, "algorithmic_GBs": by / ms / 1e6,
-            "frac_of_hbm_peak": by / ms / 1e6 / PEAK_HBM_GBS, "bytes_per_batch": by,
-            "note": "a host-resident batch would cost B*D*4 bytes over PCIe (~1.6 ms at 63 GB/s) per step instead"}
+    res = {"kernel": "k_gather_rows", "us_per_batch": ms * 1e3, "algorithmic_GBs": by / ms / 1e6,
+           "frac_of_hbm_peak": by / ms / 1e6 / PEAK_HBM_GBS, "bytes_per_batch": by,
+           "note": "a host-resident batch would cost B*D*4 bytes over PCIe (~1.6 ms at 63 GB/s) per step instead"}
+    # a shuffled epoch from the device-resident loader through the trainer: the gather of batch i+1 on the side stream
+    # beside step i (pipelined) against gather-then-step
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    from distributed_vae_amd.utils.dataloader import DeviceLoader
+    tr = cpl_mixVAE(saving_folder="", device=data.device, save_flag=False)
+    tr.init_model(n_categories=92, state_dim=2, input_dim=D, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A)
+    ld = DeviceLoader(data, torch.arange(data.shape[0]), B, True, True, seed=546)
+    for pipe in (False, True):
+        tr.pipeline = pipe
+        for _ in tr.epoch_steps(ld):
+            pass
+        e0.record()
+        n = 0
+        for _ in range(3):
+            for _b in tr.epoch_steps(ld):
+                n += 1
+        e1.record()
+        e1.synchronize()
+        res["shuffled_epoch_ms_per_step_pipelined" if pipe else "shuffled_epoch_ms_per_step_back_to_back"] = e0.elapsed_time(e1) / n
+    return res
 
 
 def augmenter_forward(args, batches, A, B, D, with_cpu):
@@ -347,7 +367,7 @@ def augmenter_forward(args, batches, A, B, D, with_cpu):
     tr.init_model(n_categories=92, state_dim=2, input_dim=D, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A)
     tr.set_augmenter(net)
     for pipe in (False, True):
-        tr.pipeline_augmenter = pipe
+        tr.pipeline = pipe
         for _ in tr.epoch_steps(batches[:3]):
             pass
         e0.record()

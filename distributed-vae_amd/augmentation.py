@@ -100,9 +100,10 @@ class Augmenter_smartseq(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     @torch.no_grad()
-    def forward(self, x, batched, scale=1.0):
+    def forward(self, x, batched, scale=1.0, out=None):
         """udagan.py:281-329 in eval mode.  batched: x is [A, B, D] (typically ``x.expand(A, -1, -1)``), returns
-        ``(s [A,B,latent], x_aug [A,B,D])``; otherwise x is [B, D] and the leading axis is dropped."""
+        ``(s [A,B,latent], x_aug [A,B,D])``; otherwise x is [B, D] and the leading axis is dropped.  ``out``: optional
+        preallocated ``(s, x_aug)`` float32 device tensors of those shapes (the trainer's pipeline reuses a ring of them)."""
         if self.training:
             raise NotImplementedError("the HIP augmenter implements eval mode only: the trainer runs netA.eval() "
                                       "(cpl_mixvae.py:184)")
@@ -132,8 +133,13 @@ class Augmenter_smartseq(nn.Module):
         need = int(N.lib().mmvae_aug_workspace_bytes(C.byref(dims), int(xs == 0)))
         if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != xt.device:
             self._ws = torch.empty(need // 4, dtype=torch.float32, device=xt.device)
-        s = torch.empty(A, B, Z, dtype=torch.float32, device=xt.device)
-        out = torch.empty(A, B, D, dtype=torch.float32, device=xt.device)
+        if out is not None:
+            s, out = out
+            assert s.shape == (A, B, Z) and out.shape == (A, B, D) and s.is_contiguous() and out.is_contiguous()
+            assert s.dtype == out.dtype == torch.float32 and out.device == xt.device
+        else:
+            s = torch.empty(A, B, Z, dtype=torch.float32, device=xt.device)
+            out = torch.empty(A, B, D, dtype=torch.float32, device=xt.device)
         N.check(N.lib().mmvae_augment(C.byref(dims), N._ptr(self._packed), N._ptr(xt), xs, N._ptr(z0), N._ptr(eps),
                                       float(scale), N._ptr(self._ws), self._ws.numel() * 4, N._ptr(s), N._ptr(out),
                                       N._stream()), "mmvae_augment")

@@ -123,8 +123,7 @@ class cpl_mixVAE:
         self.models = []
         self.device = get_device(device)
         self.aug_model, self.aug_param, self.netA = None, None, None
-        self._aug_stream = None
-        self.pipeline_augmenter = os.environ.get("MMVAE_AUG_PIPELINE", "1") != "0"
+        self.pipeline = os.environ.get("MMVAE_PIPELINE", "1") != "0"   # see epoch_steps
         if aug_file:                                            # cpl_mixvae.py:182-186
             from .augmentation import mk_augmenter
             self.aug_model, self.aug_param, netA = mk_augmenter(aug_file, load_weights)
@@ -196,41 +195,67 @@ class cpl_mixVAE:
     def epoch_steps(self, loader):
         """Generator over the loss vectors of one pass over ``loader`` (the inner loop of cpl_mixvae.py:415-478).
 
-        With an augmenter the loop is software-pipelined over two HIP streams: the (frozen, eval-mode) augmenter forward
-        of batch i+1 runs on a side stream beside the train step of batch i -- its GEMMs fill the matrix pipe while
-        the step sits in its latency-bound chain kernels (measured at the benchmark shape: 2.98 ms per batch against
-        3.20 ms back to back).  Same arithmetic and the same order of random draws as the unpipelined loop."""
-        batches = (b[0] if isinstance(b, (tuple, list)) else b for b in loader)
-        if self.netA is None or self.device.type != "cuda" or not self.pipeline_augmenter:
-            for x in batches:
-                yield self.train_step(x)
+        The loop is software-pipelined over two HIP streams: batch i+1 is *produced* -- fetched from the loader (row
+        gather of the device-resident loaders, or the H2D copy of a host batch) and, with an augmenter, passed through
+        the frozen eval-mode augmenter -- on a high-priority side stream beside the train step of batch i.  The
+        augmenter's GEMMs fill the matrix pipe while the step sits in its latency-bound chain kernels (measured at the
+        benchmark shape: 2.93 ms per augmented batch against 3.21 ms back to back).  Same arithmetic and the same order
+        of random draws as the unpipelined loop (``pipeline = False`` / MMVAE_PIPELINE=0)."""
+        A = self.n_arm
+
+        def first(b):
+            return b[0] if isinstance(b, (tuple, list)) else b
+
+        if self.device.type != "cuda" or not self.pipeline:
+            for b in loader:
+                yield self.train_step(first(b))
             return
         main = torch.cuda.current_stream(self.device)
-        if self._aug_stream is None:
-            self._aug_stream = torch.cuda.Stream(device=self.device, priority=-1)
-        side = self._aug_stream
-        prev = None
-        for x in batches:
-            x = x.to(self.device, non_blocking=True)              # produced on the main stream (loader gather / H2D)
-            ready = torch.cuda.Event()
-            ready.record(main)
+        side = N.shared_stream(self.device, "produce")
+        it = iter(loader)
+        ring = 3                                                # augmenter outputs in flight: produced, consumed, next
+        aug_out = {}
+        count = [0]
+
+        def produce():
+            b = next(it, None)
+            if b is None:
+                return None
+            x = first(b).to(self.device, non_blocking=True)
+            xs = x.expand(A, -1, -1)
+            if self.netA is not None:
+                key = (count[0] % ring, x.shape[0])
+                if key not in aug_out:                          # persistent outputs: no allocator traffic per batch
+                    aug_out[key] = (torch.empty(A, x.shape[0], self.netA._dims[4], device=self.device),
+                                    torch.empty(A, x.shape[0], x.shape[1], device=self.device))
+                xs = self.netA(xs, True, 0.1, out=aug_out[key])[1]   # cpl_mixvae.py:422-423
+            count[0] += 1
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return xs, x, ev
+
+        side.wait_stream(main)                                  # parameters / loader state written on the main stream
+        with torch.cuda.stream(side):
+            cur = produce()
+        done = []                                               # main-stream events, one per finished step
+        while cur is not None:
+            # ring buffers (loader batches, augmenter outputs) are reused every few batches: the side stream may only
+            # overwrite a slot once the step that read it is over (two steps back is enough for rings of >= 3)
+            if len(done) >= 2:
+                side.wait_event(done[-2])
             with torch.cuda.stream(side):
-                side.wait_event(ready)
-                xs = self.netA(x.expand(self.n_arm, -1, -1), True, 0.1)[1]
-                done = torch.cuda.Event()
-                done.record(side)
-            x.record_stream(side)
-            if prev is not None:
-                main.wait_event(prev[1])
-                buf = self._step(prev[0])
-                prev[0].record_stream(main)
-                yield buf
-            prev = (xs, done)
-        if prev is not None:
-            main.wait_event(prev[1])
-            buf = self._step(prev[0])
-            prev[0].record_stream(main)
+                nxt = produce()
+            xs, x, ev = cur
+            main.wait_event(ev)
+            buf = self._step(xs)
+            x.record_stream(main)                               # produced on the side stream, read on the main one
+            fin = torch.cuda.Event()
+            fin.record(main)
+            done.append(fin)
+            if len(done) > 4:
+                done.pop(0)
             yield buf
+            cur = nxt
 
     def train(self, train_loader, test_loader, n_epoch, n_epoch_p=0, c_p=0, c_onehot=0, min_con=0.5,
               max_prun_it=0, rank=None, run=None, ws=1, good_enuf_consensus=0.75):

@@ -12,9 +12,10 @@ row gather on the device (``mmvae_gather_rows``).  What is reproduced exactly:
 * ``drop_last=True`` / ``batch_size`` for training, ``batch_size=1, shuffle=False`` for the test loader,
   ``shuffle=False, drop_last=False`` for the all-data loader; every batch is ``(x, n)`` with ``n`` the float32 row
   indices, as ``TensorDataset(data, indices)`` yields them;
-* ``DistributedSampler`` sharding (:116-121): the same index sequence per (seed, epoch, rank) as torch's sampler
-  (seeded ``torch.randperm`` on the host, padded to a multiple of the world size, strided by rank).  The reference
-  passes ``shuffle=True`` together with a sampler, which torch rejects; the sharded loader here simply works.
+* ``DistributedSampler`` sharding (:116-121): pad to a multiple of the world size by wrapping, stride by rank, one
+  seeded permutation per epoch shared by all ranks.  With ``host_order = True`` the sequence is torch's sampler's,
+  index for index; by default the permutation is drawn by the device generator (same sharding, no upload per epoch).
+  The reference passes ``shuffle=True`` together with a sampler, which torch rejects; the sharded loader here works.
 
 What differs on purpose: the shuffle order of the non-distributed training loader comes from a generator owned by the
 loader (``seed``), not from torch's global RNG via DataLoader's ``RandomSampler``.
@@ -72,7 +73,7 @@ class DeviceLoader:
     (``set_epoch`` or one per ``__iter__``).  world_size > 1: DistributedSampler semantics."""
 
     def __init__(self, data: torch.Tensor, index: torch.Tensor, batch_size: int, shuffle: bool, drop_last: bool,
-                 seed: Optional[int] = None, world_size: int = 1, rank: int = 0):
+                 seed: Optional[int] = None, world_size: int = 1, rank: int = 0, ring: int = 4):
         if data.device.type != "cuda":
             raise N.NativeError("DeviceLoader needs the matrix on the GPU (the data path has no CPU fallback)")
         assert data.dim() == 2 and data.dtype == torch.float32
@@ -86,6 +87,15 @@ class DeviceLoader:
         self.epoch = 0
         self._auto_epoch = 0
         self.dataset = _Tensors(self)
+        # Batches are gathered into a ring of `ring` persistent buffers: a fresh 100 MB tensor per batch makes the caching
+        # allocator grow and hipMalloc in the middle of an epoch as soon as two streams are involved (measured: epochs
+        # of 70-90 ms instead of 11).  A yielded batch stays valid until `ring` - 1 more batches have been drawn --
+        # training loops consume a batch at once; ring = 0 returns a new tensor per batch, as a DataLoader does.
+        self.ring = int(ring)
+        self._bufs = None
+        self._slot = 0
+        self._pin, self._pin_ev, self._pin_k, self._copy_stream = None, None, 0, None
+        self.host_order = False      # True: torch's CPU permutation (DistributedSampler's exact sequence), uploaded per epoch
 
     # torch.utils.data.DistributedSampler.set_epoch
     def set_epoch(self, epoch: int):
@@ -102,39 +112,88 @@ class DeviceLoader:
         n = self._n_local()
         return n // self.batch_size if self.drop_last else math.ceil(n / self.batch_size)
 
-    def epoch_order(self) -> torch.Tensor:
-        """Positions into ``self.index`` this rank visits this epoch (host int64 tensor)."""
+    def _base_order(self, epoch: int, device) -> torch.Tensor:
         n = int(self.index.numel())
-        epoch = self.epoch if self._auto_epoch is None else self._auto_epoch
-        if self.world_size > 1:
-            # torch/utils/data/distributed.py: seeded randperm, pad by wrapping, stride by rank
-            if self.shuffle:
-                g = torch.Generator()
-                g.manual_seed(self.seed + epoch)
-                order = torch.randperm(n, generator=g)
-            else:
-                order = torch.arange(n)
-            total = math.ceil(n / self.world_size) * self.world_size
-            pad = total - n
-            if pad > 0:
-                reps = math.ceil(pad / max(n, 1))
-                order = torch.cat([order, order.repeat(reps)[:pad]])
-            return order[self.rank:total:self.world_size]
-        if self.shuffle:
-            g = torch.Generator()
-            g.manual_seed(self.seed + epoch)
-            return torch.randperm(n, generator=g)
-        return torch.arange(n)
+        if not self.shuffle:
+            return torch.arange(n, device=device)
+        g = torch.Generator(device=device)
+        g.manual_seed(self.seed + epoch)
+        return torch.randperm(n, generator=g, device=device)
+
+    def _shard(self, order: torch.Tensor) -> torch.Tensor:
+        """torch/utils/data/distributed.py: pad by wrapping to a multiple of the world size, stride by rank."""
+        if self.world_size <= 1:
+            return order
+        n = order.numel()
+        total = math.ceil(n / self.world_size) * self.world_size
+        pad = total - n
+        if pad > 0:
+            reps = math.ceil(pad / max(n, 1))
+            order = torch.cat([order, order.repeat(reps)[:pad]])
+        return order[self.rank:total:self.world_size]
+
+    def _epoch(self) -> int:
+        return self.epoch if self._auto_epoch is None else self._auto_epoch
+
+    def epoch_order(self) -> torch.Tensor:
+        """Positions into ``self.index`` this rank visits this epoch, computed on the HOST: for a sharded loader this is
+        the exact sequence of ``torch.utils.data.DistributedSampler(seed=seed)`` (tests/test_dataloader_cpu.py)."""
+        return self._shard(self._base_order(self._epoch(), "cpu"))
+
+    def epoch_order_device(self) -> torch.Tensor:
+        """The same logic with the permutation drawn on the device (seeded device generator: identical on every rank):
+        no host-to-device copy per epoch.  Such a copy (400 KB, even pinned and on a stream of its own) stalled for
+        50-90 ms every few epochs while train steps were queued -- an epoch is 11 ms."""
+        return self._shard(self._base_order(self._epoch(), self.index.device))
+
+    def _upload(self, order: torch.Tensor) -> torch.Tensor:
+        """Host permutation -> device through pinned staging and an asynchronous copy.  A plain ``.to(device)`` of
+        pageable memory while train steps are queued stalled for 25-75 ms now and then (measured: epochs of 35-85 ms
+        instead of 10.6)."""
+        n = order.numel()
+        if self._pin is None or self._pin[0].numel() < n:
+            self._pin = [torch.empty(max(n, 1), dtype=torch.int64).pin_memory() for _ in range(2)]
+            self._pin_ev = [None, None]
+        k = self._pin_k
+        self._pin_k ^= 1
+        if self._pin_ev[k] is not None:
+            self._pin_ev[k].synchronize()                       # the copy issued two epochs ago has long finished
+        self._pin[k][:n].copy_(order)
+        dev = torch.empty(n, dtype=torch.int64, device=self.index.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.index.device)
+        cur = torch.cuda.current_stream(self.index.device)
+        self._copy_stream.wait_stream(cur)                      # `dev` was just handed out by the allocator on `cur`
+        with torch.cuda.stream(self._copy_stream):              # a stream of its own: not behind the queued train steps
+            dev.copy_(self._pin[k][:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        cur.wait_event(ev)
+        dev.record_stream(self._copy_stream)
+        self._pin_ev[k] = ev
+        return dev
 
     def __iter__(self):
-        order = self.epoch_order().to(self.index.device)
+        order = self._upload(self.epoch_order()) if self.host_order else self.epoch_order_device()
         if self._auto_epoch is not None:
             self._auto_epoch += 1
         rows = self.index[order]
         nb = len(self)
+        if self.ring > 0 and (self._bufs is None or self._bufs[0][0].shape[0] != self.batch_size):
+            self._bufs = [(torch.empty(self.batch_size, self.data.shape[1], dtype=torch.float32, device=self.data.device),
+                           torch.empty(self.batch_size, dtype=torch.float32, device=self.data.device))
+                          for _ in range(self.ring)]
         for i in range(nb):
             r = rows[i * self.batch_size:(i + 1) * self.batch_size]
-            yield N.gather_rows(self.data, r), r.to(torch.float32)
+            if self.ring > 0:
+                xb, ib = self._bufs[self._slot]
+                self._slot = (self._slot + 1) % self.ring
+                xb, ib = xb[:r.numel()], ib[:r.numel()]
+                N.gather_rows(self.data, r, xb)
+                ib.copy_(r)
+                yield xb, ib
+            else:
+                yield N.gather_rows(self.data, r), r.to(torch.float32)
 
 
 def get_loaders(dataset, label: Sequence = [], seed=None, batch_size=128, train_size=0.9, use_dist_sampler=False,

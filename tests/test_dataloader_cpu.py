@@ -39,6 +39,7 @@ def _loader(n, bs, shuffle, drop_last, seed, ws=1, rk=0):
     ld.index = torch.arange(n)
     ld.batch_size, ld.shuffle, ld.drop_last = bs, shuffle, drop_last
     ld.seed, ld.world_size, ld.rank, ld.epoch, ld._auto_epoch = seed, ws, rk, 0, 0
+    ld._pin, ld._pin_ev, ld._pin_k = None, None, 0
     return ld
 
 

@@ -155,7 +155,7 @@ def test_pipelined_epoch_equals_unpipelined():
         netA = Augmenter_smartseq(NZ, Z, D, ND)
         netA.load_state_dict(sd_aug)
         t.set_augmenter(netA)
-        t.pipeline_augmenter = pipe
+        t.pipeline = pipe
         t.model._noise_seed, t.model._noise_offset = 9, 0
         torch.manual_seed(77)                                   # the augmenter's torch.randn draws
         bufs = [b.clone() for b in t.epoch_steps(batches)]

@@ -68,6 +68,27 @@ def test_distributed_shards_partition_the_training_set():
     assert len(np.unique(allv)) == len(allv) == 360                                        # 90 rows per rank, disjoint
 
 
+def test_device_and_host_orders_share_the_sharding_logic():
+    from distributed_vae_amd.utils import dataloader as DL
+    data = torch.rand(103, 8, device=DEV)
+    for ws in (1, 4):
+        parts = []
+        for rank in range(ws):
+            ld = DL.DeviceLoader(data, torch.arange(103), 10, True, True, seed=3, world_size=ws, rank=rank)
+            ld.set_epoch(2)
+            od = ld.epoch_order_device().cpu()
+            assert od.numel() == ld.epoch_order().numel()
+            parts.append(od)
+            ld2 = DL.DeviceLoader(data, torch.arange(103), 10, True, True, seed=3, world_size=ws, rank=rank)
+            ld2.set_epoch(2)
+            assert torch.equal(ld2.epoch_order_device().cpu(), od)              # deterministic in (seed, epoch, rank)
+            ld2.host_order = True
+            got = torch.cat([i.clone() for _, i in ld2]).cpu().long()     # ring buffers: copy before the next draw
+            assert torch.equal(got, ld2.index.cpu()[ld2.epoch_order()][:got.numel()])
+        allv = torch.cat(parts)
+        assert set(allv.tolist()) == set(range(103))                            # every row served, padding by wrapping
+
+
 def test_trainer_epoch_from_device_loaders():
     from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
     from distributed_vae_amd.utils import dataloader as DL
