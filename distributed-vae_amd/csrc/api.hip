@@ -199,8 +199,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     }
     // batch statistics are recombined by the kernel that consumes each BatchNorm (no finalize launches);
     // eval mode copies the running statistics into the workspace instead
-    for (int i = 0; i < 5; ++i)
-        if ((rc = launch_bn_eval_stats(c, i, bn_running))) return rc;
+    if ((rc = launch_bn_eval_stats(c, bn_running))) return rc;
     for (int layer = 2; layer <= 5; ++layer)
         if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt))) return rc;

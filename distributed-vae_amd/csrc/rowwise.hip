@@ -47,14 +47,15 @@ NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h) {
     return n;
 }
 
-// eval mode: statistics come from the running buffers
-__global__ void k_stats_from_running(const float* __restrict__ run_mean, const float* __restrict__ run_var,
-                                     int64_t run_arm_stride, int W, float eps, float* __restrict__ mean_out,
-                                     float* __restrict__ rstd_out) {
-    const int arm = blockIdx.x, col = threadIdx.x;
+// eval mode: statistics come from the running buffers.  One launch for the five BatchNorm layers: grid (A, 5).
+struct EvalStatArgs { int64_t run_mean[5], run_var[5], mean_out[5], rstd_out[5]; int W[5]; };
+__global__ void k_stats_from_running(const float* __restrict__ bn_running, int64_t run_arm_stride, EvalStatArgs a, float eps,
+                                     float* __restrict__ ws) {
+    const int arm = blockIdx.x, layer = blockIdx.y, col = threadIdx.x;
+    const int W = a.W[layer];
     if (col < W) {
-        mean_out[arm * W + col] = run_mean[arm * run_arm_stride + col];
-        rstd_out[arm * W + col] = 1.0f / sqrtf(run_var[arm * run_arm_stride + col] + eps);
+        ws[a.mean_out[layer] + arm * W + col] = bn_running[a.run_mean[layer] + arm * run_arm_stride + col];
+        ws[a.rstd_out[layer] + arm * W + col] = 1.0f / sqrtf(bn_running[a.run_var[layer] + arm * run_arm_stride + col] + eps);
     }
 }
 
@@ -958,15 +959,20 @@ static LatArgs make_lat_args(const Ctx& c) {
 
 // eval mode: BatchNorm `layer` (0..4) normalises with the running buffers; in training mode the kernel that
 // consumes the layer recombines the batch statistics itself and nothing is launched here
-int launch_bn_eval_stats(const Ctx& c, int layer, const float* bn_running) {
+int launch_bn_eval_stats(const Ctx& c, const float* bn_running) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     if (c.h.training) return 0;
     if (!bn_running) { set_error("eval-mode forward needs bn_running"); return MMVAE_E_BADARG; }
-    const int W = (layer == 4) ? d.L : d.H;
-    hipLaunchKernelGGL(k_stats_from_running, dim3(d.A), dim3(128), 0, c.stream, bn_running + c.po.bn_mean[layer],
-                       bn_running + c.po.bn_var[layer], c.po.bn_per_arm, W, c.h.eps, c.ws + L.bn_mean[layer],
-                       c.ws + L.bn_rstd[layer]);
+    EvalStatArgs a{};
+    for (int layer = 0; layer < 5; ++layer) {
+        a.run_mean[layer] = c.po.bn_mean[layer];
+        a.run_var[layer] = c.po.bn_var[layer];
+        a.mean_out[layer] = L.bn_mean[layer];
+        a.rstd_out[layer] = L.bn_rstd[layer];
+        a.W[layer] = (layer == 4) ? d.L : d.H;
+    }
+    hipLaunchKernelGGL(k_stats_from_running, dim3(d.A, 5), dim3(128), 0, c.stream, bn_running, c.po.bn_per_arm, a, c.h.eps, c.ws);
     HIP_LAUNCH_CHECK("k_stats_from_running");
     return 0;
 }
