@@ -200,8 +200,13 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     // batch statistics are recombined by the kernel that consumes each BatchNorm (no finalize launches);
     // eval mode copies the running statistics into the workspace instead
     if ((rc = launch_bn_eval_stats(c, bn_running))) return rc;
-    for (int layer = 2; layer <= 5; ++layer)
-        if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
+    static const int eval_chain = getenv("MMVAE_EVAL_CHAIN") ? atoi(getenv("MMVAE_EVAL_CHAIN")) : 1;   // A/B timing
+    if (!c.h.training && eval_chain) {
+        if ((rc = launch_chain_fwd_enc_eval(c, params))) return rc;
+    } else {
+        for (int layer = 2; layer <= 5; ++layer)
+            if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
+    }
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt))) return rc;
     if (latent_only) return 0;   // evaluation labels need c only: no decoder, no fc11
     if (couple_done && g_side) {

@@ -33,6 +33,9 @@ struct FwdLayer {
     int64_t w_off, b_off;   // inside one arm's parameter segment
     int64_t out_off;        // workspace, [A,B,N]
     int K, N, act;          // act: 1 = ReLU, 0 = identity
+    // eval-mode encoder chain: the next layer reads BatchNorm(out) with the statistics at these workspace offsets
+    // ([A,N] each; -1: the next layer reads `out` as is).  The stored `out` stays un-normalised.
+    int64_t obn_mean_off = -1, obn_rstd_off = -1;
 };
 struct ChainFwdArgs {
     int nlayers;
@@ -222,6 +225,9 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         const int col = ct * 32 + (lane & 31);
         const bool active = ct * 32 < NPad;
         const float bias = (active && col < N) ? P[Lr.b_off + col] : 0.f;   // requested before the barrier
+        const bool obn = Lr.obn_mean_off >= 0;
+        const float omean = (obn && active && col < N) ? ws[Lr.obn_mean_off + (int64_t)arm * N + col] : 0.f;
+        const float orstd = (obn && active && col < N) ? ws[Lr.obn_rstd_off + (int64_t)arm * N + col] : 0.f;
         stamp(1);
         lds_barrier();
         stamp(2);
@@ -252,7 +258,8 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
                 }
                 vals[r] = v;
                 // next layer's input: zero beyond N (up to the next multiple of 8) and beyond nvalid
-                if (col < rup(N, 8)) Xs[row * ld + col] = v;
+                const float xin = obn ? ((col < N && row < nvalid) ? (v - omean) * orstd : 0.f) : v;
+                if (col < rup(N, 8)) Xs[row * ld + col] = xin;
             }
         }
         if (last && a.stats_part_off >= 0) {
@@ -609,6 +616,38 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws, bn_running, nbt);
     HIP_LAUNCH_CHECK("k_chain_fwd<enc>");
+    return 0;
+}
+
+// eval mode: the BatchNorm statistics are fixed (running buffers), so fc2..fc5 need no launch boundary between them:
+// one launch, the activations of a row block stay in LDS from layer to layer (four launches of ~16 us -> one)
+int launch_chain_fwd_enc_eval(const Ctx& c, const float* params) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    ChainFwdArgs a{};
+    a.nlayers = 4;
+    for (int layer = 2; layer <= 5; ++layer) {
+        const int i = layer - 1;
+        FwdLayer f{c.po.o[2 * (layer - 1)], c.po.o[2 * (layer - 1) + 1], L.R[i], d.H, (layer == 5) ? d.L : d.H, 1};
+        if (layer < 5) { f.obn_mean_off = L.bn_mean[i]; f.obn_rstd_off = L.bn_rstd[i]; }   // BN5 belongs to the latent kernel
+        a.L[layer - 2] = f;
+    }
+    a.x_off = L.R[0];
+    a.K0 = d.H;
+    a.bn_mean_off = L.bn_mean[0];
+    a.bn_rstd_off = L.bn_rstd[0];
+    a.bn_part_off = -1;
+    a.stats_part_off = -1;
+    a.bn_eps = c.h.eps;
+    a.B = d.B;
+    a.ld = fwd_ld(max(d.H, d.L));
+    a.wrows = rup(max(d.H, d.L), 32);
+    a.per_arm = c.po.per_arm;
+    a.ablate = 0;
+    a.dbg_off = -1;
+    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
+                       c.ws, (float*)nullptr, (int64_t*)nullptr);
+    HIP_LAUNCH_CHECK("k_chain_fwd<enc eval>");
     return 0;
 }
 
