@@ -230,9 +230,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, D, H, L, C, S, A, B)
     if rank == 0 and world == 1 and not args.no_eval:
-        out["eval_consensus"] = eval_consensus(args, model, batches, A, B, D, H, L, C, S, not args.no_cpu_baseline)
-        out["augmenter"] = augmenter_forward(args, batches, A, B, D, not args.no_cpu_baseline)
-        out["data_path"] = data_path(data, A, B, D)
+        # the widened rows beside the headline metric; a failure here must not cost the JSON line
+        for key, fn in (("eval_consensus", lambda: eval_consensus(args, model, batches, A, B, D, H, L, C, S, not args.no_cpu_baseline)),
+                        ("augmenter", lambda: augmenter_forward(args, batches, A, B, D, not args.no_cpu_baseline)),
+                        ("data_path", lambda: data_path(data, A, B, D))):
+            try:
+                out[key] = fn()
+            except Exception as e:   # noqa: BLE001
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or args.rehearse_dp:
