@@ -203,7 +203,10 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = measure_stages(model, batches[0], A, B, D, H)
+        try:
+            roof = measure_stages(model, batches[0], A, B, D, H)
+        except Exception as e:   # noqa: BLE001
+            roof = {"error": f"{type(e).__name__}: {e}"}
         roof["step_flops_frac_of_fp32_mfma_peak"] = cells_per_s / world * fl_cell / (PEAK_FP32_MFMA_TFLOPS * 1e12)
         roof["step_bytes_frac_of_hbm_peak"] = cells_per_s / world * by_cell / (PEAK_HBM_GBS * 1e9)
 
@@ -228,7 +231,10 @@ def main():
     if roof is not None:
         out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, D, H, L, C, S, A, B)
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, D, H, L, C, S, A, B)
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_eval:
         # the widened rows beside the headline metric; a failure here must not cost the JSON line
         for key, fn in (("eval_consensus", lambda: eval_consensus(args, model, batches, A, B, D, H, L, C, S, not args.no_cpu_baseline)),
