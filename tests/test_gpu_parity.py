@@ -623,3 +623,31 @@ def test_trainer_loop_and_checkpoint(tmp_path):
     assert t2.optimizer.step_count == 55                  # 11 epochs x 5 batches
     for k, v in t2.model.state_dict().items():
         assert torch.equal(v.cpu(), loaded["model_state_dict"][k]), k
+
+
+def test_full_size_step_is_bit_reproducible():
+    """Every reduction of the step has a fixed order: identical state and noise give bit-identical gradients and
+    losses run after run at the benchmark shape.  A run-to-run difference means a race or an unpadded hardware hazard
+    (tools/soak_determinism.py runs the same check for hundreds of iterations)."""
+    U = _U()
+    from distributed_vae_amd import _native as N
+    A, B, D = 2, 5000, 5000
+    h = R.Hyper(input_dim=D, fc_dim=100, n_categories=92, state_dim=2, lowD_dim=10, n_arm=A)
+    torch.manual_seed(546)
+    m = U.build_model(h, None)
+    m.train()
+    x = R.synthetic_batch(B, D).to(U.DEV)
+    eng = m._ensure(B)
+    hyper, noise = m._hyper(1.0, False), N.make_noise(None, 7, 3)
+    bn0, nbt0 = m._bn_flat.clone(), m._nbt.clone()
+    ref = None
+    for it in range(12):
+        m._bn_flat.copy_(bn0)
+        m._nbt.copy_(nbt0)
+        buf = eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, m._flat_grad, False, None, None, 1, 0.0)
+        cur = (m._flat_grad.clone(), buf.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), f"iteration {it} differs"
+    assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
