@@ -270,7 +270,8 @@ class cpl_mixVAE:
         if D.is_dist():
             D.broadcast_flat(self.model.flat_parameters())
         hist = {"losses": [], "loss_joints": [], "loss_recs": [[] for _ in range(A)], "c_ents": [], "c_l2_dists": [],
-                "c_dists": [], "validation_loss": [], "consensus_train": [], "epoch_times": []}
+                "c_dists": [], "validation_loss": [], "validation_rec_loss": [], "consensus_train": [], "consensus_val": [],
+                "epoch_times": []}
         self.current_time = time.strftime("%Y-%m-%d-%H-%M-%S")
         for e in range(n_epoch):
             t0 = time.time()
@@ -297,8 +298,13 @@ class cpl_mixVAE:
             cons = self.consensus(train_loader)
             hist["consensus_train"].append(cons)
             # validation loss (cpl_mixvae.py:665-775): eval mode, no Gumbel noise, hard sample
-            val = self.validate(test_loader) if test_loader is not None else float("nan")
-            hist["validation_loss"].append(val)
+            if test_loader is not None:
+                val_tot, val, val_cons = self.validate(test_loader, full=True)
+            else:
+                val_tot = val = val_cons = float("nan")
+            hist["validation_loss"].append(val_tot)                # :764
+            hist["validation_rec_loss"].append(val)                # :763
+            hist["consensus_val"].append(val_cons)                 # :762
             dt = time.time() - t0
             hist["epoch_times"].append(dt)
             if rank in (None, 0, dev) or not D.is_dist():
@@ -309,7 +315,8 @@ class cpl_mixVAE:
                 run.log({"train/total-loss": hist["losses"][-1], "train/joint-loss": hist["loss_joints"][-1],
                          "train/negative-joint-entropy": hist["c_ents"][-1],
                          "train/simplex-distance": hist["c_dists"][-1], "train/l2-distance": hist["c_l2_dists"][-1],
-                         "train/time": dt, "train/consensus": cons, "validation/rec-loss": val})
+                         "train/time": dt, "train/consensus": cons, "val/total-loss": val_tot, "val/rec-loss": val,
+                         "val/consensus": val_cons})
             if self.save and self.folder and (e > 0) and (e % 10 == 0):    # :777-788
                 os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
                 self.save_checkpoint(os.path.join(self.folder, "model", f"cpl_mixVAE_model_epoch_{e}.pth"))
@@ -331,8 +338,8 @@ class cpl_mixVAE:
         self.model.eval()
         counts = confmat_counts(self.n_arm, self.n_categories, self.device)
         seen = 0
-        for batch in loader:
-            x = (batch[0] if isinstance(batch, (tuple, list)) else batch).to(self.device)
+        for x in self._eval_batches(loader):
+            x = x.to(self.device)
             if x.shape[0] < 1:
                 continue
             self.model.eval_labels(x.expand(self.n_arm, -1, -1), self.temp, counts)
@@ -344,19 +351,49 @@ class cpl_mixVAE:
             return float("nan")
         return float(np.mean(consensus_from_counts(counts).cpu().numpy()))   # np.mean(np.array(consensus)), :654
 
-    @torch.no_grad()
-    def validate(self, loader) -> float:
-        """Mean over arms and batches of rec_loss / D in eval mode (cpl_mixvae.py:700-747)."""
-        self.model.eval()
-        tot, n = 0.0, 0
+    @staticmethod
+    def _eval_batches(loader):
+        """The reference walks a loader batch by batch when ``loader.batch_size > 1`` and otherwise takes the whole set
+        as ONE batch from ``loader.dataset.tensors`` (cpl_mixvae.py:567-640, :670-760; the default test loader has
+        ``batch_size=1``).  Yields x tensors accordingly; ``len`` semantics stay the loader's."""
+        if getattr(loader, "batch_size", None) == 1 and hasattr(loader, "dataset") and hasattr(loader.dataset, "tensors"):
+            yield loader.dataset.tensors[0]
+            return
         for batch in loader:
-            x = (batch[0] if isinstance(batch, (tuple, list)) else batch).to(self.device)
-            if x.shape[0] < 2:
+            yield batch[0] if isinstance(batch, (tuple, list)) else batch
+
+    @torch.no_grad()
+    def validate(self, loader, full: bool = False):
+        """The validation block of cpl_mixvae.py:665-775 in eval mode: ``validation_rec_loss = sum over batches and arms
+        of loss_rec[a] / D, divided by len(loader) and n_arm`` (:742-763), ``validation_loss = sum of the total loss /
+        len(loader)`` (:741, :764) and the between-arm consensus of the labels (:752-762, on the device).  Returns the
+        rec loss, or the triple ``(validation_loss, validation_rec_loss, consensus_val)`` with ``full=True``.  With
+        the reference's default test loader (batch_size 1) the whole set is one batch and ``len(loader)`` its row
+        count, as in the reference."""
+        from ._utils import confmat_counts, consensus_from_counts
+        was_training = self.model.training
+        self.model.eval()
+        A = self.n_arm
+        counts = confmat_counts(A, self.n_categories, self.device)
+        tot = torch.zeros((), dtype=torch.float64, device=self.device)
+        rec = torch.zeros((), dtype=torch.float64, device=self.device)
+        seen = 0
+        for x in self._eval_batches(loader):
+            x = x.to(self.device)
+            if x.shape[0] < 1:
                 continue
-            xs = x.expand(self.n_arm, -1, -1)
+            xs = x.expand(A, -1, -1)
             out = self.model(xs, self.temp, 0.0, eval=True)
             lt = self.model.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)
-            tot += float(lt[1].mean()) / self.input_dim
-            n += 1
-        self.model.train()
-        return tot / max(n, 1)
+            tot += lt[0].double()                                             # :741 val_loss += loss.data.item()
+            rec += lt[1].double().sum() / self.input_dim                      # :742-743 sum_a loss_rec[a] / D
+            labels = torch.stack([N.classify(c) for c in out[4]])            # :744 / :752 classify(cs[a])
+            N.confmat_accumulate(labels, self.n_categories, counts)
+            seen += 1
+        self.model.train(was_training)
+        nb = max(len(loader), 1) if hasattr(loader, "__len__") else max(seen, 1)
+        val_loss, val_rec = float(tot) / nb, float(rec) / nb / A
+        if not full:
+            return val_rec
+        cons = float(np.mean(consensus_from_counts(counts).cpu().numpy())) if seen and A > 1 else float("nan")
+        return val_loss, val_rec, cons
