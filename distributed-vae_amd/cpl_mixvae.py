@@ -380,7 +380,7 @@ class cpl_mixVAE:
         seen = 0
         for x in self._eval_batches(loader):
             x = x.to(self.device)
-            if x.shape[0] < 1:
+            if x.shape[0] < 2:     # a one-cell batch has no batch variance: the reference's loss is NaN there (nn_model.py:75)
                 continue
             xs = x.expand(A, -1, -1)
             out = self.model(xs, self.temp, 0.0, eval=True)
