@@ -84,3 +84,46 @@ def test_two_reference_snapshots_agree():
         out, lo, _ = RL.reference_step(m, x.expand(A, -1, -1), 1.0, R.draw_noise(h, B, seed=11))
         res.append(float(lo[0]))
     assert res[0] == res[1]
+
+
+def test_checkpoints_round_trip_with_the_reference(tmp_path):
+    """a checkpoint written by this package's trainer (cpl_mixvae.py:783-786 layout) loads into
+    the reference model and torch.optim.Adam with strict key checking, and a checkpoint written the reference's way
+    loads back here -- so the reference's evaluation scripts keep working on these files."""
+    warnings.simplefilter("ignore")
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.cpl_mixvae import FusedAdam, cpl_mixVAE
+    ref = RL.load_reference_nn_model()
+    cfg = (3, 8, 40, 12, 4, 6, 2, False, 0.0)
+    A, B, D, H, L, C, S = cfg[:7]
+    t = cpl_mixVAE(saving_folder=str(tmp_path), device="cpu", save_flag=True)
+    t.init_model(n_categories=C, state_dim=S, input_dim=D, fc_dim=H, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A)
+    t.optimizer._bind()
+    t.optimizer.step_count = 3
+    t.optimizer.exp_avg.uniform_(-1, 1)
+    t.optimizer.exp_avg_sq.uniform_(0, 1)
+    path = str(tmp_path / "ckpt.pth")
+    t.save_checkpoint(path)
+    loaded = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(loaded) == {"model_state_dict", "optimizer_state_dict"}
+    m_ref, _ = _mk(ref, cfg, torch.float32)
+    missing = m_ref.load_state_dict(loaded["model_state_dict"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for k, v in m_ref.state_dict().items():
+        assert torch.equal(v, t.model.state_dict()[k]), k
+    opt_ref = torch.optim.Adam(m_ref.parameters(), lr=1e-3)
+    opt_ref.load_state_dict(loaded["optimizer_state_dict"])
+    assert int(opt_ref.state[next(iter(m_ref.parameters()))]["step"]) == 3
+    # the other direction: the reference's save (cpl_mixvae.py:783-786) -> this trainer's load_model
+    ref_path = str(tmp_path / "ref.pth")
+    torch.save({"model_state_dict": m_ref.state_dict(), "optimizer_state_dict": opt_ref.state_dict()}, ref_path)
+    t2 = cpl_mixVAE(saving_folder=str(tmp_path), device="cpu", save_flag=False)
+    t2.init_model(n_categories=C, state_dim=S, input_dim=D, fc_dim=H, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A,
+                  trained_model=ref_path)
+    for k, v in t2.model.state_dict().items():
+        assert torch.equal(v, m_ref.state_dict()[k]), k
+    assert t2.optimizer.step_count == 3
+    t3 = cpl_mixVAE(saving_folder=str(tmp_path), device="cpu", save_flag=False)
+    t3.init_model(n_categories=C, state_dim=S, input_dim=D, fc_dim=H, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A)
+    t3.load_model(ref_path)
+    assert torch.equal(t3.model.state_dict()["fc1.0.weight"], m_ref.state_dict()["fc1.0.weight"])
