@@ -416,6 +416,318 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 }
 
 // ---------------------------------------------------------------------------------------------
+// Half-wave layout of the latent forward (C <= 96, L <= 32, 2 S <= 32 -- the reference's 92 / 10 / 2):
+// a cell owns 32 lanes x 3 registers (96 column slots for 92 categories instead of 64 x 2 = 128), a wave instruction
+// therefore serves TWO cells, and the softmax reductions stop at 32 lanes (the last cross-half step is dropped).
+// The kernel is VALU-bound (a wave instruction occupies its SIMD for four cycles): three registers for two cells
+// instead of two for one is a quarter less element-wise work, and a reduction step now counts for two cells.
+// 8 waves x 2 halves x 3 cells = the same LAT_ROWS cells per workgroup and the same partial layouts as k_lat_fwd.
+// ---------------------------------------------------------------------------------------------
+constexpr int LH_NW = 8, LH_CPL = 3, LH_NR = LAT_ROWS / (LH_NW * 2);
+static_assert(LH_NR * LH_NW * 2 == LAT_ROWS, "LAT_ROWS must be a multiple of 16");
+template <typename Op>
+__device__ __forceinline__ float half_allreduce(float v, Op op) {   // wave_allreduce without the 32-lane swap
+    v = op(v, dpp_f<0xB1>(v));
+    v = op(v, dpp_f<0x4E>(v));
+    v = op(v, dpp_f<0x141>(v));
+    v = op(v, dpp_f<0x140>(v));
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return op(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) { return half_allreduce(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float half_max(float v) { return half_allreduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ int half_min_i(int v) {
+    const float f = half_allreduce(__builtin_bit_cast(float, v), [](float a, float b) {
+        const int x = __builtin_bit_cast(int, a), y = __builtin_bit_cast(int, b);
+        return __builtin_bit_cast(float, x < y ? x : y);
+    });
+    return __builtin_bit_cast(int, f);
+}
+
+__global__ __launch_bounds__(64 * LH_NW) void k_lat_fwd_h(const LatArgs a_in, const NoiseDev nz_in,
+                                                         const float* __restrict__ params, float* __restrict__ ws,
+                                                         float* __restrict__ bn_running, int64_t* __restrict__ nbt) {
+    constexpr int NR = LH_NR, CP = LH_CPL, NT = 64 * LH_NW;
+    const LatArgs a = a_in;
+    const NoiseDev nz = nz_in;
+    extern __shared__ __attribute__((aligned(16))) float lat_smem[];
+    __shared__ __attribute__((aligned(16))) float sh_buf[LAT_ROWS * 128];   // prologue scratch, then the c tile
+    __shared__ float sh_ps[NT / 128][128];
+    __shared__ float sh_red[LH_NW][2], sh_bn5[2][64];
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * LAT_ROWS;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane & 31, hb = lane & 32, half = lane >> 5;
+    const int B = a.B, L = a.L, C = a.C, S = a.S;
+    const float* P = params + (int64_t)arm * a.per_arm;
+    float* WcT = lat_smem;            // [L][C]
+    float* Wms = lat_smem + C * L;    // [2S][L+C]
+    const int64_t ab = (int64_t)arm * B;
+    const float eps = a.eps;
+
+    int slot[NR], bb[NR];
+    bool okr[NR];
+    float r5[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        slot[r] = r * (LH_NW * 2) + wv * 2 + half;
+        bb[r] = b0 + slot[r];
+        okr[r] = bb[r] < B;                   // per half-wave
+        r5[r] = sub < L ? ws[a.R5 + (ab + min(bb[r], B - 1)) * L + sub] : 0.f;
+    }
+    bool vcol[CP];
+    float bcv[CP];
+#pragma unroll
+    for (int t = 0; t < CP; ++t) { vcol[t] = sub + 32 * t < C; bcv[t] = vcol[t] ? P[a.o_bc + sub + 32 * t] : 0.f; }
+    lat_stage_weights(WcT, Wms, P + a.o_wc, P + a.o_wms, L, C, S);
+    const float* bms = P + a.o_bms;
+
+    if (a.bn_part5 >= 0) {
+        float mean, m2;
+        stats_from_partials<NT>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L, sh_buf, mean, m2);
+        if (threadIdx.x < L) {
+            const int t = threadIdx.x;
+            const float rstd = 1.0f / sqrtf(m2 / (float)B + eps);
+            sh_bn5[0][t] = mean;
+            sh_bn5[1][t] = rstd;
+            if (blk == 0) {
+                ws[a.mean5 + arm * L + t] = mean;
+                ws[a.rstd5 + arm * L + t] = rstd;
+                if (bn_running) {
+                    float* rm = bn_running + a.run_mean_off + arm * a.run_arm_stride;
+                    float* rv = bn_running + a.run_var_off + arm * a.run_arm_stride;
+                    rm[t] = (1.f - a.bn_momentum) * rm[t] + a.bn_momentum * mean;
+                    rv[t] = (1.f - a.bn_momentum) * rv[t] + a.bn_momentum * (m2 / (float)max(B - 1, 1));
+                }
+                if (nbt && t == 0) nbt[arm * MMVAE_N_BN + 4] += 1;
+            }
+        }
+        lds_barrier();
+    }
+    const float mu5 = sub < L ? (a.bn_part5 >= 0 ? sh_bn5[0][sub] : ws[a.mean5 + arm * L + sub]) : 0.f;
+    const float rs5 = sub < L ? (a.bn_part5 >= 0 ? sh_bn5[1][sub] : ws[a.rstd5 + arm * L + sub]) : 0.f;
+
+    // ---- x_low = BN5(R5)
+    float xl[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        xl[r] = sub < L ? (r5[r] - mu5) * rs5 : 0.f;
+        if (okr[r] && sub < L) {
+            ws[a.XLOW + (ab + bb[r]) * L + sub] = xl[r];
+            ws[a.Y + (ab + bb[r]) * (L + C) + sub] = xl[r];
+        }
+    }
+    // ---- zc = fcc(x_low); c_prob = softmax(zc)
+    float z[NR][CP];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int t = 0; t < CP; ++t) z[r][t] = bcv[t];
+    for (int k = 0; k < L; ++k) {
+        float w[CP];
+#pragma unroll
+        for (int t = 0; t < CP; ++t) w[t] = vcol[t] ? WcT[k * C + sub + 32 * t] : 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float xk = __shfl(xl[r], hb + k, 64);   // this half's own cell
+#pragma unroll
+            for (int t = 0; t < CP; ++t) z[r][t] += xk * w[t];
+        }
+    }
+    float m[NR], ssum[NR], e[NR][CP];
+    float cp[NR][CP], cc[NR][CP], lc[NR][CP], ys[NR][CP], cs[NR][CP];
+    auto softmax_rows = [&](float (&v)[NR][CP], float (&out)[NR][CP]) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            m[r] = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < CP; ++t) if (vcol[t]) m[r] = fmaxf(m[r], v[r][t]);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) m[r] = half_max(m[r]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            ssum[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < CP; ++t) { e[r][t] = vcol[t] ? expf(v[r][t] - m[r]) : 0.f; ssum[r] += e[r][t]; }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) ssum[r] = half_sum(ssum[r]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float inv = 1.f / ssum[r];
+#pragma unroll
+            for (int t = 0; t < CP; ++t) out[r][t] = e[r][t] * inv;
+        }
+    };
+    softmax_rows(z, cp);
+    // ---- c = softmax(c_prob / tau)
+    const float inv_tau = 1.f / a.tau, inv_temp = 1.f / a.temp;
+    float tmp[NR][CP];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int t = 0; t < CP; ++t) tmp[r][t] = cp[r][t] * inv_tau;
+    softmax_rows(tmp, cc);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int t = 0; t < CP; ++t) lc[r][t] = logf(cc[r][t] + eps);
+    // ---- Gumbel-softmax sample
+    bool hard = a.hard != 0;
+    if (a.eval_flag) {
+        hard = true;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int t = 0; t < CP; ++t) ys[r][t] = cc[r][t];
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int t = 0; t < CP; ++t) {
+                tmp[r][t] = 0.f;
+                if (vcol[t]) {
+                    const float U = gumbel_u(nz, arm, B, C, min(bb[r], B - 1), sub + 32 * t);
+                    const float g = -logf(-logf(U + eps) + eps);
+                    tmp[r][t] = (lc[r][t] + g) * inv_temp;
+                }
+            }
+        softmax_rows(tmp, ys);
+    }
+    if (hard) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            float mv = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < CP; ++t) if (vcol[t]) mv = fmaxf(mv, ys[r][t]);
+            mv = half_max(mv);
+            int cand = 1 << 30;
+#pragma unroll
+            for (int t = 0; t < CP; ++t) if (vcol[t] && ys[r][t] == mv) cand = min(cand, sub + 32 * t);
+            cand = half_min_i(cand);
+#pragma unroll
+            for (int t = 0; t < CP; ++t) {
+                const float hv = (sub + 32 * t == cand) ? 1.f : 0.f;
+                cs[r][t] = (hv - ys[r][t]) + ys[r][t];   // (y_hard - y).detach() + y, nn_model.py:492
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int t = 0; t < CP; ++t) cs[r][t] = ys[r][t];
+    }
+    // ---- store; c goes to the workgroup tile for the block statistics (zero rows beyond the batch)
+    float kl_acc = 0.f, ent_acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int t = 0; t < CP; ++t) {
+            const int col = sub + 32 * t;
+            sh_buf[slot[r] * 128 + col] = (okr[r] && vcol[t]) ? cc[r][t] : 0.f;
+            if (okr[r] && vcol[t]) {
+                const int64_t o = (ab + bb[r]) * C + col;
+                ws[a.CPROB + o] = cp[r][t];
+                ws[a.CC + o] = cc[r][t];
+                ws[a.YSOFT + o] = ys[r][t];
+                ws[a.CSMP + o] = cs[r][t];
+                ws[a.Y + (ab + bb[r]) * (L + C) + L + col] = cs[r][t];
+                ws[a.ZIN + (ab + bb[r]) * (C + S) + col] = cs[r][t];
+                ent_acc += cc[r][t] * lc[r][t];
+            }
+        }
+    }
+    // ---- state head: [mu | sigma_pre] = y [Wmu; Wsigma]^T + b
+    float mso[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) mso[r] = 0.f;
+    for (int o = 0; o < 2 * S; ++o) {
+        const float* w = Wms + (int64_t)o * (L + C);
+        const float wl = sub < L ? w[sub] : 0.f;
+        float wc[CP], pr[NR];
+#pragma unroll
+        for (int t = 0; t < CP; ++t) wc[t] = vcol[t] ? w[L + sub + 32 * t] : 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            pr[r] = xl[r] * wl;
+#pragma unroll
+            for (int t = 0; t < CP; ++t) pr[r] += cs[r][t] * wc[t];
+        }
+        const float bo = bms[o];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float pv = half_sum(pr[r]) + bo;
+            if (sub == o) mso[r] = pv;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (okr[r] && sub < 2 * S) ws[a.MS + (ab + bb[r]) * 2 * S + sub] = mso[r];
+        const float sg = __shfl(mso[r], hb + ((sub + S) & 31), 64);
+        if (okr[r] && sub < S) {
+            const int b = bb[r];
+            const float mu = mso[r];
+            const float var = 1.f / (1.f + expf(-sg));
+            const float lv = logf(var + eps);
+            const float sd = sqrtf(expf(lv));
+            const float U = state_u(nz, arm, B, S, b, sub);
+            const float sv = U * sd + mu;
+            float sin_ = sv;
+            if (a.training && a.s_drop > 0.f) sin_ = state_keep(nz, arm, B, S, b, sub) ? sv / (1.f - a.s_drop) : 0.f;
+            ws[a.MU + (ab + b) * S + sub] = mu;
+            ws[a.LV + (ab + b) * S + sub] = lv;
+            ws[a.SS + (ab + b) * S + sub] = sv;
+            ws[a.ZIN + (ab + b) * (C + S) + C + sub] = sin_;
+            kl_acc += 1.f + lv - mu * mu - expf(lv);
+        }
+    }
+    // ---- block partials (as k_lat_fwd): two passes over the LDS tile, NT / 128 row groups
+    kl_acc = wave_sum(kl_acc);
+    ent_acc = wave_sum(ent_acc);
+    if (lane == 0) { sh_red[wv][0] = kl_acc; sh_red[wv][1] = ent_acc; }
+    lds_barrier();
+    {
+        constexpr int G = NT / 128, RPG = LAT_ROWS / G;
+        const int col = threadIdx.x & 127, g = threadIdx.x >> 7;
+        const int nv = min(LAT_ROWS, B - b0);
+        const bool live = col < 32 * CP;              // columns the cells wrote
+        float v[RPG];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) { v[i] = live ? sh_buf[(g + G * i) * 128 + col] : 0.f; s1 += v[i]; }
+        sh_ps[g][col] = s1;
+        lds_barrier();
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < G; ++k) tot += sh_ps[k][col];
+        const float mean = tot / (float)nv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) { const float d = v[i] - mean; q += (g + G * i < nv) ? d * d : 0.f; }
+        lds_barrier();
+        sh_ps[g][col] = q;
+        lds_barrier();
+        if (g == 0 && col < C) {
+            float m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < G; ++k) m2 += sh_ps[k][col];
+            float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
+            p[col] = mean;
+            p[C + col] = m2;
+        }
+    }
+    if (threadIdx.x == 0) {
+        float* p = ws + a.lat_part + ((int64_t)arm * gridDim.x + blk) * 2;
+        float k0 = 0.f, k1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < LH_NW; ++w) { k0 += sh_red[w][0]; k1 += sh_red[w][1]; }
+        p[0] = k0;
+        p[1] = k1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // coupling: for every cell, over all arms.  u_a = log(c_a + eps) * iv_a
 //   dist += sum_{a<b} |u_a - u_b|^2 ;  l2 += sum_{a<b} |c_smp_a - c_smp_b|^2
 //   T_part[a][k] += G_a[k] * log(c_a[k] + eps),  G_a = (2 lam / B) (A u_a - sum_b u_b)
@@ -981,6 +1293,13 @@ int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, flo
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
+    static const int fullwave = getenv("MMVAE_LAT_FULLWAVE") ? atoi(getenv("MMVAE_LAT_FULLWAVE")) : 0;   // A/B timing
+    if (!fullwave && a.dbg_off < 0 && c.d.C <= 32 * LH_CPL && c.d.L <= 32 && 2 * c.d.S <= 32) {
+        hipLaunchKernelGGL(k_lat_fwd_h, dim3(c.lay.nblkl, c.d.A), dim3(64 * LH_NW), shm, c.stream, a, nd, params, c.ws,
+                           bn_running, nbt);
+        HIP_LAUNCH_CHECK("k_lat_fwd_h");
+        return 0;
+    }
     hipLaunchKernelGGL(k_lat_fwd, dim3(c.lay.nblkl, c.d.A), dim3(64 * LAT_NW), shm, c.stream, a, nd, params, c.ws,
                        bn_running, nbt);
     HIP_LAUNCH_CHECK("k_lat_fwd");
