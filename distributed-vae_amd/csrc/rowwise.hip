@@ -1086,6 +1086,198 @@ __global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Half-wave layout of the latent backward (same limits and reasons as k_lat_fwd_h): a cell owns 32 lanes x 3
+// registers, a wave instruction serves two cells.  4 waves x 2 halves x 2 cells = LAT_ROWS_BWD cells per workgroup
+// (the partial layout of k_lat_bwd).
+// ---------------------------------------------------------------------------------------------
+constexpr int LBH_NW = 4, LBH_NR = LAT_ROWS_BWD / (LBH_NW * 2);
+static_assert(LBH_NR * LBH_NW * 2 == LAT_ROWS_BWD, "LAT_ROWS_BWD must be a multiple of 8");
+__global__ __launch_bounds__(64 * LBH_NW) void k_lat_bwd_h(const LatArgs a_in, const NoiseDev nz_in,
+                                                          const float* __restrict__ params, float* __restrict__ ws) {
+    constexpr int NR = LBH_NR, CP = LH_CPL;
+    const LatArgs a = a_in;
+    const NoiseDev nz = nz_in;
+    extern __shared__ __attribute__((aligned(16))) float lat_smem[];
+    __shared__ float sh_s[LBH_NW][2][64];
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * LAT_ROWS_BWD;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane & 31, hb = lane & 32, half = lane >> 5;
+    const int A = a.A, B = a.B, L = a.L, C = a.C, S = a.S;
+    const float* P = params + (int64_t)arm * a.per_arm;
+    float* WcT = lat_smem;            // [L][C]
+    float* Wms = lat_smem + C * L;    // [2S][L+C]
+    lat_stage_weights(WcT, Wms, P + a.o_wc, P + a.o_wms, L, C, S);
+    const int64_t ab = (int64_t)arm * B;
+    const float eps = a.eps, invB = 1.f / (float)B;
+    const float coefG = 2.f * a.lam * invB;
+
+    bool vcol[CP];
+    float Tk[CP], cmean[CP], ivm[CP], ivall[MMVAE_MAX_ARMS][CP];
+#pragma unroll
+    for (int t = 0; t < CP; ++t) {
+        const int col = sub + 32 * t;
+        vcol[t] = col < C;
+        Tk[t] = vcol[t] ? ws[a.T + arm * C + col] : 0.f;
+        cmean[t] = vcol[t] ? ws[a.c_mean + arm * C + col] : 0.f;
+        ivm[t] = vcol[t] ? ws[a.c_iv + arm * C + col] : 0.f;
+#pragma unroll
+        for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa) ivall[aa][t] = (aa < A && vcol[t]) ? ws[a.c_iv + aa * C + col] : 0.f;
+    }
+    float s1 = 0.f, s2 = 0.f;   // BN5 backward sums for column `sub` (< L), this half's cells
+
+    int bb[NR];
+    bool okr[NR];
+    float gs_l[NR], mu_l[NR], lv_l[NR], sg_l[NR], xlow_l[NR];
+    float cc[NR][CP], ys[NR][CP], gz[NR][CP], cp[NR][CP], call[NR][MMVAE_MAX_ARMS][CP];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        bb[r] = b0 + r * (LBH_NW * 2) + wv * 2 + half;
+        okr[r] = bb[r] < B;                         // per half-wave
+        const int64_t b = min(bb[r], B - 1);        // cells beyond the batch recompute the last cell; nothing is stored
+        gs_l[r] = sub < S ? ws[a.GZIN + (ab + b) * (C + S) + C + sub] : 0.f;
+        mu_l[r] = sub < S ? ws[a.MU + (ab + b) * S + sub] : 0.f;
+        lv_l[r] = sub < S ? ws[a.LV + (ab + b) * S + sub] : 0.f;
+        sg_l[r] = sub < S ? ws[a.MS + (ab + b) * 2 * S + S + sub] : 0.f;
+        xlow_l[r] = sub < L ? ws[a.XLOW + (ab + b) * L + sub] : 0.f;
+#pragma unroll
+        for (int t = 0; t < CP; ++t) {
+            const int col = sub + 32 * t;
+            const int64_t o = (ab + b) * C + col;
+            cc[r][t] = vcol[t] ? ws[a.CC + o] : 0.f;
+            ys[r][t] = vcol[t] ? ws[a.YSOFT + o] : 0.f;
+            cp[r][t] = vcol[t] ? ws[a.CPROB + o] : 0.f;
+            gz[r][t] = vcol[t] ? ws[a.GZIN + (ab + b) * (C + S) + col] : 0.f;
+#pragma unroll
+            for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+                call[r][aa][t] = (aa < A && vcol[t]) ? ws[a.CC + ((int64_t)aa * B + b) * C + col] : 1.f;
+        }
+    }
+    const float inv_temp = 1.f / a.temp, inv_tau = 1.f / a.tau, inv_bm1 = 1.f / (float)(B - 1);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int b = min(bb[r], B - 1);
+        // ---- state head backward (lanes sub < S of each half)
+        float gms = 0.f;   // sub = o < 2S: d loss / d MS[o]
+        {
+            float gmu = 0.f, gsig = 0.f;
+            if (sub < S) {
+                float gs = gs_l[r];
+                if (a.training && a.s_drop > 0.f)
+                    gs = state_keep(nz, arm, B, S, b, sub) ? gs / (1.f - a.s_drop) : 0.f;
+                const float mu = mu_l[r], lv = lv_l[r], sg = sg_l[r];
+                const float var = 1.f / (1.f + expf(-sg));
+                const float U = state_u(nz, arm, B, S, b, sub);
+                const float elv = expf(lv);
+                gmu = gs + a.am1 * a.beta * mu * invB;
+                const float glv = gs * U * 0.5f * sqrtf(elv) + a.am1 * a.beta * (-0.5f * invB) * (1.f - elv);
+                const float gvar = glv / (var + eps);
+                gsig = gvar * var * (1.f - var);
+            }
+            const float gsig_sh = __shfl(gsig, hb + ((sub - S) & 31), 64);   // sub S+s takes sub s's gsig
+            if (sub < S) gms = gmu;
+            else if (sub < 2 * S) gms = gsig_sh;
+            if (okr[r] && sub < 2 * S) ws[a.GMS + (ab + b) * 2 * S + sub] = gms;
+        }
+        // ---- gy = gms [Wmu; Wsigma]
+        float gxl = 0.f, gcs[CP];
+#pragma unroll
+        for (int t = 0; t < CP; ++t) gcs[t] = 0.f;
+        for (int o = 0; o < 2 * S; ++o) {
+            const float go = __shfl(gms, hb + o, 64);
+            const float* w = Wms + (int64_t)o * (L + C);
+            if (sub < L) gxl += go * w[sub];
+#pragma unroll
+            for (int t = 0; t < CP; ++t) if (vcol[t]) gcs[t] += go * w[L + sub + 32 * t];
+        }
+        // ---- gradient w.r.t. the sample, through the Gumbel softmax to c
+        float lc[CP], gc[CP], usum[CP], rcc[CP];
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < CP; ++t) {
+            lc[t] = gc[t] = usum[t] = 0.f;
+            rcc[t] = 1.f / (cc[r][t] + eps);
+            if (vcol[t]) {
+                gcs[t] += gz[r][t];
+                dot += ys[r][t] * gcs[t];
+#pragma unroll
+                for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+                    if (aa < A) {
+                        const float l_aa = logf(call[r][aa][t] + eps);
+                        usum[t] += l_aa * ivall[aa][t];
+                        if (aa == arm) lc[t] = l_aa;
+                    }
+            }
+        }
+        if (a.eval_flag) {
+#pragma unroll
+            for (int t = 0; t < CP; ++t) gc[t] = gcs[t];
+        } else {
+            dot = half_sum(dot);
+#pragma unroll
+            for (int t = 0; t < CP; ++t) gc[t] = (ys[r][t] * (gcs[t] - dot) * inv_temp) * rcc[t];
+        }
+        // ---- coupling / entropy terms on c (nn_model.py:558-569)
+        float dot2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < CP; ++t) {
+            if (vcol[t]) {
+                const float G = coefG * ((float)A * lc[t] * ivm[t] - usum[t]);
+                gc[t] += (float)(A - 1) * (lc[t] + cc[r][t] * rcc[t]) * invB;
+                gc[t] += G * ivm[t] * rcc[t];
+                gc[t] += (Tk[t] * (-0.5f) * ivm[t] * ivm[t] * ivm[t]) * 2.f * (cc[r][t] - cmean[t]) * inv_bm1;
+                dot2 += cc[r][t] * gc[t];
+            } else {
+                gc[t] = 0.f;
+            }
+        }
+        dot2 = half_sum(dot2);
+        // ---- double softmax backward
+        float gq[CP], dot3 = 0.f;
+#pragma unroll
+        for (int t = 0; t < CP; ++t) {
+            gq[t] = cc[r][t] * (gc[t] - dot2) * inv_tau;
+            dot3 += cp[r][t] * gq[t];
+        }
+        dot3 = half_sum(dot3);
+        float gzc[CP];
+#pragma unroll
+        for (int t = 0; t < CP; ++t) {
+            gzc[t] = cp[r][t] * (gq[t] - dot3);
+            if (okr[r] && vcol[t]) ws[a.GZC + (ab + b) * C + sub + 32 * t] = gzc[t];
+        }
+        // ---- g5 = gy[:, :L] + gzc Wc
+        float g5 = 0.f;
+        for (int k = 0; k < L; ++k) {
+            float p = 0.f;
+#pragma unroll
+            for (int t = 0; t < CP; ++t) if (vcol[t]) p += gzc[t] * WcT[k * C + sub + 32 * t];
+            p = half_sum(p);
+            if (sub == k) g5 = gxl + p;
+        }
+        if (okr[r] && sub < L) {
+            ws[a.G5 + (ab + b) * L + sub] = g5;
+            s1 += g5;
+            s2 += g5 * xlow_l[r];
+        }
+    }
+    sh_s[wv][0][lane] = s1;
+    sh_s[wv][1][lane] = s2;
+    lds_barrier();
+    if (threadIdx.x < L) {
+        const int k = threadIdx.x;
+        float* p = ws + a.bnb_part5 + (((int64_t)arm * gridDim.x + blk) * 2) * L;
+        float k0 = 0.f, k1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < LBH_NW; ++w) {
+            k0 += sh_s[w][0][k] + sh_s[w][0][32 + k];      // the two halves hold different cells
+            k1 += sh_s[w][1][k] + sh_s[w][1][32 + k];
+        }
+        p[k] = k0;
+        p[L + k] = k1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // slabs -> flat gradient buffer
 // ---------------------------------------------------------------------------------------------
 struct RedDesc {
@@ -1330,6 +1522,12 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
+    static const int fullwave = getenv("MMVAE_LAT_FULLWAVE") ? atoi(getenv("MMVAE_LAT_FULLWAVE")) : 0;   // A/B timing
+    if (!fullwave && c.d.C <= 32 * LH_CPL && c.d.L <= 32 && 2 * c.d.S <= 32) {
+        hipLaunchKernelGGL(k_lat_bwd_h, dim3(cdiv(c.d.B, LAT_ROWS_BWD), c.d.A), dim3(64 * LBH_NW), shm, c.stream, a, nd, params, c.ws);
+        HIP_LAUNCH_CHECK("k_lat_bwd_h");
+        return 0;
+    }
     hipLaunchKernelGGL(k_lat_bwd, dim3(cdiv(c.d.B, LAT_ROWS_BWD), c.d.A), dim3(64 * LATB_NW), shm, c.stream, a, nd, params, c.ws);
     HIP_LAUNCH_CHECK("k_lat_bwd");
     return 0;
