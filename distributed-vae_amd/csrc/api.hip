@@ -21,11 +21,20 @@ static int g_split[6] = {0, 0, 0, 0, 0, 0};
 // second, mostly empty round: e.g. 624 workgroups on 512 slots take two rounds, 468 take one.
 Splits default_splits(const mmvae_dims& d) {
     constexpr int CUS = 256;
+    // smallest split whose grid fills whole rounds of the resident slots to >= 93 % (else the best-filling one):
+    // with A = 5 a single round would leave a fifth of the chip idle (200 k workgroups on 512 slots: k = 2 -> 78 %,
+    // k = 5 -> 98 % in two rounds; fc1 64 -> 58 us per arm)
     auto fit = [](int base_blocks, int slots, int cap) {
-        int k = slots / (base_blocks > 0 ? base_blocks : 1);
-        if (k > cap) k = cap;
-        if (k < 1) k = 1;
-        return k;
+        const int base = base_blocks > 0 ? base_blocks : 1;
+        int best = 1;
+        double best_eff = 0.0;
+        for (int k = 1; k <= cap; ++k) {
+            const int n = base * k;
+            const double eff = (double)n / (double)(((n + slots - 1) / slots) * slots);
+            if (eff >= 0.93) return k;
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+        }
+        return best;
     };
     Splits s;
     const int nb128 = cdiv(d.B, 128), nb64 = cdiv(d.B, 64);
@@ -48,6 +57,21 @@ Splits default_splits(const mmvae_dims& d) {
     s.ks_small = g_split[3] > 0 ? g_split[3] : fit(N_SMALL * d.A, 3 * CUS, 32);   // 3 workgroups / CU (136 VGPRs)
     s.ks_small = min(s.ks_small, max(1, cdiv(d.B, 32)));
     s.ks_gd10 = g_split[4] > 0 ? g_split[4] : fit(nb128 * d.A, (fastdims && d.H == 100 ? 2 : 3) * CUS, 16);   // fc_dim 100: k_gd10_v3, 2 / CU
+    if (g_split[4] <= 0 && fastdims && d.H == 100) {
+        // this is also k_fc11_zg's gene split, and that kernel fits one 256-cell workgroup per CU (152 KB of LDS): take
+        // the smallest split whose grid fills whole rounds of the chip (A = 5: 2 -> 5, 200 -> 500 workgroups,
+        // 609 -> 529 us; A = 2 keeps 6)
+        const int wg = cdiv(d.B, 256) * d.A;
+        int best = s.ks_gd10;
+        double best_eff = 0.0;
+        for (int ks = 1; ks <= 16; ++ks) {
+            const int n = wg * ks;
+            const double eff = (double)n / (double)(cdiv(n, CUS) * CUS);
+            if (eff > best_eff + 0.02) { best_eff = eff; best = ks; }
+            if (eff >= 0.93) { best = ks; break; }
+        }
+        s.ks_gd10 = best;
+    }
     s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, fastdims && d.H == 100 ? 64 : 32)));   // fc_dim 100: also k_fc11_zg's gene split
     return s;
 }
