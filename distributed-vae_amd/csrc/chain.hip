@@ -451,6 +451,30 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
             wq_valid = w_split_ok(P + Ln.w_off, Ln.K, rup(Ln.N, 8), rup(Ln.K, 32));
             if (wq_valid) w_load(wq, P + Ln.w_off, Ln.N, Ln.K);
         }
+        // the epilogue's global operands -- the saved activation that gates ReLU', or the BatchNorm input of the last
+        // layer -- are requested here, in front of the GEMM: fetched after it they cost one exposed memory latency per
+        // layer (five per decoder launch)
+        const bool last = (l + 1 == a.nlayers);
+        float pre[2][16];
+        {
+            const float* src = nullptr;
+            if (!last) {
+                const BwdLayer Ln = a.L[l + 1];
+                src = Ln.act_off >= 0 ? ws + Ln.act_off + (int64_t)arm * B * K : nullptr;
+            } else if (a.part_off >= 0) {
+                src = ws + a.rprev_off + (int64_t)arm * B * K;
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int col = (ct + 4 * ti) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + acc_row(r, lane);
+                    const bool ok = src && (ct + 4 * ti) * 32 < KPad && col < K && row < nvalid;
+                    pre[ti][r] = ok ? src[(int64_t)(b0 + row) * K + col] : (last ? 0.f : 1.f);
+                }
+            }
+        }
         // input width K may reach 255 (fc6: K = C + S): up to 8 column tiles, two per wave
         f32x16 accs[2] = {zero16(), zero16()};
 #pragma unroll
@@ -459,7 +483,6 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
             if (cti * 32 < KPad) mma_nn(accs[ti], Gs, ld, rt * 32, Ws, ld, cti * 32, NP8 / 8);
         }
         lds_barrier();
-        const bool last = (l + 1 == a.nlayers);
         float ps1[2] = {0.f, 0.f}, ps2[2] = {0.f, 0.f};
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -469,20 +492,12 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
             const int col = cti * 32 + (lane & 31);
             if (!last) {
                 const BwdLayer Ln = a.L[l + 1];   // its N == this K
-                const float* act = Ln.act_off >= 0 ? ws + Ln.act_off + (int64_t)arm * B * K : nullptr;
                 float* dz = ws + Ln.dz_off + (int64_t)arm * B * K;
-                float av[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + acc_row(r, lane);
                     const bool ok = col < K && row < nvalid;
-                    av[r] = (act && ok) ? act[(int64_t)(b0 + row) * K + col] : 1.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rt * 32 + acc_row(r, lane);
-                    const bool ok = col < K && row < nvalid;
-                    const float v = (ok && av[r] > 0.f) ? acc[r] : 0.f;
+                    const float v = (ok && pre[ti][r] > 0.f) ? acc[r] : 0.f;
                     if (ok) dz[(int64_t)(b0 + row) * K + col] = v;
                     Gs[row * ld + col] = v;
                 }
@@ -490,18 +505,10 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
                 float* go = ws + a.gout_off + (int64_t)arm * B * K;
                 float s1 = 0.f, s2 = 0.f;
                 const bool want = a.part_off >= 0;
-                const float* rp = want ? ws + a.rprev_off + (int64_t)arm * B * K : nullptr;
                 float mu = 0.f, rs = 0.f;
                 if (want && col < K) {
                     mu = ws[a.rprev_mean_off + (int64_t)arm * K + col];
                     rs = ws[a.rprev_rstd_off + (int64_t)arm * K + col];
-                }
-                float rv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rt * 32 + acc_row(r, lane);
-                    const bool ok = col < K && row < nvalid;
-                    rv[r] = (want && ok) ? rp[(int64_t)(b0 + row) * K + col] : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
                     if (col < K && row < nvalid) {
                         go[(int64_t)(b0 + row) * K + col] = acc[r];
                         s1 += acc[r];
-                        s2 += acc[r] * ((rv[r] - mu) * rs);
+                        s2 += acc[r] * ((pre[ti][r] - mu) * rs);
                     }
                 }
                 if (want) {
