@@ -223,6 +223,8 @@ EDGE = [
     (8, 16, 32, 8, 2, 4, 1, False, 0.0, 0.5),        # MMVAE_MAX_ARMS arms: 28 coupled pairs
     (2, 300, 64, 128, 64, 128, 32, False, 0.5, 0.9), # every kernel limit at once, heavy dropout
     (3, 65, 260, 36, 9, 30, 2, True, 0.0, 0.5),      # one cell past a 64-row block, 4 genes past a 64-gene tile
+    (2, 70, 64, 32, 32, 96, 16, False, 0.2, 0.5),    # the limits of the half-wave latent kernels (C = 96, L = 32, 2S = 32)
+    (2, 70, 64, 32, 33, 97, 2, True, 0.0, 0.5),      # one past them: the one-wave-per-cell kernels
 ]
 
 
