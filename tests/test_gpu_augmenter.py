@@ -163,3 +163,35 @@ def test_pipelined_epoch_equals_unpipelined():
         res.append((torch.stack(bufs).cpu(), t.model.flat_parameters().clone().cpu()))
     assert res[0][0].shape[0] == 5
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_trainer_train_loop_with_augmenter_loaders_consensus_and_validation(tmp_path):
+    """The whole mirrored loop of cpl_mixvae.py:397-790 on the device: device-resident loaders, augmenter in front of
+    every step (pipelined), per-epoch consensus, the validation block (batch_size-1 test loader = one batch), the
+    checkpoint at the end -- and the checkpoint loads back."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    from distributed_vae_amd.utils import dataloader as DL
+    from oracle import restatement as R
+    A, D, C = 2, 64, 6
+    X = R.synthetic_batch(330, D, seed=3)
+    tr, te, al = DL.get_loaders(X.numpy(), seed=546, batch_size=64, device=DEV)
+    torch.manual_seed(5)
+    t = cpl_mixVAE(saving_folder=str(tmp_path), device=DEV, save_flag=True)
+    t.init_model(n_categories=C, state_dim=2, input_dim=D, fc_dim=16, lowD_dim=4, x_drop=0.5, s_drop=0.0, n_arm=A)
+    netA = Augmenter_smartseq(8, 4, D, 40)
+    netA.load_state_dict(OA.random_state_dict(8, 4, D, 40, seed=2))
+    t.set_augmenter(netA)
+    hist = t.train(tr, te, n_epoch=3)
+    for key in ("losses", "validation_loss", "validation_rec_loss", "consensus_train", "consensus_val"):
+        assert len(hist[key]) == 3 and np.isfinite(hist[key]).all(), key
+    assert all(0.0 <= v <= 1.0 for v in hist["consensus_train"] + hist["consensus_val"])
+    assert hist["losses"][-1] < hist["losses"][0]                    # it learns
+    ckpts = [f for f in os.listdir(os.path.join(str(tmp_path), "model")) if f.endswith(".pth")]
+    assert ckpts
+    t2 = cpl_mixVAE(saving_folder=str(tmp_path), device=DEV, save_flag=False)
+    t2.init_model(n_categories=C, state_dim=2, input_dim=D, fc_dim=16, lowD_dim=4, x_drop=0.5, s_drop=0.0, n_arm=A,
+                  trained_model=os.path.join(str(tmp_path), "model", ckpts[0]))
+    for (k, v), (k2, v2) in zip(t.model.state_dict().items(), t2.model.state_dict().items()):
+        assert k == k2 and torch.equal(v.cpu(), v2.cpu()), k
