@@ -164,13 +164,7 @@ def main():
     def step(i):
         xs = batches[i % nb].expand(A, -1, -1)
         if world > 1 or args.rehearse_dp:
-            buf = model.fused_train_step(xs, 1.0, opt, do_adam=False)
-            if world > 1:
-                DD.allreduce_mean_(model.flat_grad())
-            else:
-                dist.all_reduce(model.flat_grad(), op=dist.ReduceOp.AVG)
-            opt.step()
-            return buf
+            return DD.dp_train_step(model, xs, 1.0, opt, rehearse=args.rehearse_dp)
         return model.fused_train_step(xs, 1.0, opt, do_adam=True)
 
     for i in range(args.warmup):

@@ -99,6 +99,9 @@ def lib():
     L.mmvae_set_split.argtypes = [C.c_int, C.c_int]
     L.mmvae_set_side_stream.argtypes = [vp]
     L.mmvae_set_side_stream.restype = C.c_int
+    L.mmvae_set_early_grad_event.argtypes = [vp]
+    L.mmvae_set_early_grad_event.restype = C.c_int
+    L.mmvae_early_grad_event_recorded.restype = C.c_int
     L.mmvae_forward.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp, i32,
                                 vp, C.c_size_t, vp]
     L.mmvae_loss.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, C.c_size_t, vp, vp]
@@ -207,6 +210,7 @@ class Engine:
         self.loss_buf = torch.zeros(5 + 3 * A, dtype=torch.float32, device=self.device)
         # side stream: the dW11 GEMM overlaps the latency-bound backward chain (MMVAE_SIDE_STREAM=0 disables)
         self.side = None
+        self.early_event = None
         if os.environ.get("MMVAE_SIDE_STREAM", "1") != "0":
             # High priority: HIP maps streams of one priority onto a small set of hardware queues round-robin; once
             # RCCL has created its streams the side stream can share a queue with the main stream and the overlap is
@@ -216,6 +220,21 @@ class Engine:
 
     def _bind_side(self):
         lib().mmvae_set_side_stream(C.c_void_p(self.side.cuda_stream) if self.side is not None else None)
+        ev = self.early_event
+        lib().mmvae_set_early_grad_event(C.c_void_p(ev.cuda_event) if ev is not None else None)
+
+    def enable_early_grad_event(self, on: bool = True):
+        """Data-parallel overlap: the next train_step(do_adam=False) records ``self.early_event`` on the side stream
+        once the fc11 gradients are final (see ``early_recorded``)."""
+        if on and self.early_event is None and self.side is not None:
+            self.early_event = torch.cuda.Event()
+            self.early_event.record()              # creates the underlying hipEvent_t
+        elif not on:
+            self.early_event = None
+
+    @staticmethod
+    def early_recorded() -> bool:
+        return bool(lib().mmvae_early_grad_event_recorded())
 
     def ws_view(self, name: str, width: int) -> torch.Tensor:
         off = int(lib().mmvae_ws_offset(C.byref(self.dims), WS_IDS[name]))

@@ -177,10 +177,7 @@ class cpl_mixVAE:
     # ---------------------------------------------------------------------------------------
     def _step(self, xs: torch.Tensor):
         if D.is_dist():
-            buf = self.model.fused_train_step(xs, self.temp, self.optimizer, do_adam=False)
-            D.allreduce_mean_(self.model.flat_grad())
-            self.optimizer.step()
-            return buf
+            return D.dp_train_step(self.model, xs, self.temp, self.optimizer)
         return self.model.fused_train_step(xs, self.temp, self.optimizer, do_adam=True)
 
     def train_step(self, x: torch.Tensor):

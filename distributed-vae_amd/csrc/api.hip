@@ -204,6 +204,8 @@ static int check_noise(const Ctx& c, const mmvae_noise* nz) {
 }
 
 static thread_local hipStream_t g_side = nullptr;
+static thread_local hipEvent_t g_ev_early = nullptr;   // caller's event: fc11 gradients final (mmvae_set_early_grad_event)
+static thread_local int g_early_recorded = 0;          // did the last backward of this thread record it?
 static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_lat = nullptr, g_ev_couple = nullptr,
                                g_ev_fc11 = nullptr, g_ev_dec = nullptr, g_ev_enc = nullptr;
 
@@ -291,6 +293,8 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     static const int dw11_at = getenv("MMVAE_DW11_AT") ? atoi(getenv("MMVAE_DW11_AT")) : 0;
     bool forked = false;
     const bool use_side = fast && g_side;
+    const bool early = use_side && !adam && g_ev_early != nullptr;
+    g_early_recorded = 0;
     auto fork_dw11 = [&]() -> int {
         if (!g_ev_fork) {
             if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -306,6 +310,13 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
             return MMVAE_E_LAUNCH;
         }
         if (int r = launch_dw_big_fast(cs2, x, xs, 2)) return r;
+        if (early) {
+            // data parallel: fc11.weight / fc11.bias (47 % of the parameters) are final here; reduce their slabs now
+            // and tell the caller, who starts their all-reduce beside the rest of backward
+            if (int r = launch_reduce_grads(cs2, grads, grad_scale, nullptr, true, 1)) return r;
+            if (hipEventRecord(g_ev_early, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+            g_early_recorded = 1;
+        }
         if (hipEventRecord(g_ev_join, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
         forked = true;
         return 0;
@@ -356,7 +367,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     }
     if (!small_on_side && (rc = launch_dw_small(c))) return rc;
     if (forked && hipStreamWaitEvent(c.stream, g_ev_join, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
-    return launch_reduce_grads(c, grads, grad_scale, adam, fast);
+    return launch_reduce_grads(c, grads, grad_scale, adam, fast, (early && forked) ? 2 : 3);
 }
 
 }  // namespace mmvae
@@ -373,6 +384,13 @@ int mmvae_set_side_stream(void* side_stream) {
     g_side = reinterpret_cast<hipStream_t>(side_stream);
     return 0;
 }
+
+int mmvae_set_early_grad_event(void* event) {
+    g_ev_early = reinterpret_cast<hipEvent_t>(event);
+    return 0;
+}
+
+int mmvae_early_grad_event_recorded(void) { return g_early_recorded; }
 
 int mmvae_set_split(int which, int value) {
     if (which < 0 || which > 5 || value < 0 || value > 64) { set_error("bad split"); return MMVAE_E_BADARG; }

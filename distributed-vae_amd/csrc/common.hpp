@@ -554,7 +554,8 @@ int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t x
 int launch_dw_small(const Ctx& c, int which = 3 /*bit0 decoder layers, bit1 encoder side*/);
 struct AdamHost { float* p; float* m; float* v; int64_t step; float lr, b1, b2, eps, wd; int decoupled; };
 // slabs -> grads; with `adam` (p != null) the Adam update is fused into the same pass
-int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale, const AdamHost* adam, bool dw11_fast);
+int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale, const AdamHost* adam, bool dw11_fast,
+                        int which = 3 /*bit0 fc11 tensors, bit1 the rest*/);
 int launch_adam(int64_t n, float* p, const float* g, float* m, float* v, int64_t step, float lr, float b1,
                 float b2, float eps, float wd, int decoupled, hipStream_t s);
 bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs);

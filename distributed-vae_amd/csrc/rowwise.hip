@@ -1533,7 +1533,8 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     return 0;
 }
 
-int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost* ah, bool dw11_fast) {
+// which: bit 0 = fc11.weight / fc11.bias (final as soon as the dW11 GEMM is), bit 1 = everything else
+int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost* ah, bool dw11_fast, int which) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int A = d.A, H = d.H, D = d.D, Ld = d.L, C = d.C, S = d.S;
@@ -1574,12 +1575,22 @@ int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost
     // two launches: the three large tensors want thousands of workgroups, the 23 small ones a handful
     const int64_t big_elems = (int64_t)max(H, 1) * D;
     const int gx = (int)imin64(2048, cdiv64(big_elems / 4, 256));
-    hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, grads, c.po.per_arm, aa);
+    if (which == 3) {
+        hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, grads, c.po.per_arm, aa);
+    } else {
+        RedDescs dsb{};
+        int nb = 0;
+        if (which & 2) dsb.d[nb++] = ds.d[0];
+        if (which & 1) { dsb.d[nb++] = ds.d[1]; dsb.d[nb++] = ds.d[2]; }
+        if (nb) hipLaunchKernelGGL(k_reduce, dim3(gx, nb, A), dim3(256), 0, c.stream, dsb, grads, c.po.per_arm, aa);
+    }
     HIP_LAUNCH_CHECK("k_reduce<big>");
-    RedDescs ds2{};
-    for (int i = nbig; i < n; ++i) ds2.d[i - nbig] = ds.d[i];
-    hipLaunchKernelGGL(k_reduce, dim3(16, n - nbig, A), dim3(256), 0, c.stream, ds2, grads, c.po.per_arm, aa);
-    HIP_LAUNCH_CHECK("k_reduce");
+    if (which & 2) {
+        RedDescs ds2{};
+        for (int i = nbig; i < n; ++i) ds2.d[i - nbig] = ds.d[i];
+        hipLaunchKernelGGL(k_reduce, dim3(16, n - nbig, A), dim3(256), 0, c.stream, ds2, grads, c.po.per_arm, aa);
+        HIP_LAUNCH_CHECK("k_reduce");
+    }
     return 0;
 }
 

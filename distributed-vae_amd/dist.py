@@ -64,6 +64,46 @@ def allreduce_mean_(buf: torch.Tensor):
     return buf
 
 
+def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
+    """One data-parallel step: fused forward + loss + backward, gradient all-reduce (average), Adam.
+
+    Default: ONE all-reduce of the whole flat buffer when backward is done.  MMVAE_DP_OVERLAP=1 (RCCL only) splits it:
+    the fc11.weight / fc11.bias ranges of every arm (47 % of the buffer) are final as soon as their GEMM has finished
+    on the side stream, so their all-reduce starts there, on a communication stream, beside the rest of backward, and
+    the remaining ranges follow.  Off by default: on one rank (`bench.py --rehearse-dp`) the 2 A collectives and the
+    extra reduction launch cost 65 us per step (1.07 ms against 1.005 ms), more than half of an 8.6 MB all-reduce
+    over xGMI can give back; it needs a multi-GPU node to be tuned (fewer, coalesced collectives)."""
+    import os
+    from . import _native as N
+    active = is_dist() or (rehearse and dist.is_available() and dist.is_initialized())   # rehearse: world size 1
+    overlap = (active and dist.get_backend() == "nccl" and os.environ.get("MMVAE_DP_OVERLAP", "0") == "1")
+    B = xs.shape[-2]
+    eng = model._ensure(B)
+    eng.enable_early_grad_event(overlap)
+    buf = model.fused_train_step(xs, temp, optimizer, do_adam=False)
+    flat = model.flat_grad()
+    if overlap and eng.early_event is not None and eng.early_recorded():
+        lay = model._layout
+        per_arm, o26 = int(lay.per_arm), int(lay.offset[26])
+        A = flat.numel() // per_arm
+        comm = N.shared_stream(flat.device, "comm")
+        comm.wait_event(eng.early_event)
+        works = []
+        with torch.cuda.stream(comm):
+            for a in range(A):
+                works.append(dist.all_reduce(flat[a * per_arm + o26:(a + 1) * per_arm], op=dist.ReduceOp.AVG, async_op=True))
+        for a in range(A):
+            dist.all_reduce(flat[a * per_arm:a * per_arm + o26], op=dist.ReduceOp.AVG)
+        for w in works:
+            w.wait()
+    elif active and not is_dist():
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
+    else:
+        allreduce_mean_(flat)
+    optimizer.step()
+    return buf
+
+
 def allreduce_sum_(buf: torch.Tensor):
     """Per-epoch scalar reduction (cpl_mixvae.py:480-483), folded into one small tensor."""
     if is_dist():

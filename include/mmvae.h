@@ -278,6 +278,17 @@ int mmvae_debug_stage(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noi
  * stream and must keep it alive; pass NULL to return to single-stream operation. */
 int mmvae_set_side_stream(void *side_stream);
 
+/* Data-parallel overlap (per host thread, needs a side stream).  With a non-NULL hipEvent_t set here, mmvae_backward and
+ * mmvae_train_step(do_adam == 0) reduce the gradients of fc11.weight / fc11.bias -- the last two tensors of every arm's
+ * segment of `grads`, 47 % of the parameters -- as soon as their GEMM has finished and record `event` on the side
+ * stream: the caller can start the all-reduce of those ranges while the rest of backward runs (replaces the reference's
+ * FSDP gradient traffic, train.py:140-143).  All other gradients are final when the call's work on `stream` is.
+ * NULL returns to one reduction at the end.  The caller owns the event. */
+int mmvae_set_early_grad_event(void *event);
+/* 1 if the last mmvae_backward / mmvae_train_step of this host thread recorded the event (it does not on shapes the
+ * fast kernels do not take, without a side stream, or with do_adam != 0): only then may the caller wait on it. */
+int mmvae_early_grad_event_recorded(void);
+
 /* Tuning knobs (process-wide, host side): split factors of the three large GEMMs.
  * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW1 split over the batch, 3 = small-layer dW split
  * over the batch, 4 = d(d10) GEMM split over the genes, 5 = dW11 split over the batch.  value 0 = auto.

@@ -653,3 +653,49 @@ def test_full_size_step_is_bit_reproducible():
         else:
             assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), f"iteration {it} differs"
     assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
+
+
+def test_early_gradient_event_path_gives_the_same_gradients():
+    """Data-parallel overlap (mmvae_set_early_grad_event): with the event set, train_step(do_adam=0) reduces the fc11
+    gradients early on the side stream and the rest at the end -- the gradient buffer must be bit-identical to the
+    single reduction, the event must have been recorded, and waiting on it must be enough to read the fc11 ranges."""
+    U = _U()
+    from distributed_vae_amd import _native as N
+    g = G.load("mid_a2")
+    h = G.hyper_of(g)
+    B = G.batch_of(g)
+    m = U.build_model(h, R.init_state_dict(h, int(g["seed"])))
+    m.train()
+    x = R.synthetic_batch(B, h.input_dim).to(U.DEV)
+    eng = m._ensure(B)
+    hyper, noise = m._hyper(1.0, False), N.make_noise(None, 3, 1)
+    bn0, nbt0 = m._bn_flat.clone(), m._nbt.clone()
+
+    def run(early):
+        m._bn_flat.copy_(bn0)
+        m._nbt.copy_(nbt0)
+        m._flat_grad.zero_()
+        eng.enable_early_grad_event(early)
+        eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, m._flat_grad, False, None, None, 1, 0.0)
+        rec = eng.early_recorded()
+        part = None
+        if early:
+            lay = m._layout
+            per_arm, o26 = int(lay.per_arm), int(lay.offset[26])
+            side = torch.cuda.Stream()
+            side.wait_event(eng.early_event)
+            with torch.cuda.stream(side):
+                part = m._flat_grad[o26:per_arm].clone()          # arm 0's fc11 range, read behind the event only
+            side.synchronize()
+        torch.cuda.synchronize()
+        return m._flat_grad.clone(), rec, part
+
+    g0, rec0, _ = run(False)
+    g1, rec1, part = run(True)
+    assert not rec0 and rec1
+    assert torch.equal(g0, g1)
+    lay = m._layout
+    assert torch.equal(part, g0[int(lay.offset[26]):int(lay.per_arm)]) and float(part.abs().max()) > 0
+    eng.enable_early_grad_event(False)
+    # the two ranges tile an arm's segment exactly: [0, o26) and [o26, per_arm)
+    assert int(lay.offset[26]) % 4 == 0 and int(lay.offset[27]) > int(lay.offset[26])
