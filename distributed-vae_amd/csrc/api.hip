@@ -215,7 +215,7 @@ static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_la
 // caller that the loss is on its way (event g_ev_couple) and do_loss must not launch anything.
 static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
                       const float* x, int64_t xs, float* x_rec, int need_grad, bool* couple_done = nullptr,
-                      float* loss_out = nullptr, bool latent_only = false) {
+                      float* loss_out = nullptr, bool latent_only = false, int32_t* labels = nullptr) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
     if (fast) {
@@ -235,7 +235,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         for (int layer = 2; layer <= 5; ++layer)
             if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
     }
-    if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt))) return rc;
+    if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt, labels))) return rc;
     if (latent_only) return 0;   // evaluation labels need c only: no decoder, no fc11
     if (couple_done && g_side) {
         if (!g_ev_lat && (hipEventCreateWithFlags(&g_ev_lat, hipEventDisableTiming) != hipSuccess ||
@@ -538,10 +538,10 @@ int mmvae_eval_classify(const mmvae_dims* d, const mmvae_hyper* h, const float* 
     // sample the latent kernel also produces does not enter c: it takes the Philox stream of seed 0
     mmvae_noise nzp{};
     nzp.mode = 1;
+    // the latent kernel's hard-sample argmax IS classify(c) in eval mode: the labels come out of it directly
     if ((rc = do_forward(c, &nzp, params, const_cast<float*>(bn_running), nullptr, x, x_arm_stride, nullptr, 0, nullptr,
-                         nullptr, true)))
+                         nullptr, true, labels)))
         return rc;
-    if ((rc = launch_classify(c.ws + c.lay.CC, (int64_t)d->A * d->B, d->C, labels, c.stream))) return rc;
     if (counts) return launch_confmat(labels, d->A, d->B, d->C, counts, c.stream);
     return 0;
 }

@@ -540,7 +540,8 @@ int launch_fc1_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, con
 int launch_bn_eval_stats(const Ctx& c, const float* bn_running);   // eval mode: all five layers, one launch
 int launch_chain_fwd_enc(const Ctx& c, int layer /*2..5*/, const float* params, float* bn_running, int64_t* nbt);
 int launch_chain_fwd_enc_eval(const Ctx& c, const float* params);   // eval mode: fc2..fc5 in one launch
-int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt);
+int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
+                   int32_t* labels = nullptr /*eval: argmax of c per cell and arm*/);
 int launch_chain_fwd_dec(const Ctx& c, const float* params);
 int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
 int launch_couple(const Ctx& c);

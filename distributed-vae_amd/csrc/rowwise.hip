@@ -71,6 +71,7 @@ struct LatArgs {
     int64_t GZIN, GMS, GZC, G5, bnb_part5, T, c_mean, c_iv;
     float am1, beta, lam;
     int64_t dbg_off;   // >= 0: diagnostic stamp counters (MMVAE_ABLATE_L=8)
+    int32_t* labels;   // non-null (eval): labels[arm * B + b] = argmax_k c, the `classify` of the consensus path
     // forward, training: BN5's partials [A][nblk][2][L] are recombined by every row block
     int64_t bn_part5, run_mean_off, run_var_off, run_arm_stride;
     int bn5_n;             // partials fc5's launch emitted (one per CHAIN_ROWS cells)
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 #pragma unroll
             for (int t = 0; t < CPL; ++t) if (vcol[t] && ys[r][t] == mv) cand = min(cand, lane + 64 * t);
             cand = wave_min_i(cand);
+            if (a.labels && a.eval_flag && okr[r] && lane == 0) a.labels[ab + bb[r]] = cand;   // eval: ys == c
 #pragma unroll
             for (int t = 0; t < CPL; ++t) {
                 const float hv = (lane + 64 * t == cand) ? 1.f : 0.f;
@@ -606,6 +608,7 @@ __global__ __launch_bounds__(64 * LH_NW) void k_lat_fwd_h(const LatArgs a_in, co
 #pragma unroll
             for (int t = 0; t < CP; ++t) if (vcol[t] && ys[r][t] == mv) cand = min(cand, sub + 32 * t);
             cand = half_min_i(cand);
+            if (a.labels && a.eval_flag && okr[r] && sub == 0) a.labels[ab + bb[r]] = cand;    // eval: ys == c
 #pragma unroll
             for (int t = 0; t < CP; ++t) {
                 const float hv = (sub + 32 * t == cand) ? 1.f : 0.f;
@@ -1481,8 +1484,10 @@ int launch_bn_eval_stats(const Ctx& c, const float* bn_running) {
     return 0;
 }
 
-int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt) {
+int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
+                   int32_t* labels) {
     LatArgs a = make_lat_args(c);
+    a.labels = labels;
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
     static const int fullwave = getenv("MMVAE_LAT_FULLWAVE") ? atoi(getenv("MMVAE_LAT_FULLWAVE")) : 0;   // A/B timing
