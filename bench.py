@@ -449,9 +449,30 @@ def measure_stages(model, x, A, B, D, H):
     dom = max((k for k in res if res[k]["critical_path"]), key=lambda k: res[k]["avg_launch_ms"])
     ach = res[dom]["tflops"]
     traffic, src = pmc_traffic(dom, A, B, D, H)
-    return {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": src, "avg_launch_ms": res[dom]["avg_launch_ms"], "stages": res}
+    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+           "traffic_source": src, "avg_launch_ms": res[dom]["avg_launch_ms"], "stages": res}
+    busy = pmc_mfma_busy(dom, A, B, D, H)
+    if busy is not None:
+        out["mfma_busy"] = busy
+    return out
+
+
+def pmc_mfma_busy(kernel, A, B, D, H):
+    """Matrix-pipe utilisation of `kernel` from the committed PMC pass (profiles/r01_pmc_mfma_summary.csv):
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), and the shader clock the kernel ran at
+    (SQ_BUSY_CU_CYCLES / 256 CUs / its duration in the same pass is not recorded there, so the clock is derived from
+    this run's launch time).  Only for the shape the pass was collected on."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mfma_summary.csv")
+    if (A, B, D, H) != (2, 5000, 5000, 100) or not os.path.exists(path):
+        return None
+    for r in csv.DictReader(open(path)):
+        if r["kernel"].startswith(kernel) and r.get("SQ_VALU_MFMA_BUSY_CYCLES") and r.get("SQ_BUSY_CU_CYCLES"):
+            cu = float(r["SQ_BUSY_CU_CYCLES"])
+            return {"pipe_busy_frac": float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * cu), "busy_cu_cycles_per_launch": cu,
+                    "source": "profiles/r01_pmc_mfma_summary.csv"}
+    return None
 
 
 def pmc_traffic(kernel, A, B, D, H):
