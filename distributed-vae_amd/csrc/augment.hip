@@ -492,7 +492,7 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     {
         const size_t shm = aug_latent_lds_bytes(*d);
         if (shm > 64 * 1024)
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aug_latent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aug_latent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         const int blocks = (int)imin64(cdiv64(R, AL_NW * 2), 1024);
         hipLaunchKernelGGL(k_aug_latent, dim3(blocks), dim3(64 * AL_NW), shm, s, packed, L, d->A, d->B, d->N5, d->Z, d->NZ,
                            shared ? 1 : 0, w + W.P, W.ld5, z0, eps_n, scale, s_out, w + W.H6);

@@ -1452,7 +1452,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         const size_t shm = (size_t)(3 * 64 * ldk + 8 * 32 * ZG_LD + 16) * sizeof(float);
         static bool attr_done = false;
         if (!attr_done) {   // more than 64 KB of dynamic LDS needs the opt-in
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fc11_zg<13, true, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fc11_zg<13, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
             attr_done = true;
         }
