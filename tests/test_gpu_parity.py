@@ -699,3 +699,37 @@ def test_early_gradient_event_path_gives_the_same_gradients():
     eng.enable_early_grad_event(False)
     # the two ranges tile an arm's segment exactly: [0, o26) and [o26, per_arm)
     assert int(lay.offset[26]) % 4 == 0 and int(lay.offset[27]) > int(lay.offset[26])
+
+
+@pytest.mark.parametrize("A", [3, 5])
+def test_full_size_more_arms_fused_step_matches_api_path(A):
+    """BASELINE.json's A = 3 and A = 5 configurations at the full batch / gene size: the fused train step (fused fc11
+    kernel, two-round grids, side-stream overlaps) gives the loss vector and gradients of forward() / loss() /
+    backward() -- the path the reference-generated fixtures pin at small sizes (tiny_a3, tiny_a5)."""
+    U = _U()
+    from distributed_vae_amd import _native as N
+    B, D = 5000, 5000
+    h = R.Hyper(input_dim=D, fc_dim=100, n_categories=92, state_dim=2, lowD_dim=10, n_arm=A)
+    torch.manual_seed(546 + A)
+    m = U.build_model(h, None)
+    m.train()
+    x = R.synthetic_batch(B, D, seed=A).to(U.DEV)
+    eng = m._ensure(B)
+    hyper, noise = m._hyper(1.0, False), N.make_noise(None, 11, A)
+    bn0, nbt0 = m._bn_flat.clone(), m._nbt.clone()
+    # API path: forward(need_grad) + loss + backward
+    eng.forward(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, None, True)
+    l_api = eng.loss(hyper).clone()
+    g_api = torch.empty_like(m._flat_grad)
+    eng.backward(hyper, noise, m._flat, x, 0, g_api)
+    # fused path from the same state
+    m._bn_flat.copy_(bn0)
+    m._nbt.copy_(nbt0)
+    buf = eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, m._flat_grad, False, None, None, 1, 0.0).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(buf).all() and torch.isfinite(m._flat_grad).all()
+    assert float((buf - l_api).abs().max()) <= 1e-5 * float(l_api.abs().max())
+    err = (m._flat_grad - g_api).abs()
+    scale = float(g_api.abs().max())
+    assert float(err.max()) <= 5 * GRAD_TOL * scale                      # a few ReLU flips at 25 M decisions per arm
+    assert float(torch.quantile(err[::97].float(), 0.9)) <= 1e-4 * scale
