@@ -241,6 +241,10 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or args.rehearse_dp:
+        # rank 0 measured its stages after the timed region: the others wait for it, so that every rank tears the
+        # communicator down together
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
