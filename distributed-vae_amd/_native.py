@@ -14,6 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB") or os.path.join(HERE, "libmmvae_hip.so")   # env override: A/B timing of builds
 
+ABI_VERSION = 2
 N_PARAM_TENSORS = 28
 N_BN = 6
 MAX_ARMS = 8
@@ -30,7 +31,7 @@ BN_NAMES = ["batch_l1", "batch_l2", "batch_l3", "batch_l4", "batch_l5", "batch_s
 WS_IDS = {name: i for i, name in enumerate([
     "x_low", "c_prob", "c", "c_smp", "s_mean", "s_logvar", "s_smp", "y_soft",
     "r1", "r2", "r3", "r4", "r5", "d6", "d7", "d8", "d9", "d10", "zin", "dz11", "dz1", "gzin", "gzc", "g5",
-    "bn_mean1",
+    "bn_mean1", "gd10_slab",
 ])}
 
 LOSS_TOTAL, LOSS_JOINT, LOSS_CENT, LOSS_CDIST, LOSS_CL2, LOSS_REC0 = 0, 1, 2, 3, 4, 5
@@ -69,6 +70,40 @@ class AugTensors(C.Structure):
                 ("bnz_weight", C.c_void_p), ("bnz_bias", C.c_void_p), ("bnz_mean", C.c_void_p), ("bnz_var", C.c_void_p)]
 
 
+N_EVENTS = 8
+N_TUNE = 24
+# mmvae_exec.tune indices (include/mmvae.h MMVAE_TUNE_*) and the environment switch that sets each one: the LIBRARY reads
+# no environment variables, this module translates them (experiments and A/B timing only; none is needed in production)
+TUNE_ENV = {
+    "MMVAE_EVAL_CHAIN": (0, lambda v: int(int(v) == 0)), "MMVAE_DW11_AT": (1, int), "MMVAE_SIDE_SMALL": (2, int),
+    "MMVAE_AUG_TILE": (3, int), "MMVAE_ABLATE_C": (4, int), "MMVAE_ABLATE": (5, int), "MMVAE_PADLDS": (6, int),
+    "MMVAE_FC1_V2": (7, int), "MMVAE_FC11_ZG": (8, lambda v: int(int(v) == 0)), "MMVAE_ABLATE_Z": (9, int),
+    "MMVAE_FC11_NSZ": (10, int), "MMVAE_GD10_V2": (11, int), "MMVAE_DW1_V2": (12, int), "MMVAE_DW11_V2": (13, int),
+    "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_PERSIST": (16, lambda v: int(int(v) == 0)),
+}
+
+
+class Exec(C.Structure):
+    """mmvae_exec: the caller-owned execution context of one engine (side stream, fork / join events, split factors,
+    experiment switches)."""
+    _fields_ = [("side_stream", C.c_void_p), ("ev", C.c_void_p * N_EVENTS), ("early_grad_event", C.c_void_p),
+                ("early_recorded", C.c_int32), ("split", C.c_int32 * 6), ("tune", C.c_int32 * N_TUNE)]
+
+
+def exec_from_env() -> Exec:
+    """An Exec with the split factors (MMVAE_SPLIT<i>) and experiment switches the environment asks for."""
+    ex = Exec()
+    for w in range(6):
+        v = os.environ.get(f"MMVAE_SPLIT{w}")
+        if v:
+            ex.split[w] = int(v)
+    for name, (idx, conv) in TUNE_ENV.items():
+        v = os.environ.get(name)
+        if v:
+            ex.tune[idx] = conv(v)
+    return ex
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -92,28 +127,27 @@ def lib():
     L.mmvae_last_error_string.restype = C.c_char_p
     L.mmvae_check_dims.argtypes = [C.POINTER(Dims)]
     L.mmvae_param_layout.argtypes = [C.POINTER(Dims), C.POINTER(ParamLayout)]
-    L.mmvae_workspace_bytes.argtypes = [C.POINTER(Dims)]
+    ex = C.POINTER(Exec)
+    L.mmvae_workspace_bytes.argtypes = [C.POINTER(Dims), ex]
     L.mmvae_workspace_bytes.restype = C.c_size_t
-    L.mmvae_ws_offset.argtypes = [C.POINTER(Dims), C.c_int]
+    L.mmvae_ws_offset.argtypes = [C.POINTER(Dims), ex, C.c_int]
     L.mmvae_ws_offset.restype = i64
-    L.mmvae_set_split.argtypes = [C.c_int, C.c_int]
-    L.mmvae_set_side_stream.argtypes = [vp]
-    L.mmvae_set_side_stream.restype = C.c_int
-    L.mmvae_set_early_grad_event.argtypes = [vp]
-    L.mmvae_set_early_grad_event.restype = C.c_int
-    L.mmvae_early_grad_event_recorded.restype = C.c_int
+    L.mmvae_ws_debug_offset.argtypes = [C.POINTER(Dims), ex]
+    L.mmvae_ws_debug_offset.restype = i64
+    L.mmvae_splits.argtypes = [C.POINTER(Dims), ex, C.POINTER(C.c_int32 * 6)]
     L.mmvae_forward.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp, i32,
-                                vp, C.c_size_t, vp]
-    L.mmvae_loss.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, C.c_size_t, vp, vp]
+                                vp, C.c_size_t, ex, vp]
+    L.mmvae_loss.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, C.c_size_t, vp, ex, vp]
     L.mmvae_backward.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, i64, f32, vp,
-                                 C.c_size_t, vp, vp]
+                                 C.c_size_t, vp, ex, vp]
     L.mmvae_adam_step.argtypes = [i64, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
     L.mmvae_train_step.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp,
-                                   C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
+                                   C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, ex, vp]
     L.mmvae_debug_stage.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), i32, vp, vp, i64, vp,
-                                    C.c_size_t, vp, vp]
+                                    C.c_size_t, vp, ex, vp]
     L.mmvae_dump_noise.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, vp]
-    L.mmvae_eval_classify.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, vp, vp, i64, vp, C.c_size_t, vp, vp, vp]
+    L.mmvae_eval_classify.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), vp, vp, vp, i64, vp, C.c_size_t, vp, vp, ex,
+                                      vp]
     L.mmvae_classify.argtypes = [vp, i64, i32, vp, vp]
     L.mmvae_confmat_accumulate.argtypes = [vp, i32, i64, i32, vp, vp]
     L.mmvae_consensus.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -122,20 +156,15 @@ def lib():
     L.mmvae_aug_workspace_bytes.argtypes = [C.POINTER(AugDims), i32]
     L.mmvae_aug_workspace_bytes.restype = C.c_size_t
     L.mmvae_aug_pack.argtypes = [C.POINTER(AugDims), C.POINTER(AugTensors), vp, vp]
-    L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, vp]
+    L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, ex, vp]
     L.mmvae_gather_rows.argtypes = [vp, i64, i64, vp, i64, i32, vp, vp]
-    for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_set_split", "mmvae_forward", "mmvae_loss",
+    for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_splits", "mmvae_forward", "mmvae_loss",
                "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",
                "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus", "mmvae_aug_pack",
                "mmvae_augment", "mmvae_gather_rows"):
         getattr(L, fn).restype = C.c_int
-    if L.mmvae_abi_version() != 1:
-        raise NativeError("libmmvae_hip.so ABI version mismatch")
-    # tuning knobs (timing experiments): MMVAE_SPLIT<i>=<n> overrides split factor i of mmvae_set_split
-    for w in range(6):
-        v = os.environ.get(f"MMVAE_SPLIT{w}")
-        if v:
-            L.mmvae_set_split(w, int(v))
+    if L.mmvae_abi_version() != ABI_VERSION:
+        raise NativeError("libmmvae_hip.so ABI version mismatch (rebuild: python distributed-vae_amd/build.py)")
     _lib = L
     return L
 
@@ -158,8 +187,8 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def make_noise(explicit: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, offset: int = 0) -> Noise:
@@ -196,80 +225,104 @@ def shared_stream(device, name: str) -> "torch.cuda.Stream":
 
 
 class Engine:
-    """Owns the workspace for one (dims, device) and issues the C-ABI calls on torch's current stream."""
+    """Owns the workspace and the execution context (mmvae_exec: side stream, events, split factors, switches) of one
+    (dims, device) and issues the C-ABI calls on torch's current stream OF THAT DEVICE.  Nothing is shared between
+    engines except the process-wide side stream of a device (see ``shared_stream``): each engine has its own events."""
 
-    def __init__(self, A, B, D, H, L, Cc, S, device):
+    def __init__(self, A, B, D, H, L, Cc, S, device, ex: Optional[Exec] = None):
         self.dims = Dims(A, B, D, H, L, Cc, S)
         check(lib().mmvae_check_dims(C.byref(self.dims)), "mmvae_check_dims")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise NativeError("the HIP engine needs a GPU device (no CPU fallback)")
-        self.ws_bytes = int(lib().mmvae_workspace_bytes(C.byref(self.dims)))
-        self.ws = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
-        assert self.ws.data_ptr() % 256 == 0
-        self.loss_buf = torch.zeros(5 + 3 * A, dtype=torch.float32, device=self.device)
-        # side stream: the dW11 GEMM overlaps the latency-bound backward chain (MMVAE_SIDE_STREAM=0 disables)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.ex = ex if ex is not None else exec_from_env()
         self.side = None
         self.early_event = None
-        if os.environ.get("MMVAE_SIDE_STREAM", "1") != "0":
-            # High priority: HIP maps streams of one priority onto a small set of hardware queues round-robin; once
-            # RCCL has created its streams the side stream can share a queue with the main stream and the overlap is
-            # silently lost (measured with an initialised process group: 1.146 ms per step against 1.028 ms with a
-            # high-priority side stream; no difference without a process group).
-            self.side = shared_stream(self.device, "step")
+        self._events = []
+        with torch.cuda.device(self.device):
+            self.ws_bytes = int(lib().mmvae_workspace_bytes(C.byref(self.dims), C.byref(self.ex)))
+            self.ws = torch.empty(self.ws_bytes // 4, dtype=torch.float32, device=self.device)
+            assert self.ws.data_ptr() % 256 == 0
+            self.loss_buf = torch.zeros(5 + 3 * A, dtype=torch.float32, device=self.device)
+            # side stream: the dW11 GEMM overlaps the latency-bound backward chain (MMVAE_SIDE_STREAM=0 disables)
+            if os.environ.get("MMVAE_SIDE_STREAM", "1") != "0":
+                # High priority: HIP maps streams of one priority onto a small set of hardware queues round-robin; once
+                # RCCL has created its streams the side stream can share a queue with the main stream and the overlap
+                # is silently lost (measured with an initialised process group: 1.146 ms per step against 1.028 ms with
+                # a high-priority side stream; no difference without a process group).
+                self.side = shared_stream(self.device, "step")
+                self.ex.side_stream = self.side.cuda_stream
+                for i in range(N_EVENTS):
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)               # creates the underlying hipEvent_t on this device
+                    self._events.append(ev)
+                    self.ex.ev[i] = ev.cuda_event
 
-    def _bind_side(self):
-        lib().mmvae_set_side_stream(C.c_void_p(self.side.cuda_stream) if self.side is not None else None)
-        ev = self.early_event
-        lib().mmvae_set_early_grad_event(C.c_void_p(ev.cuda_event) if ev is not None else None)
+    def _s(self):
+        return _stream(self.device)
+
+    def _x(self):
+        return C.byref(self.ex)
 
     def enable_early_grad_event(self, on: bool = True):
         """Data-parallel overlap: the next train_step(do_adam=False) records ``self.early_event`` on the side stream
         once the fc11 gradients are final (see ``early_recorded``)."""
         if on and self.early_event is None and self.side is not None:
-            self.early_event = torch.cuda.Event()
-            self.early_event.record()              # creates the underlying hipEvent_t
+            with torch.cuda.device(self.device):
+                self.early_event = torch.cuda.Event()
+                self.early_event.record(self.side)     # creates the underlying hipEvent_t
+            self.ex.early_grad_event = self.early_event.cuda_event
         elif not on:
             self.early_event = None
+            self.ex.early_grad_event = None
 
-    @staticmethod
-    def early_recorded() -> bool:
-        return bool(lib().mmvae_early_grad_event_recorded())
+    def early_recorded(self) -> bool:
+        return bool(self.ex.early_recorded)
 
     def ws_view(self, name: str, width: int) -> torch.Tensor:
-        off = int(lib().mmvae_ws_offset(C.byref(self.dims), WS_IDS[name]))
+        off = int(lib().mmvae_ws_offset(C.byref(self.dims), self._x(), WS_IDS[name]))
         if off < 0:
             raise NativeError(f"unknown workspace region {name}")
         d = self.dims
         return self.ws[off: off + d.A * d.B * width].view(d.A, d.B, width)
 
+    def splits(self):
+        """Split factors of the layout (order of mmvae_exec.split)."""
+        out = (C.c_int32 * 6)()
+        check(lib().mmvae_splits(C.byref(self.dims), self._x(), C.byref(out)), "mmvae_splits")
+        return list(out)
+
     def ws_raw(self, name: str, numel: int) -> torch.Tensor:
-        off = int(lib().mmvae_ws_offset(C.byref(self.dims), WS_IDS[name]))
+        off = int(lib().mmvae_ws_offset(C.byref(self.dims), self._x(), WS_IDS[name]))
+        return self.ws[off: off + numel]
+
+    def ws_debug(self, numel: int = 1024) -> torch.Tensor:
+        off = int(lib().mmvae_ws_debug_offset(C.byref(self.dims), self._x()))
         return self.ws[off: off + numel]
 
     def forward(self, hyper: Hyper, noise: Noise, params, bn_running, nbt, x, x_arm_stride, x_rec, need_grad):
         check(lib().mmvae_forward(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params), _ptr(bn_running),
                                   _ptr(nbt), _ptr(x), x_arm_stride, _ptr(x_rec), int(need_grad), _ptr(self.ws),
-                                  self.ws_bytes, _stream()), "mmvae_forward")
+                                  self.ws_bytes, self._x(), self._s()), "mmvae_forward")
 
     def loss(self, hyper: Hyper) -> torch.Tensor:
         check(lib().mmvae_loss(C.byref(self.dims), C.byref(hyper), _ptr(self.ws), self.ws_bytes, _ptr(self.loss_buf),
-                               _stream()), "mmvae_loss")
+                               self._x(), self._s()), "mmvae_loss")
         return self.loss_buf
 
     def backward(self, hyper: Hyper, noise: Noise, params, x, x_arm_stride, grads, grad_scale=1.0):
-        self._bind_side()
         check(lib().mmvae_backward(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params), _ptr(x),
                                    x_arm_stride, float(grad_scale), _ptr(self.ws), self.ws_bytes, _ptr(grads),
-                                   _stream()), "mmvae_backward")
+                                   self._x(), self._s()), "mmvae_backward")
 
     def train_step(self, hyper, noise, params, bn_running, nbt, x, x_arm_stride, grads, do_adam, exp_avg,
                    exp_avg_sq, step, lr, b1=0.9, b2=0.999, adam_eps=1e-8, wd=0.0, decoupled=False):
-        self._bind_side()
         check(lib().mmvae_train_step(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params),
                                      _ptr(bn_running), _ptr(nbt), _ptr(x), x_arm_stride, _ptr(self.ws), self.ws_bytes,
                                      _ptr(grads), _ptr(self.loss_buf), int(do_adam), _ptr(exp_avg), _ptr(exp_avg_sq),
-                                     int(step), lr, b1, b2, adam_eps, wd, int(decoupled), _stream()),
+                                     int(step), lr, b1, b2, adam_eps, wd, int(decoupled), self._x(), self._s()),
               "mmvae_train_step")
         return self.loss_buf
 
@@ -277,13 +330,13 @@ class Engine:
         """Encoder + latent block in eval mode, labels[a, b] = argmax c; counts (int64 [pairs, C, C]) accumulate."""
         check(lib().mmvae_eval_classify(C.byref(self.dims), C.byref(hyper), _ptr(params), _ptr(bn_running), _ptr(x),
                                         x_arm_stride, _ptr(self.ws), self.ws_bytes, _ptr(labels), _ptr(counts),
-                                        _stream()), "mmvae_eval_classify")
+                                        self._x(), self._s()), "mmvae_eval_classify")
         return labels
 
     def debug_stage(self, stage: int, hyper: Hyper, noise: Noise, params, x, x_arm_stride, grads=None):
         check(lib().mmvae_debug_stage(C.byref(self.dims), C.byref(hyper), C.byref(noise), int(stage), _ptr(params),
-                                      _ptr(x), x_arm_stride, _ptr(self.ws), self.ws_bytes, _ptr(grads), _stream()),
-              "mmvae_debug_stage")
+                                      _ptr(x), x_arm_stride, _ptr(self.ws), self.ws_bytes, _ptr(grads), self._x(),
+                                      self._s()), "mmvae_debug_stage")
 
     def dump_noise(self, hyper: Hyper, noise: Noise):
         d = self.dims
@@ -292,13 +345,13 @@ class Engine:
         us = torch.empty(d.A, d.B, d.S, dtype=torch.float32, device=self.device)
         sm = torch.empty(d.A, d.B, d.S, dtype=torch.uint8, device=self.device)
         check(lib().mmvae_dump_noise(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(xm), _ptr(ug), _ptr(us),
-                                     _ptr(sm), _stream()), "mmvae_dump_noise")
+                                     _ptr(sm), self._s()), "mmvae_dump_noise")
         return {"x_mask": xm, "u_gumbel": ug, "u_state": us, "s_mask": sm}
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0, decoupled=False):
     check(lib().mmvae_adam_step(params.numel(), _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), int(step),
-                                lr, b1, b2, eps, wd, int(decoupled), _stream()), "mmvae_adam_step")
+                                lr, b1, b2, eps, wd, int(decoupled), _stream(params.device)), "mmvae_adam_step")
 
 
 def classify(probs: torch.Tensor) -> torch.Tensor:
@@ -308,7 +361,7 @@ def classify(probs: torch.Tensor) -> torch.Tensor:
     p = probs.contiguous().float()
     n, Cc = p.numel() // p.shape[-1], p.shape[-1]
     out = torch.empty(p.shape[:-1], dtype=torch.int32, device=p.device)
-    check(lib().mmvae_classify(_ptr(p), n, Cc, _ptr(out), _stream()), "mmvae_classify")
+    check(lib().mmvae_classify(_ptr(p), n, Cc, _ptr(out), _stream(p.device)), "mmvae_classify")
     return out
 
 
@@ -320,7 +373,8 @@ def confmat_accumulate(labels: torch.Tensor, Cc: int, counts: Optional[torch.Ten
     A, n = lab.shape
     if counts is None:
         counts = torch.zeros(max(A * (A - 1) // 2, 1), Cc, Cc, dtype=torch.int64, device=lab.device)
-    check(lib().mmvae_confmat_accumulate(_ptr(lab), A, n, Cc, _ptr(counts), _stream()), "mmvae_confmat_accumulate")
+    check(lib().mmvae_confmat_accumulate(_ptr(lab), A, n, Cc, _ptr(counts), _stream(lab.device)),
+          "mmvae_confmat_accumulate")
     return counts
 
 
@@ -332,7 +386,7 @@ def consensus(counts: torch.Tensor, want_norm: bool = False):
     P, Cc, _ = cnt.shape
     out = torch.empty(P, dtype=torch.float64, device=cnt.device)
     norm = torch.empty(P, Cc, Cc, dtype=torch.float64, device=cnt.device) if want_norm else None
-    check(lib().mmvae_consensus(_ptr(cnt), P, Cc, _ptr(norm), _ptr(out), _stream()), "mmvae_consensus")
+    check(lib().mmvae_consensus(_ptr(cnt), P, Cc, _ptr(norm), _ptr(out), _stream(cnt.device)), "mmvae_consensus")
     return (out, norm) if want_norm else out
 
 
@@ -346,6 +400,7 @@ def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tenso
     if out is None:
         out = torch.empty(n, Dm, dtype=torch.float32, device=data.device)
     if n:
-        check(lib().mmvae_gather_rows(_ptr(data), data.stride(0), data.shape[0], _ptr(idx), n, Dm, _ptr(out), _stream()),
+        check(lib().mmvae_gather_rows(_ptr(data), data.stride(0), data.shape[0], _ptr(idx), n, Dm, _ptr(out),
+                                      _stream(data.device)),
               "mmvae_gather_rows")
     return out

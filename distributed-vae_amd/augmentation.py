@@ -59,6 +59,11 @@ class Augmenter_smartseq(nn.Module):
         """Call after modifying parameters or running statistics in place (the packed copy is otherwise kept)."""
         self._packed = None
 
+    def _exec(self) -> N.Exec:
+        if getattr(self, "_ex", None) is None:
+            self._ex = N.exec_from_env()      # MMVAE_AUG_TILE (A/B timing); the library itself reads no environment
+        return self._ex
+
     def _aug_dims(self, A, B) -> N.AugDims:
         D, n1, n3, n5, z, nz = self._dims
         return N.AugDims(A, B, D, n1, n3, n5, z, nz)
@@ -88,8 +93,8 @@ class Augmenter_smartseq(nn.Module):
         if n == 0:
             N.check(-2, "mmvae_aug_packed_floats")
         packed = torch.empty(n, dtype=torch.float32, device=dev)
-        N.check(N.lib().mmvae_aug_pack(C.byref(dims), C.byref(t), N._ptr(packed), N._stream()), "mmvae_aug_pack")
-        torch.cuda.current_stream().synchronize()   # `keep` may be freed once the pack kernels have run
+        N.check(N.lib().mmvae_aug_pack(C.byref(dims), C.byref(t), N._ptr(packed), N._stream(dev)), "mmvae_aug_pack")
+        torch.cuda.current_stream(dev).synchronize()   # `keep` may be freed once the pack kernels have run
         self._packed = packed
 
     # ------------------------------------------------------------------ noise control (parity hook)
@@ -142,7 +147,7 @@ class Augmenter_smartseq(nn.Module):
             out = torch.empty(A, B, D, dtype=torch.float32, device=xt.device)
         N.check(N.lib().mmvae_augment(C.byref(dims), N._ptr(self._packed), N._ptr(xt), xs, N._ptr(z0), N._ptr(eps),
                                       float(scale), N._ptr(self._ws), self._ws.numel() * 4, N._ptr(s), N._ptr(out),
-                                      N._stream()), "mmvae_augment")
+                                      C.byref(self._exec()), N._stream(xt.device)), "mmvae_augment")
         return (s, out) if batched else (s[0], out[0])
 
 

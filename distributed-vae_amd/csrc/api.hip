@@ -14,12 +14,12 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static int g_split[6] = {0, 0, 0, 0, 0, 0};
-
 // Split factors are chosen so that each large kernel's grid fills the chip's resident-workgroup
 // slots once (256 CUs x workgroups per CU that its registers / LDS admit) without spilling into a
 // second, mostly empty round: e.g. 624 workgroups on 512 slots take two rounds, 468 take one.
-Splits default_splits(const mmvae_dims& d) {
+Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex) {
+    int g_split[6] = {0, 0, 0, 0, 0, 0};
+    if (ex) for (int i = 0; i < 6; ++i) g_split[i] = ex->split[i] > 0 && ex->split[i] <= 64 ? ex->split[i] : 0;
     constexpr int CUS = 256;
     // smallest split whose grid fills whole rounds of the resident slots to >= 93 % (else the best-filling one); an exact
     // fill one or two steps further is preferred.  With A = 5 a single round would leave a fifth of the chip idle (200 k
@@ -103,14 +103,14 @@ POff make_poff(const mmvae_dims& d) {
     return p;
 }
 
-Layout make_layout(const mmvae_dims& d) {
+Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     Layout L{};
     const int64_t A = d.A, B = d.B, D = d.D, H = d.H, Ld = d.L, C = d.C, S = d.S;
     L.nblk32 = cdiv(d.B, 32);
     L.nblk64 = cdiv(d.B, 64);
     L.nblkc = cdiv(d.B, CHAIN_ROWS);
     L.nblkl = cdiv(d.B, LAT_ROWS);
-    L.sp = default_splits(d);
+    L.sp = default_splits(d, ex);
     int64_t off = 0;
     auto take = [&](int64_t n) { const int64_t o = off; off += cdiv64(n, 64) * 64; return o; };
     const int64_t nb = L.nblk32;
@@ -153,8 +153,8 @@ Layout make_layout(const mmvae_dims& d) {
 
 static int check_dims(const mmvae_dims* d) {
     if (!d) { set_error("dims is null"); return MMVAE_E_BADARG; }
-    if (d->A < 1 || d->B < 2 || d->D < 1 || d->H < 1 || d->L < 1 || d->C < 1 || d->S < 1) {
-        set_error("non-positive dimension (A=%d B=%d D=%d H=%d L=%d C=%d S=%d; B must be >= 2 for batch statistics)",
+    if (d->A < 1 || d->B < 1 || d->D < 1 || d->H < 1 || d->L < 1 || d->C < 1 || d->S < 1) {
+        set_error("non-positive dimension (A=%d B=%d D=%d H=%d L=%d C=%d S=%d)",
                   d->A, d->B, d->D, d->H, d->L, d->C, d->S);
         return MMVAE_E_BADARG;
     }
@@ -168,12 +168,24 @@ static int check_dims(const mmvae_dims* d) {
     return 0;
 }
 
-static int make_ctx(Ctx& c, const mmvae_dims* d, const mmvae_hyper* h, void* ws, size_t ws_bytes, void* stream) {
+static int make_ctx(Ctx& c, const mmvae_dims* d, const mmvae_hyper* h, void* ws, size_t ws_bytes, mmvae_exec* ex,
+                    void* stream) {
     if (int rc = check_dims(d)) return rc;
     if (!h || !ws) { set_error("null hyper / workspace"); return MMVAE_E_BADARG; }
+    if (h->training && d->B < 2) {   // a one-cell batch has no batch statistics; eval mode (running statistics) takes it
+        set_error("training mode needs B >= 2 for the batch statistics (got B=%d)", d->B);
+        return MMVAE_E_BADARG;
+    }
     c.d = *d;
     c.h = *h;
-    c.lay = make_layout(*d);
+    c.ex_out = ex;
+    if (ex) c.ex = *ex; else memset(&c.ex, 0, sizeof(c.ex));
+    if (c.ex.side_stream) {
+        for (int i = 0; i < MMVAE_N_EVENTS; ++i)
+            if (!c.ex.ev[i]) { set_error("mmvae_exec: side_stream is set but ev[%d] is null", i); return MMVAE_E_BADARG; }
+        if (c.ex.side_stream == stream) { set_error("mmvae_exec: side_stream must differ from the call's stream"); return MMVAE_E_BADARG; }
+    }
+    c.lay = make_layout(*d, &c.ex);
     c.po = make_poff(*d);
     if ((size_t)c.lay.total * sizeof(float) > ws_bytes) {
         set_error("workspace too small: need %zu bytes, got %zu", (size_t)c.lay.total * sizeof(float), ws_bytes);
@@ -203,16 +215,26 @@ static int check_noise(const Ctx& c, const mmvae_noise* nz) {
     return 0;
 }
 
-static thread_local hipStream_t g_side = nullptr;
-static thread_local hipEvent_t g_ev_early = nullptr;   // caller's event: fc11 gradients final (mmvae_set_early_grad_event)
-static thread_local int g_early_recorded = 0;          // did the last backward of this thread record it?
-static thread_local hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_lat = nullptr, g_ev_couple = nullptr,
-                               g_ev_fc11 = nullptr, g_ev_dec = nullptr, g_ev_enc = nullptr;
-
 // Train step with a side stream (couple_done != null): the coupling kernel needs only the latent block's outputs
 // and the loss scalars only the coupling and fc11 partials, so both run on the side stream -- the coupling beside
 // the decoder chain and fc11, the finalisation (loss_out != null) beside the d(d10) GEMM.  *couple_done tells the
-// caller that the loss is on its way (event g_ev_couple) and do_loss must not launch anything.
+// caller that the loss is on its way (event EV_COUPLE) and do_loss must not launch anything.
+static int fork_to_side(const Ctx& c, int ev) {
+    if (hipEventRecord(c.ev(ev), c.stream) != hipSuccess || hipStreamWaitEvent(c.side(), c.ev(ev), 0) != hipSuccess) {
+        set_error("stream fork failed");
+        return MMVAE_E_LAUNCH;
+    }
+    return 0;
+}
+static int record_on_side(const Ctx& c, int ev) {
+    if (hipEventRecord(c.ev(ev), c.side()) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+    return 0;
+}
+static int join_from_side(const Ctx& c, int ev) {
+    if (hipStreamWaitEvent(c.stream, c.ev(ev), 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
+    return 0;
+}
+
 static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
                       const float* x, int64_t xs, float* x_rec, int need_grad, bool* couple_done = nullptr,
                       float* loss_out = nullptr, bool latent_only = false, int32_t* labels = nullptr) {
@@ -228,8 +250,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     // batch statistics are recombined by the kernel that consumes each BatchNorm (no finalize launches);
     // eval mode copies the running statistics into the workspace instead
     if ((rc = launch_bn_eval_stats(c, bn_running))) return rc;
-    static const int eval_chain = getenv("MMVAE_EVAL_CHAIN") ? atoi(getenv("MMVAE_EVAL_CHAIN")) : 1;   // A/B timing
-    if (!c.h.training && eval_chain) {
+    if (!c.h.training && !c.tune(MMVAE_TUNE_EVAL_CHAIN_OFF)) {
         if ((rc = launch_chain_fwd_enc_eval(c, params))) return rc;
     } else {
         for (int layer = 2; layer <= 5; ++layer)
@@ -237,42 +258,22 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     }
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt, labels))) return rc;
     if (latent_only) return 0;   // evaluation labels need c only: no decoder, no fc11
-    if (couple_done && g_side) {
-        if (!g_ev_lat && (hipEventCreateWithFlags(&g_ev_lat, hipEventDisableTiming) != hipSuccess ||
-                          hipEventCreateWithFlags(&g_ev_couple, hipEventDisableTiming) != hipSuccess)) {
-            set_error("event creation failed");
-            return MMVAE_E_LAUNCH;
-        }
-        Ctx cs = c;
-        cs.stream = g_side;
-        if (hipEventRecord(g_ev_lat, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_lat, 0) != hipSuccess) {
-            set_error("stream fork failed");
-            return MMVAE_E_LAUNCH;
-        }
+    Ctx cs = c;
+    cs.stream = c.side();
+    if (couple_done && c.side()) {
+        if ((rc = fork_to_side(c, EV_LAT))) return rc;
         if ((rc = launch_couple(cs))) return rc;
         *couple_done = true;
     }
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
     if (fast && fc11_split_path(c, params, x, xs) && couple_done && *couple_done && loss_out) {
-        if (!g_ev_fc11 && hipEventCreateWithFlags(&g_ev_fc11, hipEventDisableTiming) != hipSuccess) {
-            set_error("event creation failed");
-            return MMVAE_E_LAUNCH;
-        }
-        Ctx cs = c;
-        cs.stream = g_side;
         if ((rc = launch_fc11_fast(c, params, x, xs, x_rec, need_grad, 1))) return rc;
-        if (hipEventRecord(g_ev_fc11, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fc11, 0) != hipSuccess) {
-            set_error("stream fork failed");
-            return MMVAE_E_LAUNCH;
-        }
+        if ((rc = fork_to_side(c, EV_FC11))) return rc;
         if ((rc = launch_loss_finalize(cs, loss_out))) return rc;
-        if (hipEventRecord(g_ev_couple, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+        if ((rc = record_on_side(c, EV_COUPLE))) return rc;
         return launch_fc11_fast(c, params, x, xs, x_rec, need_grad, 2);
     }
-    if (couple_done && *couple_done && hipEventRecord(g_ev_couple, g_side) != hipSuccess) {
-        set_error("event record failed");
-        return MMVAE_E_LAUNCH;
-    }
+    if (couple_done && *couple_done && (rc = record_on_side(c, EV_COUPLE))) return rc;
     if (fast) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
     return launch_fc11_fused(c, params, x, xs, x_rec, need_grad);
 }
@@ -289,35 +290,28 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     const bool fast = fast_path_ok(c, params, x, xs);
     // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain.  Where it is
     // forked matters: beside it the latent backward takes 82 us instead of 28 and the decoder chain 70 instead of 55.
-    // MMVAE_DW11_AT: 0 = fork at the start of backward, 1 = after the decoder chain, 2 = after the latent backward.
-    static const int dw11_at = getenv("MMVAE_DW11_AT") ? atoi(getenv("MMVAE_DW11_AT")) : 0;
+    // MMVAE_TUNE_DW11_AT: 0 = fork at the start of backward, 1 = after the decoder chain, 2 = after the latent backward.
+    const int dw11_at = c.tune(MMVAE_TUNE_DW11_AT);
     bool forked = false;
-    const bool use_side = fast && g_side;
-    const bool early = use_side && !adam && g_ev_early != nullptr;
-    g_early_recorded = 0;
+    const bool use_side = fast && c.side();
+    const bool early = use_side && !adam && c.ex.early_grad_event != nullptr;
+    if (c.ex_out) c.ex_out->early_recorded = 0;
+    Ctx cs = c;
+    cs.stream = c.side();
     auto fork_dw11 = [&]() -> int {
-        if (!g_ev_fork) {
-            if (hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming) != hipSuccess) {
-                set_error("event creation failed");
-                return MMVAE_E_LAUNCH;
-            }
-        }
-        Ctx cs2 = c;
-        cs2.stream = g_side;
-        if (hipEventRecord(g_ev_fork, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_fork, 0) != hipSuccess) {
-            set_error("stream fork failed");
-            return MMVAE_E_LAUNCH;
-        }
-        if (int r = launch_dw_big_fast(cs2, x, xs, 2)) return r;
+        if (int r = fork_to_side(c, EV_FORK)) return r;
+        if (int r = launch_dw_big_fast(cs, x, xs, 2)) return r;
         if (early) {
             // data parallel: fc11.weight / fc11.bias (47 % of the parameters) are final here; reduce their slabs now
             // and tell the caller, who starts their all-reduce beside the rest of backward
-            if (int r = launch_reduce_grads(cs2, grads, grad_scale, nullptr, true, 1)) return r;
-            if (hipEventRecord(g_ev_early, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
-            g_early_recorded = 1;
+            if (int r = launch_reduce_grads(cs, grads, grad_scale, nullptr, true, 1)) return r;
+            if (hipEventRecord(reinterpret_cast<hipEvent_t>(c.ex.early_grad_event), c.side()) != hipSuccess) {
+                set_error("event record failed");
+                return MMVAE_E_LAUNCH;
+            }
+            if (c.ex_out) c.ex_out->early_recorded = 1;
         }
-        if (hipEventRecord(g_ev_join, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+        if (int r = record_on_side(c, EV_JOIN)) return r;
         forked = true;
         return 0;
     };
@@ -329,36 +323,22 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     // stream behind dW11 -- decoder layers beside the encoder backward chain, encoder side beside the dW1 GEMM.
     // Measured at the benchmark shape: 1.010 ms per step against 1.006 ms with them after dW1 on the main stream
     // (A/B/A/B on one box): what they would hide behind is itself short of CUs.
-    static const int side_small = getenv("MMVAE_SIDE_SMALL") ? atoi(getenv("MMVAE_SIDE_SMALL")) : 0;
-    const bool small_on_side = forked && side_small;
-    Ctx cs = c;
-    cs.stream = g_side;
+    const bool small_on_side = forked && c.tune(MMVAE_TUNE_SIDE_SMALL);
     if (small_on_side) {
-        if (!g_ev_dec && (hipEventCreateWithFlags(&g_ev_dec, hipEventDisableTiming) != hipSuccess ||
-                          hipEventCreateWithFlags(&g_ev_enc, hipEventDisableTiming) != hipSuccess)) {
-            set_error("event creation failed");
-            return MMVAE_E_LAUNCH;
-        }
-        if (hipEventRecord(g_ev_dec, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_dec, 0) != hipSuccess) {
-            set_error("stream fork failed");
-            return MMVAE_E_LAUNCH;
-        }
+        if ((rc = fork_to_side(c, EV_DEC))) return rc;
         if ((rc = launch_dw_small(cs, 1))) return rc;
     }
     // T (sum of G log c, from the loss finalisation) is first needed here
-    if (wait_loss && hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
+    if (wait_loss && (rc = join_from_side(c, EV_COUPLE))) return rc;
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
     if (use_side && dw11_at >= 2 && (rc = fork_dw11())) return rc;
     for (int layer = 5; layer >= 2; --layer)
         if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
     if (small_on_side) {
-        if (hipEventRecord(g_ev_enc, c.stream) != hipSuccess || hipStreamWaitEvent(g_side, g_ev_enc, 0) != hipSuccess) {
-            set_error("stream fork failed");
-            return MMVAE_E_LAUNCH;
-        }
+        if ((rc = fork_to_side(c, EV_ENC))) return rc;
         if ((rc = launch_dw_small(cs, 2))) return rc;
-        if (hipEventRecord(g_ev_join, g_side) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
+        if ((rc = record_on_side(c, EV_JOIN))) return rc;
     }
     if (fast) {
         if ((rc = launch_dw_big_fast(c, x, xs, forked ? 1 : 3))) return rc;
@@ -366,7 +346,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         return rc;
     }
     if (!small_on_side && (rc = launch_dw_small(c))) return rc;
-    if (forked && hipStreamWaitEvent(c.stream, g_ev_join, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
+    if (forked && (rc = join_from_side(c, EV_JOIN))) return rc;
     return launch_reduce_grads(c, grads, grad_scale, adam, fast, (early && forked) ? 2 : 3);
 }
 
@@ -376,27 +356,9 @@ using namespace mmvae;
 
 extern "C" {
 
-int mmvae_abi_version(void) { return 1; }
+int mmvae_abi_version(void) { return 2; }
 const char* mmvae_last_error_string(void) { return g_err; }
 int mmvae_check_dims(const mmvae_dims* d) { return check_dims(d); }
-
-int mmvae_set_side_stream(void* side_stream) {
-    g_side = reinterpret_cast<hipStream_t>(side_stream);
-    return 0;
-}
-
-int mmvae_set_early_grad_event(void* event) {
-    g_ev_early = reinterpret_cast<hipEvent_t>(event);
-    return 0;
-}
-
-int mmvae_early_grad_event_recorded(void) { return g_early_recorded; }
-
-int mmvae_set_split(int which, int value) {
-    if (which < 0 || which > 5 || value < 0 || value > 64) { set_error("bad split"); return MMVAE_E_BADARG; }
-    g_split[which] = value;
-    return 0;
-}
 
 int mmvae_param_layout(const mmvae_dims* d, mmvae_param_layout_t* out) {
     if (int rc = check_dims(d)) return rc;
@@ -413,14 +375,14 @@ int mmvae_param_layout(const mmvae_dims* d, mmvae_param_layout_t* out) {
     return 0;
 }
 
-size_t mmvae_workspace_bytes(const mmvae_dims* d) {
+size_t mmvae_workspace_bytes(const mmvae_dims* d, const mmvae_exec* ex) {
     if (check_dims(d)) return 0;
-    return (size_t)make_layout(*d).total * sizeof(float);
+    return (size_t)make_layout(*d, ex).total * sizeof(float);
 }
 
-int64_t mmvae_ws_offset(const mmvae_dims* d, int id) {
+int64_t mmvae_ws_offset(const mmvae_dims* d, const mmvae_exec* ex, int id) {
     if (check_dims(d)) return -1;
-    const Layout L = make_layout(*d);
+    const Layout L = make_layout(*d, ex);
     switch (id) {
         case MMVAE_WS_X_LOW: return L.XLOW;
         case MMVAE_WS_C_PROB: return L.CPROB;
@@ -447,38 +409,48 @@ int64_t mmvae_ws_offset(const mmvae_dims* d, int id) {
         case MMVAE_WS_GZC: return L.GZC;
         case MMVAE_WS_G5: return L.G[5];
         case MMVAE_WS_BN_MEAN1: return L.bn_mean[0];
+        case MMVAE_WS_GD10_SLAB: return L.GD10_slab;
         default: set_error("unknown workspace id %d", id); return -1;
     }
 }
 
-int64_t mmvae_ws_debug_offset(const mmvae_dims* d) {
+int mmvae_splits(const mmvae_dims* d, const mmvae_exec* ex, int32_t out[6]) {
+    if (int rc = check_dims(d)) return rc;
+    if (!out) { set_error("out is null"); return MMVAE_E_BADARG; }
+    const Splits s = default_splits(*d, ex);
+    out[0] = s.ks_fc1; out[1] = s.ns_fc11; out[2] = s.ks_dw; out[3] = s.ks_small; out[4] = s.ks_gd10; out[5] = s.ks_dw11;
+    return 0;
+}
+
+int64_t mmvae_ws_debug_offset(const mmvae_dims* d, const mmvae_exec* ex) {
     if (check_dims(d)) return -1;
-    return make_layout(*d).loss_scratch + 2048;
+    return make_layout(*d, ex).loss_scratch + 2048;
 }
 
 int mmvae_forward(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, const float* params,
                   float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride, float* x_rec, int need_grad,
-                  void* ws, size_t ws_bytes, void* stream) {
+                  void* ws, size_t ws_bytes, mmvae_exec* ex, void* stream) {
     Ctx c;
-    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
     if (!params || !x) { set_error("null params / x"); return MMVAE_E_BADARG; }
     if (int rc = check_noise(c, nz)) return rc;
     if (need_grad && !h->training) { set_error("need_grad requires training mode (batch statistics)"); return MMVAE_E_UNSUPPORTED; }
     return do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, x_rec, need_grad);
 }
 
-int mmvae_loss(const mmvae_dims* d, const mmvae_hyper* h, void* ws, size_t ws_bytes, float* loss_out, void* stream) {
+int mmvae_loss(const mmvae_dims* d, const mmvae_hyper* h, void* ws, size_t ws_bytes, float* loss_out, mmvae_exec* ex,
+               void* stream) {
     Ctx c;
-    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
     if (!loss_out) { set_error("loss_out is null"); return MMVAE_E_BADARG; }
     return do_loss(c, loss_out);
 }
 
 int mmvae_backward(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, const float* params,
                    const float* x, int64_t x_arm_stride, float grad_scale, void* ws, size_t ws_bytes, float* grads,
-                   void* stream) {
+                   mmvae_exec* ex, void* stream) {
     Ctx c;
-    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
     if (!params || !x || !grads) { set_error("null params / x / grads"); return MMVAE_E_BADARG; }
     if (int rc = check_noise(c, nz)) return rc;
     if (!h->training) { set_error("backward requires training mode"); return MMVAE_E_UNSUPPORTED; }
@@ -500,9 +472,9 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
                      float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes,
                      float* grads, float* loss_out, int do_adam, float* exp_avg, float* exp_avg_sq, int64_t step,
                      float lr, float beta1, float beta2, float adam_eps, float weight_decay, int decoupled,
-                     void* stream) {
+                     mmvae_exec* ex, void* stream) {
     Ctx c;
-    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
     if (!params || !x || !grads || !loss_out) { set_error("null params / x / grads / loss_out"); return MMVAE_E_BADARG; }
     if (int rc = check_noise(c, nz)) return rc;
     if (!h->training) { set_error("train_step requires training mode"); return MMVAE_E_UNSUPPORTED; }
@@ -511,7 +483,7 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
     if ((rc = do_forward(c, nz, params, bn_running, nbt, x, x_arm_stride, nullptr, 1, &side_loss, loss_out))) return rc;
     const bool loss_on_side = side_loss && fc11_split_path(c, params, x, x_arm_stride);
     if (side_loss && !loss_on_side) {   // general path: coupling done on the side, finalise here
-        if (hipStreamWaitEvent(c.stream, g_ev_couple, 0) != hipSuccess) { set_error("stream join failed"); return MMVAE_E_LAUNCH; }
+        if ((rc = join_from_side(c, EV_COUPLE))) return rc;
         if ((rc = launch_loss_finalize(c, loss_out))) return rc;
     } else if (!side_loss && (rc = do_loss(c, loss_out))) {
         return rc;
@@ -528,9 +500,9 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
 
 int mmvae_eval_classify(const mmvae_dims* d, const mmvae_hyper* h, const float* params, const float* bn_running,
                         const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes, int32_t* labels,
-                        int64_t* counts, void* stream) {
+                        int64_t* counts, mmvae_exec* ex, void* stream) {
     Ctx c;
-    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
     if (!params || !x || !bn_running || !labels) { set_error("null params / x / bn_running / labels"); return MMVAE_E_BADARG; }
     if (h->training || !h->eval_flag) { set_error("eval_classify needs training = 0 and eval_flag = 1"); return MMVAE_E_UNSUPPORTED; }
     int rc;
@@ -567,9 +539,9 @@ int mmvae_consensus(const int64_t* counts, int npairs, int C, double* cm_norm, d
 
 int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, int stage,
                       const float* params, const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes,
-                      float* grads, void* stream) {
+                      float* grads, mmvae_exec* ex, void* stream) {
     Ctx c;
-    if (int rc = make_ctx(c, d, h, ws, ws_bytes, stream)) return rc;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
     if (!params || !x) { set_error("null params / x"); return MMVAE_E_BADARG; }
     if (int rc = check_noise(c, nz)) return rc;
     switch (stage) {

@@ -371,14 +371,14 @@ static void aug_gemm_launch(hipStream_t s, bool relu, bool affine, const float* 
     else hipLaunchKernelGGL((k_aug_gemm<BM, BN, BK, false, false>), grid, block, 0, s, A, lda, M, W, ldw, N, K, sc, sh, C, ldc, tiles_n, tiles_m);
 }
 
-static int aug_gemm(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* pk,
+static int aug_gemm(hipStream_t s, int force_tile, bool relu, bool affine, const float* A, int lda, int M, const float* pk,
                     const AugLayer& g, float* C, int ldc) {
     const int ncols = ldc < (int)pad4(g.N) ? ldc : (int)pad4(g.N);   // the K padding of the next layer is written too (zeros)
     const float* W = pk + g.w;
     const float* sc = pk + g.sc;
     const float* sh = pk + g.sh;
     // the largest tile that still leaves two workgroups per CU (256 CUs); MMVAE_AUG_TILE=<BM><BN> code forces one
-    static const int force = getenv("MMVAE_AUG_TILE") ? atoi(getenv("MMVAE_AUG_TILE")) : 0;   // 11 12 21 22 (1 = 64, 2 = 128)
+    const int force = force_tile;   // 11 12 21 22 (1 = 64, 2 = 128), 0 = automatic
     auto count = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(ncols, bn); };
     int pick = 11;
     if (count(128, 128) >= 512) pick = 22;
@@ -468,7 +468,8 @@ int mmvae_aug_pack(const mmvae_aug_dims* d, const mmvae_aug_tensors* t, float* p
 }
 
 int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, int64_t x_arm_stride, const float* z0,
-                  const float* eps_n, float scale, void* ws, size_t ws_bytes, float* s_out, float* x_aug, void* stream) {
+                  const float* eps_n, float scale, void* ws, size_t ws_bytes, float* s_out, float* x_aug,
+                  const mmvae_exec* ex, void* stream) {
     if (int rc = aug_check_dims(d)) return rc;
     if (!packed || !x || !z0 || !eps_n || !ws || !s_out || !x_aug) { set_error("augment: null argument"); return MMVAE_E_BADARG; }
     const bool shared = x_arm_stride == 0;
@@ -482,13 +483,14 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     const AugPacked L = aug_packed_layout(*d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* w = reinterpret_cast<float*>(ws);
+    const int ft = ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0;
     int rc;
     // trunk: once per cell when the arms share x
-    if ((rc = aug_gemm(s, true, true, x, d->D, T, packed, L.g[0], w + W.h1, W.ld1))) return rc;
-    if ((rc = aug_gemm(s, true, true, w + W.h1, W.ld1, T, packed, L.g[1], w + W.h2, W.ld1))) return rc;
-    if ((rc = aug_gemm(s, true, true, w + W.h2, W.ld1, T, packed, L.g[2], w + W.h3, W.ld3))) return rc;
-    if ((rc = aug_gemm(s, true, true, w + W.h3, W.ld3, T, packed, L.g[3], w + W.h4, W.ld3))) return rc;
-    if ((rc = aug_gemm(s, false, false, w + W.h4, W.ld3, T, packed, L.g[4], w + W.P, W.ld5))) return rc;
+    if ((rc = aug_gemm(s, ft, true, true, x, d->D, T, packed, L.g[0], w + W.h1, W.ld1))) return rc;
+    if ((rc = aug_gemm(s, ft, true, true, w + W.h1, W.ld1, T, packed, L.g[1], w + W.h2, W.ld1))) return rc;
+    if ((rc = aug_gemm(s, ft, true, true, w + W.h2, W.ld1, T, packed, L.g[2], w + W.h3, W.ld3))) return rc;
+    if ((rc = aug_gemm(s, ft, true, true, w + W.h3, W.ld3, T, packed, L.g[3], w + W.h4, W.ld3))) return rc;
+    if ((rc = aug_gemm(s, ft, false, false, w + W.h4, W.ld3, T, packed, L.g[4], w + W.P, W.ld5))) return rc;
     {
         const size_t shm = aug_latent_lds_bytes(*d);
         if (shm > 64 * 1024)
@@ -498,11 +500,11 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
                            shared ? 1 : 0, w + W.P, W.ld5, z0, eps_n, scale, s_out, w + W.H6);
         HIP_LAUNCH_CHECK("k_aug_latent");
     }
-    if ((rc = aug_gemm(s, true, true, w + W.H6, W.ld5, R, packed, L.g[5], w + W.h7, W.ld3))) return rc;
-    if ((rc = aug_gemm(s, true, true, w + W.h7, W.ld3, R, packed, L.g[6], w + W.h8, W.ld3))) return rc;
-    if ((rc = aug_gemm(s, true, true, w + W.h8, W.ld3, R, packed, L.g[7], w + W.h9, W.ld1))) return rc;
-    if ((rc = aug_gemm(s, true, true, w + W.h9, W.ld1, R, packed, L.g[8], w + W.h10, W.ld1))) return rc;
-    return aug_gemm(s, true, true, w + W.h10, W.ld1, R, packed, L.g[9], x_aug, d->D);
+    if ((rc = aug_gemm(s, ft, true, true, w + W.H6, W.ld5, R, packed, L.g[5], w + W.h7, W.ld3))) return rc;
+    if ((rc = aug_gemm(s, ft, true, true, w + W.h7, W.ld3, R, packed, L.g[6], w + W.h8, W.ld3))) return rc;
+    if ((rc = aug_gemm(s, ft, true, true, w + W.h8, W.ld3, R, packed, L.g[7], w + W.h9, W.ld1))) return rc;
+    if ((rc = aug_gemm(s, ft, true, true, w + W.h9, W.ld1, R, packed, L.g[8], w + W.h10, W.ld1))) return rc;
+    return aug_gemm(s, ft, true, true, w + W.h10, W.ld1, R, packed, L.g[9], x_aug, d->D);
 }
 
 }  // extern "C"

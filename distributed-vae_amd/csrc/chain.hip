@@ -618,7 +618,7 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     a.ld = fwd_ld(max(d.H, N));
     a.wrows = max(rup(N, 32), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch (statistics prologue / epilogue)
     a.per_arm = c.po.per_arm;
-    a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
+    a.ablate = c.tune(MMVAE_TUNE_ABLATE_C);
     a.dbg_off = L.loss_scratch + 2048;
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws, bn_running, nbt);
@@ -676,7 +676,7 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.ld = fwd_ld(max(max(d.H, d.L), d.C + d.S));
     a.wrows = rup(max(d.H, d.L), 32);
     a.per_arm = c.po.per_arm;
-    a.ablate = getenv("MMVAE_ABLATE_C") ? atoi(getenv("MMVAE_ABLATE_C")) : 0;
+    a.ablate = c.tune(MMVAE_TUNE_ABLATE_C);
     a.dbg_off = L.loss_scratch + 2048;
     hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
                        c.ws, (float*)nullptr, (int64_t*)nullptr);

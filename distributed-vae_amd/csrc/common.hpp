@@ -68,8 +68,8 @@ struct Layout {
     int64_t total;
 };
 
-Layout make_layout(const mmvae_dims& d);
-Splits default_splits(const mmvae_dims& d);
+Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex);
+Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex);
 
 // Per-arm parameter offsets (floats) -- mirrors mmvae_param_layout_t
 struct POff {
@@ -529,7 +529,14 @@ struct Ctx {
     POff po;
     float* ws;
     hipStream_t stream;
+    mmvae_exec ex;          // copy of the caller's execution context (zeros when the caller passed none)
+    mmvae_exec* ex_out;     // the caller's own, for `early_recorded` (may be null)
+    hipStream_t side() const { return reinterpret_cast<hipStream_t>(ex.side_stream); }
+    hipEvent_t ev(int i) const { return reinterpret_cast<hipEvent_t>(ex.ev[i]); }
+    int tune(int i) const { return ex.tune[i]; }
 };
+// events of mmvae_exec.ev by role
+enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE };
 
 #ifdef __HIPCC__
 NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h);

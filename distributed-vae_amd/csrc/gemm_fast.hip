@@ -1409,11 +1409,11 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
     const mmvae_dims& d = c.d;
     const bool use_mask = c.h.training && c.h.x_drop > 0.f;
     const int KS = c.lay.sp.ks_fc1;
-    static const int ablate = getenv("MMVAE_ABLATE") ? atoi(getenv("MMVAE_ABLATE")) : 0;   // timing experiments only
-    static const int padlds = getenv("MMVAE_PADLDS") ? atoi(getenv("MMVAE_PADLDS")) : 0;   // occupancy experiments
+    const int ablate = c.tune(MMVAE_TUNE_ABLATE);   // timing experiments only
+    const int padlds = c.tune(MMVAE_TUNE_PADLDS);   // occupancy experiments
     dim3 grid(cdiv(d.B, 128), KS, d.A);
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits);
-    static const int v3off = getenv("MMVAE_FC1_V2") ? atoi(getenv("MMVAE_FC1_V2")) : 0;   // A/B timing
+    const int v3off = c.tune(MMVAE_TUNE_FC1_V2);   // A/B timing
     if (d.H == 100 && !v3off) {
         if (use_mask)
             hipLaunchKernelGGL((k_fc1_fwd_v3<true>), grid, dim3(256), padlds, c.stream, x, xs, params, c.po.per_arm,
@@ -1443,7 +1443,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
     const int NS = L.sp.ns_fc11;
     // train step at fc_dim 100: d(d10) is folded into the fc11 kernel (k_fc11_zg), whose gene split count equals the
     // d(d10) kernel's so that the decoder backward sums the same number of slabs whichever forward ran
-    static const int zg_off = getenv("MMVAE_FC11_ZG") ? (atoi(getenv("MMVAE_FC11_ZG")) == 0) : 0;   // A/B timing
+    const int zg_off = c.tune(MMVAE_TUNE_FC11_ZG_OFF);   // A/B timing
     const bool use_zg = need_grad && !x_rec && d.H == 100 && !zg_off &&
                         (int64_t)cdiv(d.B, 256) * L.sp.ks_gd10 <= L.n11;
     if ((which & 1) && use_zg) {
@@ -1468,13 +1468,13 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
         const int ntall = cdiv(d.D, 64);
         const int kgv = rup(d.H, 8) / 8;
-        static const int ablz = getenv("MMVAE_ABLATE_Z") ? atoi(getenv("MMVAE_ABLATE_Z")) : 0;   // timing experiments
+        const int ablz = c.tune(MMVAE_TUNE_ABLATE_Z);   // timing experiments
         {
             // one 512-thread workgroup per CU: split the gene range so that the grid fills the chip once
             const int nb = cdiv(d.B, 256);
             int nsz = max(1, min(min(256 / max(nb * d.A, 1), 16), ntall));
             while (nsz > 1 && (int64_t)nb * nsz > L.n11) --nsz;
-            static const int nsz_env = getenv("MMVAE_FC11_NSZ") ? atoi(getenv("MMVAE_FC11_NSZ")) : 0;
+            const int nsz_env = c.tune(MMVAE_TUNE_FC11_NSZ);
             if (nsz_env > 0 && (int64_t)nb * nsz_env <= L.n11) nsz = min(nsz_env, ntall);
             const size_t shm = (size_t)(2 * 64 * ldk + 16) * sizeof(float);
             dim3 grid(nb, nsz, d.A);
@@ -1509,7 +1509,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         }
     }
     if (need_grad && (which & 2)) {
-        static const int v2only = getenv("MMVAE_GD10_V2") ? atoi(getenv("MMVAE_GD10_V2")) : 0;   // A/B timing
+        const int v2only = c.tune(MMVAE_TUNE_GD10_V2);   // A/B timing
         if (d.H == 100 && !v2only)
             hipLaunchKernelGGL(k_gd10_v3, dim3(cdiv(d.B, 128), L.sp.ks_gd10, d.A), dim3(256), 0, c.stream, c.ws + L.DZ11,
                                params, c.po.per_arm, c.po.o[26], c.ws + L.GD10_slab, d.A, d.B, d.D, d.H, L.sp.ks_gd10);
@@ -1531,7 +1531,7 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
     if (which & 1) {   // dW1[h][d] = sum_b dZ1[b][h] x~[b][d]   -> slab [KS][A][H][D]
         const int tiles_n = cdiv(d.D, 128);
         dim3 grid(cdiv(d.H, 128) * tiles_n, KS, d.A);
-        static const int v2only = getenv("MMVAE_DW1_V2") ? atoi(getenv("MMVAE_DW1_V2")) : 0;   // A/B timing
+        const int v2only = c.tune(MMVAE_TUNE_DW1_V2);   // A/B timing
         if (d.H == 100 && !v2only) {
             if (use_mask)
                 hipLaunchKernelGGL((k_tn_v3m<true>), grid, dim3(256), 0, c.stream, c.ws + L.DZ[1],
@@ -1557,7 +1557,7 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
         const int tiles_n = cdiv(d.H + 1, 128);
         const int KS11 = L.sp.ks_dw11;
         dim3 grid(cdiv(d.D, 128) * tiles_n, KS11, d.A);
-        static const int v2o = getenv("MMVAE_DW11_V2") ? atoi(getenv("MMVAE_DW11_V2")) : 0;   // A/B timing
+        const int v2o = c.tune(MMVAE_TUNE_DW11_V2);   // A/B timing
         if (d.H == 100 && !v2o)
             hipLaunchKernelGGL(k_tn_v3n, grid, dim3(256), 0, c.stream, c.ws + L.DZ11, (int64_t)d.B * d.D,
                                d.D, d.D, c.ws + L.Dk[4], (int64_t)d.B * d.H, d.H, d.H, bits, wpr, c.ws + L.dw11_slab,

@@ -1459,7 +1459,7 @@ static LatArgs make_lat_args(const Ctx& c) {
     a.bn5_n = L.nblkc;
     a.run_mean_off = c.po.bn_mean[4]; a.run_var_off = c.po.bn_var[4]; a.run_arm_stride = c.po.bn_per_arm;
     a.bn_momentum = c.h.bn_momentum;
-    static const int abl = getenv("MMVAE_ABLATE_L") ? atoi(getenv("MMVAE_ABLATE_L")) : 0;
+    const int abl = c.tune(MMVAE_TUNE_ABLATE_L);
     a.dbg_off = (abl & 8) ? L.loss_scratch + 2048 : -1;
     return a;
 }
@@ -1490,7 +1490,7 @@ int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, flo
     a.labels = labels;
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    static const int fullwave = getenv("MMVAE_LAT_FULLWAVE") ? atoi(getenv("MMVAE_LAT_FULLWAVE")) : 0;   // A/B timing
+    const int fullwave = c.tune(MMVAE_TUNE_LAT_FULLWAVE);   // A/B timing
     if (!fullwave && a.dbg_off < 0 && c.d.C <= 32 * LH_CPL && c.d.L <= 32 && 2 * c.d.S <= 32) {
         hipLaunchKernelGGL(k_lat_fwd_h, dim3(c.lay.nblkl, c.d.A), dim3(64 * LH_NW), shm, c.stream, a, nd, params, c.ws,
                            bn_running, nbt);
@@ -1527,7 +1527,7 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    static const int fullwave = getenv("MMVAE_LAT_FULLWAVE") ? atoi(getenv("MMVAE_LAT_FULLWAVE")) : 0;   // A/B timing
+    const int fullwave = c.tune(MMVAE_TUNE_LAT_FULLWAVE);   // A/B timing
     if (!fullwave && c.d.C <= 32 * LH_CPL && c.d.L <= 32 && 2 * c.d.S <= 32) {
         hipLaunchKernelGGL(k_lat_bwd_h, dim3(cdiv(c.d.B, LAT_ROWS_BWD), c.d.A), dim3(64 * LBH_NW), shm, c.stream, a, nd, params, c.ws);
         HIP_LAUNCH_CHECK("k_lat_bwd_h");

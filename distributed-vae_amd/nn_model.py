@@ -125,6 +125,7 @@ class mixVAE_model(nn.Module):
         self._explicit_noise = None
         self._noise_seed = None
         self._noise_offset = 0
+        self._exec: Optional[N.Exec] = None   # None: split factors / experiment switches from the environment
 
     # ------------------------------------------------------------------ flat parameter storage
     def _dims(self, B: int) -> N.Dims:
@@ -193,7 +194,7 @@ class mixVAE_model(nn.Module):
             self._pack()
         if self._engine is None or self._engine.dims.B != B or self._engine.device != self._flat.device:
             d = self._dims(B)
-            self._engine = N.Engine(d.A, d.B, d.D, d.H, d.L, d.C, d.S, self._flat.device)
+            self._engine = N.Engine(d.A, d.B, d.D, d.H, d.L, d.C, d.S, self._flat.device, self._exec)
         return self._engine
 
     def flat_parameters(self) -> torch.Tensor:
@@ -271,17 +272,50 @@ class mixVAE_model(nn.Module):
         grab = lambda name, w: list(eng.ws_view(name, w).clone().unbind(0))
         out = (list(x_rec.unbind(0)), [], [], grab("x_low", L), grab("c", Cc), grab("s_smp", S), grab("c_smp", Cc),
                grab("s_mean", S), grab("s_logvar", S), grab("c_prob", Cc))
-        self._ctx["out_ids"] = (id(out[0][0]), id(out[7][0]))
+        self._ctx["outs"] = out           # loss() checks that it is handed exactly these
+        self._ctx["x_in"] = x if isinstance(x, torch.Tensor) else list(x)
         return out
 
+    @staticmethod
+    def _same(given, kept) -> bool:
+        """Is ``given`` (a list of per-arm tensors, or one stacked tensor) the list ``forward`` returned?"""
+        if isinstance(given, torch.Tensor):
+            given = list(given.unbind(0)) if given.dim() == kept[0].dim() + 1 else [given]
+        try:
+            given = list(given)
+        except TypeError:
+            return False
+        return len(given) == len(kept) and all(
+            isinstance(g, torch.Tensor) and (g is k or (g.data_ptr() == k.data_ptr() and g.shape == k.shape
+                                                         and g._version == k._version))
+            for g, k in zip(given, kept))
+
     def loss(self, recon_x, p_x, r_x, x, mu, log_sigma, qc, c, prior_c=[]):
-        """Same contract as nn_model.py:495-598.  The tensors must be the ones the preceding
-        ``forward`` returned (the kernels keep their own copies); returns the reference's 9-tuple."""
+        """Same contract as nn_model.py:495-598; returns the reference's 9-tuple.
+
+        The loss is evaluated by the kernels on what the preceding ``forward`` left in the workspace, so ``recon_x``,
+        ``mu``, ``log_sigma``, ``qc`` and ``c`` MUST be the tensors that ``forward`` returned (outputs 0, 7, 8, 4, 6,
+        unmodified) and ``x`` the input it was given: anything else raises instead of silently returning the loss of
+        other tensors (the reference, mmidas/model.py:108-113, computes from whatever it is handed)."""
         assert len(recon_x) == len(c) == self.n_arm
         assert not self.ref_prior
         if self._ctx is None:
             raise RuntimeError("loss() must follow forward()")
         A = self.n_arm
+        kept = self._ctx["outs"]
+        for name, given, idx in (("recon_x", recon_x, 0), ("mu", mu, 7), ("log_sigma", log_sigma, 8), ("qc", qc, 4),
+                                 ("c", c, 6)):
+            if not self._same(given, kept[idx]):
+                raise ValueError(f"loss(): `{name}` is not the unmodified output {idx} of the preceding forward(); the HIP "
+                                 "engine evaluates the loss on the tensors its forward produced")
+        x_in = self._ctx["x_in"]
+        same_obj = x is x_in or (not isinstance(x, torch.Tensor) and not isinstance(x_in, torch.Tensor) and x is not None
+                                 and len(x) == len(x_in) and all(p is q for p, q in zip(x, x_in)))
+        if x is not None and not same_obj:   # (None: callers that only want the scalars of the last forward)
+            xt, _ = self._prep_x(x)
+            x0 = self._ctx["x"]
+            if not (xt.data_ptr() == x0.data_ptr() or (xt.shape == x0.shape and torch.equal(xt, x0))):
+                raise ValueError("loss(): `x` is not the input of the preceding forward()")
         eng = self._engine
         buf = eng.loss(self._ctx["hyper"])
         if A == 1:

@@ -18,8 +18,10 @@
  *
  * Conventions
  *   - plain pointers and sizes only; every buffer is caller-owned DEVICE memory (fp32 unless
- *     noted); the library never allocates or frees device memory and keeps no global mutable
- *     state besides the last error string (thread-local).
+ *     noted); the library never allocates or frees device memory, creates no streams or events and keeps no
+ *     global mutable state besides the last error string (thread-local).  Everything a call needs beyond its
+ *     arguments -- the optional second stream, the events that fork and join it, split factors, experiment
+ *     switches -- travels in a caller-owned mmvae_exec passed to the call; two engines never share any.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant, with no
  *     hidden synchronisation.
  *   - return value: 0 = ok, <0 = error (MMVAE_E_*); mmvae_last_error_string() explains.
@@ -82,6 +84,58 @@ typedef struct mmvae_noise {
     uint64_t offset;        /* advance by 1 per step                                       */
 } mmvae_noise;
 
+
+/* Caller-owned execution context (one per engine / workspace; NULL = defaults: single stream, automatic split
+ * factors).  The library reads it during a call and writes only `early_recorded`.
+ *   side_stream  optional second hipStream_t on the same device.  With it mmvae_backward / mmvae_train_step run the
+ *                [dW11 | db11] GEMM, the coupling terms and the loss scalars beside the latency-bound chains of the main
+ *                stream (fork / join by the events below).  The caller keeps stream and events alive while work that
+ *                uses them is in flight.
+ *   ev           MMVAE_N_EVENTS hipEvent_t (hipEventDisableTiming suffices), all non-NULL when side_stream is.
+ *   early_grad_event  data-parallel overlap: when non-NULL (and side_stream is set), mmvae_backward and
+ *                mmvae_train_step(do_adam == 0) reduce the gradients of fc11.weight / fc11.bias -- the last two
+ *                tensors of every arm's segment of `grads`, 47 % of the parameters -- as soon as their GEMM has
+ *                finished and record this event on the side stream, so the caller can start the all-reduce of those
+ *                ranges while the rest of backward runs (replaces the reference's FSDP gradient traffic,
+ *                train.py:140-143).  All other gradients are final when the call's work on `stream` is.
+ *   early_recorded  out: 1 if the call recorded early_grad_event (it does not on shapes the fast kernels do not
+ *                take, without a side stream, or with do_adam != 0): only then may the caller wait on it.
+ *   split        split factors of the large GEMMs, 0 = automatic: 0 fc1 split-K, 1 fc11 column splits, 2 dW1 batch
+ *                splits, 3 small-layer dW batch splits, 4 d(d10) gene splits, 5 dW11 batch splits.  They change the
+ *                workspace layout: pass the same context to mmvae_workspace_bytes / mmvae_ws_offset.
+ *   tune         experiment switches (A/B timing, ablations; MMVAE_TUNE_*), 0 = production behaviour.  The library
+ *                reads no environment variables. */
+#define MMVAE_N_EVENTS 8
+#define MMVAE_N_TUNE 24
+enum {
+    MMVAE_TUNE_EVAL_CHAIN_OFF = 0, /* eval mode: fc2..fc5 as four launches instead of one          */
+    MMVAE_TUNE_DW11_AT,            /* where dW11 forks: 0 start of backward, 1 after decoder chain, 2 after latent */
+    MMVAE_TUNE_SIDE_SMALL,         /* small-layer dW GEMMs on the side stream                         */
+    MMVAE_TUNE_AUG_TILE,           /* augmenter GEMM tile 11 12 21 22 (1 = 64, 2 = 128)              */
+    MMVAE_TUNE_ABLATE_C,           /* chain kernels: timing ablations / cycle stamps (results wrong) */
+    MMVAE_TUNE_ABLATE,             /* fc1 forward ablations                                           */
+    MMVAE_TUNE_PADLDS,             /* fc1 forward: extra dynamic LDS (occupancy experiments)          */
+    MMVAE_TUNE_FC1_V2,             /* previous kernel generations ...                                 */
+    MMVAE_TUNE_FC11_ZG_OFF,
+    MMVAE_TUNE_ABLATE_Z,
+    MMVAE_TUNE_FC11_NSZ,
+    MMVAE_TUNE_GD10_V2,
+    MMVAE_TUNE_DW1_V2,
+    MMVAE_TUNE_DW11_V2,
+    MMVAE_TUNE_ABLATE_L,           /* latent kernels: ablations                                       */
+    MMVAE_TUNE_LAT_FULLWAVE,       /* latent kernels: one wave per cell instead of the half-wave layout */
+    MMVAE_TUNE_PERSIST_OFF,        /* encoder chains as one launch per layer instead of the persistent kernels */
+    MMVAE_TUNE_COUNT_
+};
+typedef struct mmvae_exec {
+    void *side_stream;
+    void *ev[MMVAE_N_EVENTS];
+    void *early_grad_event;
+    int32_t early_recorded;
+    int32_t split[6];
+    int32_t tune[MMVAE_N_TUNE];
+} mmvae_exec;
+
 /* Where things are, in floats.  Filled by mmvae_param_layout. Tensor order t = 0..27:
  *  0 fc1.w[H,D] 1 fc1.b 2 fc2.w[H,H] 3 fc2.b 4 fc3.w 5 fc3.b 6 fc4.w 7 fc4.b 8 fc5.w[L,H] 9 fc5.b
  * 10 fcc.w[C,L] 11 fcc.b 12 fc_mu.w[S,L+C] 13 fc_sigma.w[S,L+C] 14 fc_mu.b 15 fc_sigma.b
@@ -133,22 +187,28 @@ typedef enum mmvae_ws_id {
     MMVAE_WS_GZC,       /* [A,B,C]  d loss / d fcc output */
     MMVAE_WS_G5,        /* [A,B,L]  d loss / d x_low */
     MMVAE_WS_BN_MEAN1,  /* [A,H] batch mean of R1 (then BN_MEAN1+i for layer i+1) */
+    MMVAE_WS_GD10_SLAB, /* [n_slab][A,B,H] gene-split partial sums of d loss / d d10 = dZ11 W11 (n_slab: mmvae_splits[4]) */
     MMVAE_WS_COUNT_
 } mmvae_ws_id;
 
 /* ---- queries (host only, no GPU needed) ------------------------------------------------- */
 int mmvae_abi_version(void);
 const char *mmvae_last_error_string(void);
-/* 0 if the kernels support these dims (H,C,L<=128, L+C,C+S<=256, A<=MMVAE_MAX_ARMS, ...). */
+/* 0 if the kernels support these dims (H,C<=128, L<=64, S<=32, L+C,C+S<=255, A<=MMVAE_MAX_ARMS).  Calls with
+ * h->training != 0 additionally need B >= 2 (batch statistics); eval mode takes a one-cell batch. */
 int mmvae_check_dims(const mmvae_dims *d);
 int mmvae_param_layout(const mmvae_dims *d, mmvae_param_layout_t *out);
 /* bytes of caller-provided workspace that forward/loss/backward/train_step need */
-size_t mmvae_workspace_bytes(const mmvae_dims *d);
+size_t mmvae_workspace_bytes(const mmvae_dims *d, const mmvae_exec *ex);
 /* offset (in floats) of a named region inside the workspace, or -1 */
-int64_t mmvae_ws_offset(const mmvae_dims *d, int ws_id);
+int64_t mmvae_ws_offset(const mmvae_dims *d, const mmvae_exec *ex, int ws_id);
+/* the split factors the layout uses for these dims and context, in the order of mmvae_exec.split (0 fc1 split-K, 1 fc11 column
+ * splits, 2 dW1 batch splits, 3 small-layer dW batch splits, 4 d(d10) gene splits = slabs of MMVAE_WS_GD10_SLAB,
+ * 5 dW11 batch splits) */
+int mmvae_splits(const mmvae_dims *d, const mmvae_exec *ex, int32_t out[6]);
 /* offset (in floats) of a 1024-float block inside the workspace that only diagnostic builds write
  * (in-kernel cycle stamps, enabled by environment switches; never read by any kernel) */
-int64_t mmvae_ws_debug_offset(const mmvae_dims *d);
+int64_t mmvae_ws_debug_offset(const mmvae_dims *d, const mmvae_exec *ex);
 
 /* ---- compute (device pointers, asynchronous on stream) ----------------------------------- */
 
@@ -162,18 +222,18 @@ int64_t mmvae_ws_debug_offset(const mmvae_dims *d);
 int mmvae_forward(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,
                   const float *params, float *bn_running, int64_t *num_batches_tracked,
                   const float *x, int64_t x_arm_stride, float *x_rec, int need_grad,
-                  void *ws, size_t ws_bytes, void *stream);
+                  void *ws, size_t ws_bytes, mmvae_exec *ex, void *stream);
 
 /* Finishes the loss scalars from what forward left in ws.  Must follow mmvae_forward on the same
  * ws/stream. */
 int mmvae_loss(const mmvae_dims *d, const mmvae_hyper *h, void *ws, size_t ws_bytes,
-               float *loss_out, void *stream);
+               float *loss_out, mmvae_exec *ex, void *stream);
 
 /* Gradient of loss_out[0] * grad_scale w.r.t. every parameter into `grads` (flat, same layout
  * as params; fully overwritten).  Needs forward(need_grad=1) + loss on the same ws. */
 int mmvae_backward(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,
                    const float *params, const float *x, int64_t x_arm_stride, float grad_scale,
-                   void *ws, size_t ws_bytes, float *grads, void *stream);
+                   void *ws, size_t ws_bytes, float *grads, mmvae_exec *ex, void *stream);
 
 /* torch.optim.Adam / AdamW semantics on a flat buffer of n floats. step >= 1. */
 int mmvae_adam_step(int64_t n, float *params, const float *grads, float *exp_avg,
@@ -188,7 +248,7 @@ int mmvae_train_step(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
                      const float *x, int64_t x_arm_stride, void *ws, size_t ws_bytes,
                      float *grads, float *loss_out, int do_adam, float *exp_avg,
                      float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2,
-                     float adam_eps, float weight_decay, int decoupled, void *stream);
+                     float adam_eps, float weight_decay, int decoupled, mmvae_exec *ex, void *stream);
 
 /* ---- evaluation labels and between-arm consensus ----------------
  * Replaces the per-epoch host loop of mmidas/cpl_mixvae.py:563-657: eval-mode forward of every batch,
@@ -208,7 +268,7 @@ int mmvae_train_step(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
  *   cm_norm (double [npairs, C, C]) may be NULL; consensus: double [npairs]. */
 int mmvae_eval_classify(const mmvae_dims *d, const mmvae_hyper *h, const float *params,
                         const float *bn_running, const float *x, int64_t x_arm_stride, void *ws,
-                        size_t ws_bytes, int32_t *labels, int64_t *counts, void *stream);
+                        size_t ws_bytes, int32_t *labels, int64_t *counts, mmvae_exec *ex, void *stream);
 int mmvae_classify(const float *c_probs, int64_t n_cells, int C, int32_t *labels, void *stream);
 int mmvae_confmat_accumulate(const int32_t *labels, int A, int64_t n, int C, int64_t *counts,
                              void *stream);
@@ -245,7 +305,7 @@ int mmvae_aug_pack(const mmvae_aug_dims *d, const mmvae_aug_tensors *t, float *p
  * ready as the per-arm input of mmvae_train_step (x_arm_stride = B*D). */
 int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, int64_t x_arm_stride,
                   const float *z0, const float *eps, float scale, void *ws, size_t ws_bytes, float *s_out,
-                  float *x_aug, void *stream);
+                  float *x_aug, const mmvae_exec *ex, void *stream);
 
 /* ---- device-resident data path ------------------------------------
  * out[i, :] = data[idx[i], :], i < n: the batch assembly of the reference's DataLoader
@@ -270,30 +330,7 @@ int mmvae_dump_noise(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
  * 12 dW1 GEMM, 13 [dW11|db11] GEMM, 14 fc1 GEMM without its epilogue. */
 int mmvae_debug_stage(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz, int stage,
                       const float *params, const float *x, int64_t x_arm_stride, void *ws,
-                      size_t ws_bytes, float *grads, void *stream);
-
-/* Optional side stream (per host thread).  When set (non-NULL), mmvae_backward / mmvae_train_step run
- * the [dW11 | db11] GEMM on it, concurrently with the latency-bound decoder/encoder backward chain on
- * the main stream, fork/join by events (created lazily, one pair per host thread).  The caller owns the
- * stream and must keep it alive; pass NULL to return to single-stream operation. */
-int mmvae_set_side_stream(void *side_stream);
-
-/* Data-parallel overlap (per host thread, needs a side stream).  With a non-NULL hipEvent_t set here, mmvae_backward and
- * mmvae_train_step(do_adam == 0) reduce the gradients of fc11.weight / fc11.bias -- the last two tensors of every arm's
- * segment of `grads`, 47 % of the parameters -- as soon as their GEMM has finished and record `event` on the side
- * stream: the caller can start the all-reduce of those ranges while the rest of backward runs (replaces the reference's
- * FSDP gradient traffic, train.py:140-143).  All other gradients are final when the call's work on `stream` is.
- * NULL returns to one reduction at the end.  The caller owns the event. */
-int mmvae_set_early_grad_event(void *event);
-/* 1 if the last mmvae_backward / mmvae_train_step of this host thread recorded the event (it does not on shapes the
- * fast kernels do not take, without a side stream, or with do_adam != 0): only then may the caller wait on it. */
-int mmvae_early_grad_event_recorded(void);
-
-/* Tuning knobs (process-wide, host side): split factors of the three large GEMMs.
- * which: 0 = fc1 split-K, 1 = fc11 column splits, 2 = dW1 split over the batch, 3 = small-layer dW split
- * over the batch, 4 = d(d10) GEMM split over the genes, 5 = dW11 split over the batch.  value 0 = auto.
- * Changes the workspace size. */
-int mmvae_set_split(int which, int value);
+                      size_t ws_bytes, float *grads, mmvae_exec *ex, void *stream);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,34 @@ def test_against_oracle_shared_and_per_arm_input(cfg):
     assert _rel(s3, s_ref3) < TOL and _rel(xa3, x_ref3) < TOL
 
 
+@pytest.mark.parametrize("D", [5000, 5032])
+def test_production_shape_against_oracle(D):
+    """The shape bench.py times (B = 5000 cells, A = 2 arms, n_dim 500, noise 50, latent 10) at the synthetic gene count
+    and at the SmartSeq panel's D = 5032, where D / 5 = 1006 is not a multiple of 4 (padded weight rows and activation
+    columns in every D/5-wide layer) and D % 128 != 0 (edge tiles of fc11): per-layer tile selection and the shared-trunk
+    path differ from the small cases above.  Both against the fp64 oracle, with the fp32 oracle as the noise floor."""
+    NZ, Z, ND, A, B = 50, 10, 500, 2, 5000
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=D)
+    m = _model(NZ, Z, D, ND, sd)
+    g = torch.Generator().manual_seed(D)
+    x = (torch.rand(B, D, generator=g) < 0.2).float() * torch.randn(B, D, generator=g).abs() * 3
+    z0, eps = torch.randn(A, B, NZ, generator=g), torch.randn(A, B, Z, generator=g)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    s64, x64 = OA.forward_eval(sd64, x.double().expand(A, -1, -1), z0.double(), eps.double(), 0.1)
+    s32, x32 = OA.forward_eval(sd, x.expand(A, -1, -1), z0, eps, 0.1)
+    m.set_explicit_noise(z0, eps)
+    s, xa = m(x.to(DEV).expand(A, -1, -1), True, 0.1)                  # arms share x: trunk once per cell
+    floor_s, floor_x = _rel(s32.double(), s64), _rel(x32.double(), x64)
+    assert _rel(s.double(), s64) < max(TOL / 4, 4 * floor_s), (_rel(s.double(), s64), floor_s)
+    assert _rel(xa.double(), x64) < max(TOL / 4, 4 * floor_x), (_rel(xa.double(), x64), floor_x)
+    assert float((x64 > 0).float().mean()) > 0.02
+    xs = torch.stack([x * (1 + 0.25 * a) for a in range(A)])           # distinct per-arm inputs: no shared trunk
+    s64b, x64b = OA.forward_eval(sd64, xs.double(), z0.double(), eps.double(), 0.1)
+    s2, xa2 = m(xs.to(DEV), True, 0.1)
+    assert _rel(s2.double(), s64b) < max(TOL / 4, 4 * floor_s) and _rel(xa2.double(), x64b) < max(TOL / 4, 4 * floor_x)
+    assert _rel(xa2[0], xa[0].cpu()) < 1e-6                            # arm 0 saw the same x on both paths
+
+
 def test_device_noise_statistics_and_determinism():
     """Without the explicit hook the module draws torch.randn on the device like the reference: same seed, same
     output; different arms differ; s has the spread the noise implies."""

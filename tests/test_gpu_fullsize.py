@@ -1,0 +1,183 @@
+"""-m gpu: BASELINE.json's configurations at FULL size against the ORACLE (not against this engine's other path).
+
+  cfg2  A = 2, B = 5000, D = 5000   (the benchmark line; also tests/test_gpu_parity.py::test_full_size_against_oracle)
+  cfg4  A = 5, B = 5000, D = 5000   (ten arm pairs in the coupling terms)
+  cfg5  A = 3, B = 5000, D = 5032   (the SmartSeq gene panel stand-in: D % 64 = 40, edge tiles of every big GEMM)
+  and   A = 3, B = 5000, D = 5000
+
+Per case, on one seeded input and explicit noise (oracle/restatement.py, the reference's arithmetic):
+  * the FUSED train step (mmvae_train_step, the path the trainer and bench.py run) against the oracle evaluated in fp64,
+    with the oracle's own fp32 evaluation as the noise floor: two-part bound (typical entry tight, worst entry loose),
+    because 25 M ReLU / 0.1-threshold decisions per arm include a few pre-activations within fp32 rounding of the
+    threshold, and a flipped decision moves one row of a weight gradient in ANY fp32 evaluation order;
+  * a stage-level pin of the dominant kernel's two outputs (k_fc11_zg: dZ11 and the gene-split slabs of d(d10)):
+    every element whose fp64 pre-activation is more than MARGIN from the ReLU threshold must agree with the fp64 oracle
+    to max(STAGE_TOL, 4 x the fp32 CPU oracle's own distance from fp64) of the tensor's largest magnitude -- no allowance for a fraction of bad elements (round 1 had a store
+    hazard that corrupted 81 k of 50 M dZ11 elements and sat inside a 1 % allowance); the number of excluded elements
+    is asserted small; the d(d10) GEMM is pinned exactly against the dZ11 this engine produced.
+"""
+import gc
+import math
+
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL, GRAD_TOL = 1e-5, 1e-3
+STAGE_TOL = 1e-5          # of the largest magnitude of the compared tensor
+MARGIN = 1e-4             # |fp64 pre-activation| below this: the ReLU decision may legitimately differ in fp32
+CASES = {
+    "cfg2_a2_d5000": (2, 5000, 5000),
+    "a3_d5000": (3, 5000, 5000),
+    "cfg4_a5_d5000": (5, 5000, 5000),
+    "cfg5_a3_d5032": (3, 5000, 5032),
+}
+
+
+def _U():
+    from tests import gpu_util as U
+    return U
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request):
+    """Oracle results (fp32 autograd, fp64 autograd, fp64 stage tensors) and one fused step on the GPU."""
+    U = _U()
+    A, B, D = CASES[request.param]
+    h = R.Hyper(input_dim=D, n_arm=A)
+    sd = R.init_state_dict(h, 546 + A)
+    x = R.synthetic_batch(B, D, seed=546 + D)
+    noise = R.draw_noise(h, B, seed=7 + A)
+    # --- oracle, fp32 (noise floor) and fp64 (the reference value)
+    _, lt_32, g_32 = R.grads_autograd({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    n64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in noise.items()}
+    _, lt_64, g_64 = R.grads_autograd({k: v.clone() for k, v in sd64.items()}, [x.double()] * A, h, n64)
+    with torch.no_grad():
+        out64, saved = R.forward({k: v.clone() for k, v in sd64.items()}, [x.double()] * A, h, n64, keep=True)
+    am1 = float(max(A - 1, 1))
+    d10 = torch.stack([s["d10"] for s in saved])                                  # [A,B,H] fp64
+    z11, gz11, gd = [], [], []
+    for a in range(A):
+        z = d10[a] @ sd64[f"fc11.{a}.weight"].t() + sd64[f"fc11.{a}.bias"]       # fc11 pre-activation (nn_model.py:286)
+        gz = am1 * (torch.relu(z) - x.double()) / B * (z > 0)                     # d total / d z11 (nn_model.py:544, :587)
+        z11.append(z.float())
+        gz11.append(gz)
+        gd.append(gz @ sd64[f"fc11.{a}.weight"])
+    del out64, saved
+    # the fp32 oracle's own stage values: its distance from fp64 is the noise floor of ANY fp32 evaluation (BatchNorm
+    # divides by the batch deviation of every unit, a nearly dead unit amplifies rounding noise by 1/sqrt(var + 1e-8))
+    with torch.no_grad():
+        _, saved32 = R.forward({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise, keep=True)
+    d10_32 = torch.stack([s["d10"] for s in saved32])
+    floor_d10 = float((d10_32.double() - d10).abs().max() / d10.abs().max())
+    floor_dz = 0.0
+    for a in range(A):
+        z32 = d10_32[a] @ sd[f"fc11.{a}.weight"].t() + sd[f"fc11.{a}.bias"]
+        gz32 = am1 * (torch.relu(z32) - x) / B * (z32 > 0)
+        far = z11[a].abs() > MARGIN
+        floor_dz = max(floor_dz, float(((gz32.double() - gz11[a]).abs() * far).max() / gz11[a].abs().max()))
+        del z32, gz32, far
+    del saved32, d10_32
+    # --- one fused train step (no Adam) on the GPU from the same state
+    m = U.build_model(h, sd)
+    m.train()
+    m.set_explicit_noise(U.noise_to_device(noise))
+    xd = x.to(U.DEV)
+    buf = m.fused_train_step(xd.expand(A, -1, -1), 1.0, None, do_adam=False).clone()
+    torch.cuda.synchronize()
+    grads = {k: gv.detach().cpu().clone() for (k, _), gv in zip(m.named_parameters(), m._grad_views)}
+    eng = m._engine
+    ns = eng.splits()[4]
+    stage = {
+        "dz11": eng.ws_view("dz11", D).cpu(),
+        "gd10": eng.ws_raw("gd10_slab", ns * A * B * h.fc_dim).view(ns, A, B, h.fc_dim).cpu(),
+        "d10": eng.ws_view("d10", h.fc_dim).cpu(),
+    }
+    yield dict(A=A, B=B, D=D, h=h, sd=sd, lt_32=lt_32, lt_64=lt_64, g_32=g_32, g_64=g_64, buf=buf.cpu(), grads=grads,
+               stage=stage, z11=z11, x=x, floor_d10=floor_d10, floor_dz=floor_dz, gz11=gz11, gd=gd, d10=d10)
+    del m, eng
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_fused_step_against_oracle(case):
+    """Loss vector and every parameter gradient of the fused step against the fp64 oracle."""
+    c = case
+    A = c["A"]
+    from distributed_vae_amd import _native as N
+    lt = c["lt_64"]
+    lt = [v.detach() if torch.is_tensor(v) else v for v in lt]
+    want = [float(lt[0]), float(lt[2]), float(lt[3]), float(lt[4]), float(lt[5])]
+    want += [float(v) for v in lt[1]] + [float(v) for v in lt[6]] + [float(v) for v in lt[8]]
+    got = c["buf"].double().tolist()
+    tol = [LOSS_TOL, LOSS_TOL, 1e-4, LOSS_TOL, 1e-4] + [LOSS_TOL] * A + [1e-4] * A + [LOSS_TOL] * A
+    assert len(got) == N.LOSS_REC0 + 3 * A
+    for i, (g_, w_, t_) in enumerate(zip(got, want, tol)):
+        assert abs(g_ - w_) <= t_ * abs(w_) + 1e-7, (i, g_, w_)
+    p90 = lambda e: float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
+    for k, v in c["grads"].items():
+        ref = c["g_64"][k]
+        sc = float(ref.abs().max()) + 1e-30
+        e_gpu = ((v.double() - ref).abs() / sc).flatten()
+        e_cpu = ((c["g_32"][k].double() - ref).abs() / sc).flatten()
+        assert p90(e_gpu) < max(3.0 * p90(e_cpu), 1e-4), (k, p90(e_gpu), p90(e_cpu))
+        assert float(e_gpu.max()) < 5 * GRAD_TOL, (k, float(e_gpu.max()))
+        thr = max(GRAD_TOL / 4, 2.0 * float(e_cpu.max()))
+        assert int((e_gpu > thr).sum()) <= max(3, e_gpu.numel() // 100), (k, thr, float(e_gpu.max()))
+
+
+def test_dominant_kernel_outputs_against_oracle(case):
+    """k_fc11_zg's outputs element for element: dZ11 [A,B,D] and the summed d(d10) slabs [A,B,H]."""
+    c = case
+    A, B, D = c["A"], c["B"], c["D"]
+    st = c["stage"]
+    # the kernel's input first: a wrong d10 would show up as a wrong dZ11
+    sc = float(c["d10"].abs().max())
+    tol_d10 = max(STAGE_TOL, 4.0 * c["floor_d10"])
+    tol_dz = max(STAGE_TOL, 4.0 * c["floor_dz"])
+    assert tol_d10 < 2e-4 and tol_dz < 2e-4, (c["floor_d10"], c["floor_dz"])      # the floor itself stays small
+    e_d10 = float((st["d10"].double() - c["d10"]).abs().max()) / sc
+    assert e_d10 <= tol_d10, (e_d10, c["floor_d10"])
+    n_excl = 0
+    for a in range(A):
+        ref = c["gz11"][a]
+        sc = float(ref.abs().max())
+        err = (st["dz11"][a].double() - ref).abs()
+        near = c["z11"][a].abs() <= MARGIN               # decisions fp32 may take either way
+        n_excl += int(near.sum())
+        bad = (err > tol_dz * sc) & ~near
+        assert not bool(bad.any()), (a, int(bad.sum()), float(err[~near].max() / sc), c["floor_dz"])
+        # an excluded element is either right or on the other side of the ReLU (0 <-> coef (0 - x)): nothing else
+        flipped = near & (err > tol_dz * sc)
+        if bool(flipped.any()):
+            coef = max(A - 1, 1) / B
+            alt = torch.where(c["z11"][a] > 0, torch.zeros_like(ref), -coef * c["x"].double())
+            assert float((st["dz11"][a].double() - alt)[flipped].abs().max()) <= tol_dz * sc + MARGIN * coef
+    assert n_excl <= 2e-3 * A * B * D, n_excl            # measured: a few 1e-4 of the elements
+    # d(d10) = dZ11 W11: (1) the GEMM itself, exactly, on the dZ11 this engine produced; (2) against the oracle
+    got = st["gd10"].double().sum(0)                      # fixed-order sum of the gene-split slabs (decoder prologue)
+    for a in range(A):
+        w = c["sd"][f"fc11.{a}.weight"].double()
+        own = st["dz11"][a].double() @ w
+        sc = float(own.abs().max())
+        assert float((got[a] - own).abs().max()) <= STAGE_TOL * sc, a
+        e = ((got[a] - c["gd"][a]).abs() / float(c["gd"][a].abs().max())).flatten()
+        p90 = float(e.kthvalue(int(0.9 * e.numel())).values)
+        assert p90 <= tol_dz and float(e.max()) < 5 * GRAD_TOL, (a, p90, float(e.max()))
+
+
+def test_loss_rec_counts_every_threshold_decision(case):
+    """loss_rec = 0.5 sum (x_rec - x)^2 / B + 50 * mismatch fraction (nn_model.py:544-546): the mismatch count is an
+    integer over B * D decisions; a wrong count of n elements moves loss_rec by 50 n / (B D).  Bound: the number of
+    elements whose fp64 |x_rec - 0.1| is within fp32 rounding cannot explain more than a 1e-6 relative difference."""
+    c = case
+    A = c["A"]
+    rec_gpu = c["buf"][5:5 + A].double()
+    rec_ref = torch.as_tensor([float(v) for v in c["lt_64"][1]]).double()
+    assert float(((rec_gpu - rec_ref).abs() / rec_ref.abs()).max()) < 2e-6
+    assert math.isfinite(float(c["buf"][0]))

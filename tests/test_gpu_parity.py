@@ -471,7 +471,7 @@ def test_c_abi_error_codes():
     bad = N.Dims(2, 32, 64, 200, 5, 7, 2)               # fc_dim > 128
     assert L.mmvae_check_dims(C.byref(bad)) == -2
     assert b"unsupported" in L.mmvae_last_error_string()
-    assert L.mmvae_check_dims(C.byref(N.Dims(2, 1, 64, 16, 5, 7, 2))) == -1   # B < 2
+    assert L.mmvae_check_dims(C.byref(N.Dims(2, 0, 64, 16, 5, 7, 2))) == -1   # B < 1
     d = N.Dims(2, 32, 64, 16, 5, 7, 2)
     hy = N.Hyper(0.005, 1.0, 1.0, 1.0, 1e-8, 0.01, 0.5, 0.0, 0, 1, 0)
     nz = N.make_noise(None, 1, 1)
@@ -479,7 +479,7 @@ def test_c_abi_error_codes():
     x = torch.zeros(32, 64, device="cuda:0")
     p = torch.zeros(100000, device="cuda:0")
     rc = L.mmvae_forward(C.byref(d), C.byref(hy), C.byref(nz), p.data_ptr(), None, None, x.data_ptr(), 0, None, 0,
-                         ws.data_ptr(), ws.numel() * 4, None)
+                         ws.data_ptr(), ws.numel() * 4, None, None)
     assert rc == -4 and b"workspace" in L.mmvae_last_error_string()
     with pytest.raises(NotImplementedError):
         N.Engine(2, 32, 64, 200, 5, 7, 2, "cuda:0")
@@ -555,15 +555,14 @@ def test_full_size_properties(full):
     (3.0 * lt[0]).backward()
     for k, p in m3.named_parameters():
         assert G.rel_err(p.grad.cpu(), 3.0 * g1[k]) < 1e-6, k
-    # split factors change only the summation order
-    try:
-        for which, val in [(0, 3), (1, 5), (2, 7), (3, 9)]:
-            N.lib().mmvae_set_split(which, val)
-        m4 = U.build_model(h, sd); m4.train()
-        _, lt4, g4 = U.run_step(m4, xd, noise)
-    finally:
-        for which in range(4):
-            N.lib().mmvae_set_split(which, 0)
+    # split factors change only the summation order (they travel in the engine's mmvae_exec)
+    ex = N.exec_from_env()
+    for which, val in [(0, 3), (1, 5), (2, 7), (3, 9)]:
+        ex.split[which] = val
+    m4 = U.build_model(h, sd); m4.train()
+    m4._exec = ex
+    _, lt4, g4 = U.run_step(m4, xd, noise)
+    assert m4._engine.splits()[:4] == [3, 5, 7, 9]
     _loss_close(lt4[0], lt1[0], 1e-6)
     # summation-order noise only -- which, through ReLU decisions that sit within fp32 rounding of zero, shows up as a
     # few isolated elements: same two-part bound as test_full_size_against_oracle (typical element tight, worst loose)

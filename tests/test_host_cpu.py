@@ -24,7 +24,11 @@ def test_library_exports_every_declared_symbol():
     L = N.lib()
     for n in names:
         assert hasattr(L, n), n
-    assert L.mmvae_abi_version() == 1
+    assert L.mmvae_abi_version() == 2
+    # the library keeps no process-wide or per-thread knobs: no setters, and it reads no environment variables
+    assert not [n for n in names if n.startswith("mmvae_set_")]
+    blob = open(N.LIB_PATH, "rb").read()
+    assert b"getenv" not in blob and b"MMVAE_" not in blob
 
 
 def test_param_layout_matches_state_dict_shapes():
@@ -47,7 +51,15 @@ def test_param_layout_matches_state_dict_shapes():
     assert lay.per_arm >= total and lay.per_arm % 64 == 0
     # the state head is one [2S, L+C] matrix for the kernels
     assert lay.offset[13] == lay.offset[12] + 2 * 102 and lay.offset[15] == lay.offset[14] + 2
-    assert N.lib().mmvae_workspace_bytes(C.byref(d)) > 200e6
+    assert N.lib().mmvae_workspace_bytes(C.byref(d), None) > 200e6
+    # split factors travel in the caller's mmvae_exec and change the layout
+    ex = N.Exec()
+    base = (C.c_int32 * 6)()
+    assert N.lib().mmvae_splits(C.byref(d), C.byref(ex), C.byref(base)) == 0 and all(v >= 1 for v in base)
+    ex.split[2] = base[2] + 3
+    out = (C.c_int32 * 6)()
+    assert N.lib().mmvae_splits(C.byref(d), C.byref(ex), C.byref(out)) == 0 and out[2] == base[2] + 3
+    assert N.lib().mmvae_workspace_bytes(C.byref(d), C.byref(ex)) > N.lib().mmvae_workspace_bytes(C.byref(d), None)
 
 
 def test_constructor_matches_reference_initialisation():
@@ -168,11 +180,11 @@ def test_widened_entry_points_validate_arguments_on_the_host():
     assert L.mmvae_aug_packed_floats(C.byref(N.AugDims(2, 100, 5000, 1000, 1000, 200, 10, 50))) == 0     # n/5 > 128
     assert L.mmvae_aug_packed_floats(C.byref(N.AugDims(2, 100, 400, 80, 640, 128, 64, 128))) == 0        # LDS
     assert L.mmvae_aug_pack(C.byref(ok), None, None, None) == -1
-    assert L.mmvae_augment(C.byref(ok), None, None, 0, None, None, 0.1, None, 0, None, None, None) == -1
+    assert L.mmvae_augment(C.byref(ok), None, None, 0, None, None, 0.1, None, 0, None, None, None, None) == -1
     # data path
     assert L.mmvae_gather_rows(None, 8, 4, None, 2, 8, None, None) == -1
     # eval labels: needs eval mode
     d = N.Dims(2, 32, 64, 16, 4, 6, 2)
     h = N.Hyper(0.005, 1.0, 1.0, 1.0, 1e-8, 0.01, 0.5, 0.0, 0, 1, 0)     # training = 1
     one = (C.c_float * 4)()
-    assert L.mmvae_eval_classify(C.byref(d), C.byref(h), one, one, one, 0, one, 16, one, None, None) in (-2, -4)
+    assert L.mmvae_eval_classify(C.byref(d), C.byref(h), one, one, one, 0, one, 16, one, None, None, None) in (-2, -4)

@@ -14,8 +14,7 @@ x = (torch.rand(B, D, generator=g, device=dev) < 0.2).float() * torch.randn(B, D
 torch.manual_seed(546)
 m = mixVAE_model(input_dim=D, fc_dim=H, n_categories=Cc, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev, eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE").to(dev)
 m.train(); eng = m._ensure(B); hyper = m._hyper(1.0, False); noise = N.make_noise(None, 99, 1)
-L_ = N.lib(); L_.mmvae_ws_offset.restype = C.c_int64
-off = L_.mmvae_ws_offset(C.byref(eng.dims), 19)   # MMVAE_WS_DZ11
+off = int(N.lib().mmvae_ws_offset(C.byref(eng.dims), C.byref(eng.ex), 19))   # MMVAE_WS_DZ11
 print("dz11 offset", off)
 def dz():
     return eng.ws[off: off + A * B * D].view(A, B, D).clone()

@@ -15,8 +15,7 @@ m = mixVAE_model(input_dim=D, fc_dim=H, n_categories=Cc, state_dim=S, lowD_dim=L
 m.train(); eng = m._ensure(B); hyper = m._hyper(1.0, False); noise = N.make_noise(None, 99, 1)
 eng.forward(hyper, noise, m._flat, m._bn_flat, None, x, 0, None, True); eng.loss(hyper); eng.backward(hyper, noise, m._flat, x, 0, m._flat_grad)
 torch.cuda.synchronize()
-L_ = N.lib(); L_.mmvae_ws_debug_offset.restype = C.c_int64; L_.mmvae_ws_debug_offset.argtypes = [C.POINTER(N.Dims)]
-off = L_.mmvae_ws_debug_offset(C.byref(eng.dims))
+off = int(N.lib().mmvae_ws_debug_offset(C.byref(eng.dims), C.byref(eng.ex)))
 dbg = eng.ws[off: off + 64].view(torch.int64)
 names = ["weights to LDS + stats loads", "x_low, fcc, softmax 1", "softmax 2 + Gumbel", "stores + c statistics", "state head", "block reduction"]
 dbg.zero_(); torch.cuda.synchronize()

@@ -31,14 +31,16 @@ def timeit(eng, sid, hyper, noise, m, reps=10):
 which = {0: 0, 1: 1, 2: 2, 3: 3}
 for stage, split_id in which.items():
     for ks in [int(v) for v in (sys.argv[1:] or ["2", "3", "4", "5", "6", "8", "10", "12", "16"])]:
+        ex = N.exec_from_env()
         for w in range(4):
-            N.lib().mmvae_set_split(w, 0)
-        N.lib().mmvae_set_split(split_id, ks)
+            ex.split[w] = 0
+        ex.split[split_id] = ks
         torch.manual_seed(546)
         m = mixVAE_model(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0,
                          n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev,
                          eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE").to(dev)
         m.train()
+        m._exec = ex
         eng = m._ensure(B)
         hyper = m._hyper(1.0, False)
         noise = N.make_noise(None, 99, 1)

@@ -7,9 +7,6 @@ from distributed_vae_amd import _native as N
 from distributed_vae_amd.nn_model import mixVAE_model
 A, B, D, H, L, C, S = 2, 5000, 5000, 100, 10, 92, 2
 dev = torch.device("cuda", 0)
-for w in range(5):
-    v = os.environ.get(f"MMVAE_SPLIT{w}")
-    if v: N.lib().mmvae_set_split(w, int(v))
 g = torch.Generator(device=dev).manual_seed(1)
 x = (torch.rand(B, D, generator=g, device=dev) < 0.2).float() * torch.randn(B, D, generator=g, device=dev).abs() * 3
 torch.manual_seed(546)
