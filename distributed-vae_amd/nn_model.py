@@ -117,6 +117,7 @@ class mixVAE_model(nn.Module):
                                                     affine=False) for _ in range(n_arm)]))
         # engine state (created lazily on the parameters' device)
         self._engine: Optional[N.Engine] = None
+        self._engines = {}
         self._flat = self._flat_grad = self._bn_flat = self._nbt = None
         self._grad_views: List[torch.Tensor] = []
         self._layout = None
@@ -188,13 +189,23 @@ class mixVAE_model(nn.Module):
         self._grad_views = gv_sorted
         self._flat, self._flat_grad, self._bn_flat, self._nbt, self._layout = flat, grad, bn, nbt, lay
         self._engine = None
+        self._engines = {}
 
     def _ensure(self, B: int) -> N.Engine:
         if not self._is_packed():
             self._pack()
         if self._engine is None or self._engine.dims.B != B or self._engine.device != self._flat.device:
-            d = self._dims(B)
-            self._engine = N.Engine(d.A, d.B, d.D, d.H, d.L, d.C, d.S, self._flat.device, self._exec)
+            # a trainer alternates between a few batch sizes (training batch, evaluation chunks, their ragged tails):
+            # keep the last few engines (workspace + events each) instead of reallocating 0.5 GB per switch
+            key = (B, str(self._flat.device), id(self._exec))
+            eng = self._engines.pop(key, None)
+            if eng is None:
+                d = self._dims(B)
+                eng = N.Engine(d.A, d.B, d.D, d.H, d.L, d.C, d.S, self._flat.device, self._exec)
+            self._engines[key] = eng
+            while len(self._engines) > 3:
+                self._engines.pop(next(iter(self._engines)))
+            self._engine = eng
         return self._engine
 
     def flat_parameters(self) -> torch.Tensor:
@@ -208,17 +219,32 @@ class mixVAE_model(nn.Module):
             self._pack()
         return self._flat_grad
 
+    def bind_grads(self):
+        """Point every parameter's ``.grad`` at its view of the flat gradient buffer (what ``loss.backward()`` does on
+        the three-call path), so that a stock ``torch.optim`` optimizer can follow a fused step run with do_adam=False."""
+        if not self._is_packed():
+            self._pack()
+        for p, gv in zip(self.parameters(), self._grad_views):
+            p.grad = gv
+
     # ------------------------------------------------------------------ noise control
-    def set_explicit_noise(self, noise: Optional[dict]):
+    def set_explicit_noise(self, noise):
         """Parity hook: x_mask uint8 [A,B,D], u_gumbel [A,B,C], u_state [A,B,S], s_mask uint8 [A,B,S]
-        (device tensors) consumed by the next forward passes; None returns to in-kernel Philox."""
-        self._explicit_noise = noise
+        (device tensors) consumed by the next forward passes; None returns to in-kernel Philox.  A LIST of such
+        dicts is a schedule: every forward / fused step takes the next entry (running out raises), which is how a
+        recorded run of the reference trainer is replayed step by step."""
+        self._explicit_noise = list(noise) if isinstance(noise, (list, tuple)) else noise
 
     def _hyper(self, temp: float, eval_flag: bool) -> N.Hyper:
         return N.Hyper(self.tau, float(temp), self.beta, self.lam, self.eps, self.momentum, float(self.x_dp.p),
                        float(self.s_dp.p), int(bool(self.hard)), int(self.training), int(bool(eval_flag)))
 
     def _next_noise(self) -> N.Noise:
+        if isinstance(self._explicit_noise, list):
+            if not self._explicit_noise:
+                raise RuntimeError("explicit noise schedule exhausted")
+            self._noise_keep = self._explicit_noise.pop(0)      # keeps the tensors alive while the kernels read them
+            return N.make_noise(self._noise_keep)
         if self._explicit_noise is not None:
             return N.make_noise(self._explicit_noise)
         if self._noise_seed is None:
@@ -249,8 +275,13 @@ class mixVAE_model(nn.Module):
         assert self.varitional, "Non-variational not implemented"
         assert len(x) == self.n_arm
         if mask is not None:
-            raise NotImplementedError("category masks belong to the pruning phase, which the reference disables "
-                                      "(cpl_mixvae.py:1005-1008); not part of the HIP path")
+            # eval_model passes the indices of the categories whose fcc bias is non-zero (cpl_mixvae.py:1476-1478, :1524):
+            # for an unpruned model that is every category, which leaves forward unchanged (nn_model.py:332-337)
+            import numpy as _np
+            mk = _np.unique(_np.asarray(mask.detach().cpu() if isinstance(mask, torch.Tensor) else mask).astype(_np.int64))
+            if not (mk.size == self.n_categories and mk[0] == 0 and mk[-1] == self.n_categories - 1):
+                raise NotImplementedError("a category mask that removes categories belongs to the pruning phase, which "
+                                          "the reference disables (cpl_mixvae.py:1005-1008); not part of the HIP path")
         if self.ref_prior:
             raise NotImplementedError("ref_prior is rejected by the reference loss (nn_model.py:578)")
         xt, xs = self._prep_x(x)

@@ -190,3 +190,58 @@ def load_reference_augmenter():
         assert len(keep) == len(names), (path, names)
         exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
     return ns["Augmenter_smartseq"]
+
+
+_TRAINER = os.path.join(REFERENCE_ROOT, "mmidas", "cpl_mixvae.py")
+
+
+def load_reference_trainer(ref_nn=None) -> types.SimpleNamespace:
+    """The reference's own trainer class ``cpl_mixVAE`` (mmidas/cpl_mixvae.py:150-1650: ``__init__``, ``init_model``,
+    ``train``, ``eval_model``) compiled in memory from the reference file where it lies, bound to the reference model
+    (``load_reference_nn_model``) and the reference's consensus helpers.  The module does not import on this image
+    (py3.12-only ``def unwrap[T]`` at :104, ``torchvision`` / ``wandb`` absent): that one line is neutralised in
+    memory, only the class and the module's small helper functions are compiled, and the names its top level would
+    have imported are supplied here (``wandb`` is not needed: ``run=None`` or a stand-in logger).  Nothing is copied
+    into the repo."""
+    import ast
+    import pickle
+    import time as _time
+    from functools import reduce
+
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    import torch.nn.utils.prune as prune
+    import torch.optim as optim
+    from torch import nn
+    from torch.optim.optimizer import Optimizer
+    from torch.utils.data import DataLoader, TensorDataset
+    from tqdm import tqdm, trange
+    from typing import Any, Iterable, Literal, Mapping, Optional, Sequence
+
+    if ref_nn is None:
+        ref_nn = load_reference_nn_model()
+    with open(_TRAINER, "r") as fh:
+        src = fh.read()
+    a = "def unwrap[T](x: Optional[T]) -> T:"
+    if a not in src:
+        raise RuntimeError("reference cpl_mixvae.py changed; loader recipe no longer applies")
+    tree = ast.parse(src.replace(a, "def unwrap(x):"), filename=_TRAINER)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) or (isinstance(n, ast.ClassDef) and n.name == "cpl_mixVAE")]
+    # helpers of mmidas/_utils.py the trainer imports (:35-41 of the trainer)
+    with open(_UTILS, "r") as fh:
+        utree = ast.parse(fh.read(), filename=_UTILS)
+    ukeep = [n for n in utree.body if isinstance(n, ast.FunctionDef)
+             and n.name in ("to_np", "classify", "compute_confmat", "confmat_mean", "confmat_normalize")]
+    ns: Dict[str, Any] = dict(os=os, pickle=pickle, time=_time, reduce=reduce, plt=plt, np=np, torch=torch, th=torch,
+                              dist=dist, nn=nn, F=F, prune=prune, optim=optim, Optimizer=Optimizer, DataLoader=DataLoader,
+                              TensorDataset=TensorDataset, tqdm=tqdm, trange=trange, Optional=Optional, Literal=Literal,
+                              Sequence=Sequence, Iterable=Iterable, Any=Any, Mapping=Mapping, wandb=None,
+                              mixVAE_model=ref_nn.mixVAE_model, VAEConfig=ref_nn.VAEConfig)
+    exec(compile(ast.Module(body=ukeep, type_ignores=[]), _UTILS, "exec"), ns)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), _TRAINER, "exec"), ns)
+    return types.SimpleNamespace(cpl_mixVAE=ns["cpl_mixVAE"], nn_model=ref_nn, ns=ns)

@@ -119,7 +119,13 @@ def test_fused_step_against_oracle(case):
     assert len(got) == N.LOSS_REC0 + 3 * A
     for i, (g_, w_, t_) in enumerate(zip(got, want, tol)):
         assert abs(g_ - w_) <= t_ * abs(w_) + 1e-7, (i, g_, w_)
-    p90 = lambda e: float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
+    # "typical entry": the 90th percentile -- of a tensor large enough for one flipped decision not to reach it.  One flipped
+    # ReLU of a decoder unit (d6 has L = 10 units x 5000 cells; the fp32 paths differ by ~1e-5 in its input through the
+    # tau = 0.005 softmax) moves that unit's bias gradient and its row of the weight gradient (10 % of fc6.weight), so
+    # tensors under 1000 entries are judged by their median; all entries stay under the worst-entry bound below
+    def p90(e):
+        q = 0.9 if e.numel() >= 1000 else 0.5
+        return float(e.kthvalue(max(1, int(q * e.numel()))).values)
     for k, v in c["grads"].items():
         ref = c["g_64"][k]
         sc = float(ref.abs().max()) + 1e-30
