@@ -176,9 +176,19 @@ class cpl_mixVAE:
 
     # ---------------------------------------------------------------------------------------
     def _step(self, xs: torch.Tensor):
+        """zero_grad / forward / loss / backward / optimizer.step of cpl_mixvae.py:434-463 for one batch.  With the
+        trainer's own ``FusedAdam`` the update rides on the gradient reduction of the fused step; any other
+        ``torch.optim`` optimizer assigned to ``self.optimizer`` (the reference pattern ``cplMixVAE.optimizer =
+        optim.Adam(model.parameters())``, train.py:144-147) gets the gradients of the fused step through each
+        parameter's ``.grad`` and steps itself."""
         if D.is_dist():
             return D.dp_train_step(self.model, xs, self.temp, self.optimizer)
-        return self.model.fused_train_step(xs, self.temp, self.optimizer, do_adam=True)
+        if isinstance(self.optimizer, FusedAdam) and self.optimizer.model is self.model:
+            return self.model.fused_train_step(xs, self.temp, self.optimizer, do_adam=True)
+        buf = self.model.fused_train_step(xs, self.temp, None, do_adam=False)
+        self.model.bind_grads()
+        self.optimizer.step()
+        return buf
 
     def train_step(self, x: torch.Tensor):
         """One batch of cpl_mixvae.py:416-463 (x -> device, x.expand over arms, [augmenter,] zero_grad, forward,
@@ -256,8 +266,11 @@ class cpl_mixVAE:
 
     def train(self, train_loader, test_loader, n_epoch, n_epoch_p=0, c_p=0, c_onehot=0, min_con=0.5,
               max_prun_it=0, rank=None, run=None, ws=1, good_enuf_consensus=0.75):
-        """Training loop of cpl_mixvae.py:397-492 (+ validation loss :665-775 and the 10-epoch
-        checkpoint :777-788).  Pruning (:996-1444) is disabled upstream and not offered."""
+        """Training loop of cpl_mixvae.py:397-492, the per-epoch consensus on the training set (:563-657), the
+        validation block (:665-775), the 10-epoch checkpoint (:777-788) and the stop at ``good_enuf_consensus``
+        (:851-927: checkpoint ``cns_cpl_mixVAE_model_before_pruning_A{A}_...pth``, then ``break``).  Pruning
+        (:996-1444) is disabled upstream and not offered.  Returns the per-epoch history (the reference returns None and
+        hands the same numbers to its logger ``run``)."""
         A, Dm = self.n_arm, self.input_dim
         dev = self.device
         if not self.init:
@@ -267,32 +280,40 @@ class cpl_mixVAE:
         if D.is_dist():
             D.broadcast_flat(self.model.flat_parameters())
         hist = {"losses": [], "loss_joints": [], "loss_recs": [[] for _ in range(A)], "c_ents": [], "c_l2_dists": [],
-                "c_dists": [], "validation_loss": [], "validation_rec_loss": [], "consensus_train": [], "consensus_val": [],
-                "epoch_times": []}
+                "c_dists": [], "validation_loss": [], "validation_rec_loss": [], "consensus_train": [], "consensus_aug": [],
+                "consensus_val": [], "epoch_times": [], "stopped_at": None}
         self.current_time = time.strftime("%Y-%m-%d-%H-%M-%S")
-        for e in range(n_epoch):
+        # the reference classifies the training set batch by batch only when the TEST loader's batch size exceeds one,
+        # otherwise the whole ``train_loader.dataset.tensors`` (:567 / :617): every row, no shuffle consumed
+        whole_train = test_loader is not None and not ((getattr(test_loader, "batch_size", None) or 0) > 1)
+        from ._utils import confmat_counts, consensus_from_counts
+        E = n_epoch
+        for e in range(E):
             t0 = time.time()
             self.model.train()
             acc = torch.zeros(5 + 3 * A, dtype=torch.float32, device=dev)   # sums of the loss vector
+            counts_aug = confmat_counts(A, self.n_categories, dev)            # labels of the TRAINING forwards (:510-525)
             nb = 0
             for buf in self.epoch_steps(train_loader):
                 acc += buf                                                   # :469-475 without .item()
                 nb += 1
+                eng = self.model._engine
+                N.confmat_accumulate(N.classify(eng.ws_view("c", self.n_categories)), self.n_categories, counts_aug)
             red = torch.cat([acc, torch.tensor([float(nb)], device=dev)])
-            D.allreduce_sum_(red)                                            # :480-483 folded into one
-            red = red.cpu().numpy()
+            both = torch.stack([D.allreduce_sum_(red.clone()), red]).cpu().numpy()   # :480-483 folded into one
+            red, loc = both[0], both[1]
             nsteps = red[-1]
-            nws = D.dist.get_world_size() if D.is_dist() else 1
-            Bs = max(nb, 1)
-            hist["losses"].append(red[N.LOSS_TOTAL] / nsteps)                # :485
-            hist["loss_joints"].append(red[N.LOSS_JOINT] / nws / Bs)
-            hist["c_ents"].append(red[N.LOSS_CENT] / nws / Bs)
-            hist["c_l2_dists"].append(red[N.LOSS_CL2] / nws / Bs)
-            hist["c_dists"].append(red[N.LOSS_CDIST] / nsteps)
+            Bs = max(nb, 1)                                                  # len(train_loader) of this rank
+            hist["losses"].append(red[N.LOSS_TOTAL] / nsteps)                # :485 (all-reduced sum / all-reduced count)
+            hist["loss_joints"].append(loc[N.LOSS_JOINT] / Bs)               # :486-488: rank-local sums / len(loader)
+            hist["c_ents"].append(loc[N.LOSS_CENT] / Bs)
+            hist["c_l2_dists"].append(loc[N.LOSS_CL2] / Bs)
+            hist["c_dists"].append(red[N.LOSS_CDIST] / nsteps)               # :489
             for a in range(A):
                 hist["loss_recs"][a].append(red[N.LOSS_REC0 + a] / Dm / nsteps)   # :475, :491
+            hist["consensus_aug"].append(float(np.mean(consensus_from_counts(counts_aug).cpu().numpy())) if nb else float("nan"))
             # consensus between the arms on the training set (cpl_mixvae.py:563-657), on the device
-            cons = self.consensus(train_loader)
+            cons = self.consensus(train_loader, whole_set=whole_train)
             hist["consensus_train"].append(cons)
             # validation loss (cpl_mixvae.py:665-775): eval mode, no Gumbel noise, hard sample
             if test_loader is not None:
@@ -307,35 +328,49 @@ class cpl_mixVAE:
             if rank in (None, 0, dev) or not D.is_dist():
                 print(f"epoch {e} | loss: {hist['losses'][-1]:.2f} | rec: {hist['loss_recs'][0][-1]:.2f} | "
                       f"distance: {hist['c_dists'][-1]:.2f} | l2 distance: {hist['c_l2_dists'][-1]:.2f} | "
-                      f"val: {val:.2f} | time: {dt:.2f}", flush=True)
+                      f"aug-cns: {hist['consensus_aug'][-1]:.2f} | train-cns: {cons:.2f} | val: {val:.2f} | "
+                      f"time: {dt:.2f}", flush=True)
             if run:
                 run.log({"train/total-loss": hist["losses"][-1], "train/joint-loss": hist["loss_joints"][-1],
                          "train/negative-joint-entropy": hist["c_ents"][-1],
                          "train/simplex-distance": hist["c_dists"][-1], "train/l2-distance": hist["c_l2_dists"][-1],
-                         "train/time": dt, "train/consensus": cons, "val/total-loss": val_tot, "val/rec-loss": val,
-                         "val/consensus": val_cons})
+                         "train/time": dt, "train/consensus_aug": hist["consensus_aug"][-1],
+                         **{f"train/rec-loss{a}": hist["loss_recs"][a][-1] for a in range(A)}})
+                run.log({"train/consensus": cons})
+                run.log({"val/total-loss": val_tot, "val/rec-loss": val, "val/consensus": val_cons})
             if self.save and self.folder and (e > 0) and (e % 10 == 0):    # :777-788
                 os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
                 self.save_checkpoint(os.path.join(self.folder, "model", f"cpl_mixVAE_model_epoch_{e}.pth"))
-        if self.save and self.folder:
+            if cons >= good_enuf_consensus or e == E - 1:                   # :851-927 (a NaN consensus never stops)
+                if self.folder:
+                    os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
+                    self.save_checkpoint(os.path.join(
+                        self.folder, "model", f"cns_cpl_mixVAE_model_before_pruning_A{A}_{self.current_time}.pth"))
+                hist["stopped_at"] = e
+                break
+        if self.save and self.folder and n_epoch > 0:                       # :958-972
             os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
             self.save_checkpoint(os.path.join(self.folder, "model",
                                               f"cpl_mixVAE_model_before_pruning_A{A}_{self.current_time}.pth"))
         return hist
 
     @torch.no_grad()
-    def consensus(self, loader) -> float:
+    def consensus(self, loader, whole_set: Optional[bool] = None, chunk: Optional[int] = None) -> float:
         """Mean over arm pairs of ``confmat_mean(confmat_normalize(compute_confmat(labels_a, labels_b, C)))`` with
-        ``labels = classify(c)`` of the eval-mode forward over the whole loader (cpl_mixvae.py:563-657).  Labels,
-        counts and the normalisation stay on the device: one host read of A(A-1)/2 doubles per epoch.  Under data
-        parallelism every rank counts its own shard and the integer counts are summed (the reference, never run
-        distributed, would report rank-local values)."""
+        ``labels = classify(c)`` of the eval-mode forward (cpl_mixvae.py:563-657).  ``whole_set``: classify every row
+        of ``loader.dataset.tensors`` in its base order (what the reference does when the test loader's batch size is
+        one, :617) instead of walking the loader (:567; a shuffled drop_last loader would skip its tail rows and spend a
+        permutation); None decides from the loader's own batch size, as the validation block does.  Eval mode uses the
+        running statistics, so cells are independent and the whole set is processed in chunks of ``chunk`` rows
+        (default: the loader's batch size) with identical labels.  Labels, counts and the normalisation stay on the
+        device: one host read of A(A-1)/2 doubles per epoch.  Under data parallelism every rank counts its own shard and
+        the integer counts are summed (the reference, never run distributed, would report rank-local values)."""
         from ._utils import confmat_counts, consensus_from_counts
         was_training = self.model.training
         self.model.eval()
         counts = confmat_counts(self.n_arm, self.n_categories, self.device)
         seen = 0
-        for x in self._eval_batches(loader):
+        for x in self._eval_batches(loader, whole_set, chunk):
             x = x.to(self.device)
             if x.shape[0] < 1:
                 continue
@@ -349,12 +384,25 @@ class cpl_mixVAE:
         return float(np.mean(consensus_from_counts(counts).cpu().numpy()))   # np.mean(np.array(consensus)), :654
 
     @staticmethod
-    def _eval_batches(loader):
-        """The reference walks a loader batch by batch when ``loader.batch_size > 1`` and otherwise takes the whole set
+    def _eval_batches(loader, whole_set: Optional[bool] = None, chunk: Optional[int] = None):
+        """The reference walks a loader batch by batch when its ``batch_size > 1`` and otherwise takes the whole set
         as ONE batch from ``loader.dataset.tensors`` (cpl_mixvae.py:567-640, :670-760; the default test loader has
-        ``batch_size=1``).  Yields x tensors accordingly; ``len`` semantics stay the loader's."""
-        if getattr(loader, "batch_size", None) == 1 and hasattr(loader, "dataset") and hasattr(loader.dataset, "tensors"):
-            yield loader.dataset.tensors[0]
+        ``batch_size=1``).  Yields x tensors accordingly.  ``chunk``: rows per yielded piece of the whole set (only
+        for per-cell work such as the evaluation labels; None = one piece, as the loss needs)."""
+        has_set = hasattr(loader, "dataset") and hasattr(loader.dataset, "tensors")
+        if whole_set is None:
+            whole_set = getattr(loader, "batch_size", None) == 1 and has_set
+        if whole_set and has_set:
+            if chunk is None and getattr(loader, "batch_size", None) == 1:
+                yield loader.dataset.tensors[0]
+                return
+            step = int(chunk or getattr(loader, "batch_size", None) or 1)
+            if hasattr(loader, "row_chunks"):          # device-resident loader: gather piece by piece
+                yield from loader.row_chunks(step)
+                return
+            x = loader.dataset.tensors[0]
+            for i in range(0, x.shape[0], step):
+                yield x[i:i + step]
             return
         for batch in loader:
             yield batch[0] if isinstance(batch, (tuple, list)) else batch
@@ -394,3 +442,72 @@ class cpl_mixVAE:
             return val_rec
         cons = float(np.mean(consensus_from_counts(counts).cpu().numpy())) if seen and A > 1 else float("nan")
         return val_loss, val_rec, cons
+
+    @torch.no_grad()
+    def eval_model(self, dl, c_p=0, c_onehot=0):
+        """``cpl_mixVAE.eval_model`` (cpl_mixvae.py:1450-1619): eval-mode forward + loss over every batch ``(x, index)`` of
+        ``dl`` and the reference's dictionary -- same keys, shapes and dtypes (float64 numpy arrays, as ``np.zeros``
+        gives them): ``state_mu`` / ``state_var`` (s_mean, s_logvar) [A,N,S], ``state_cat`` (argmax c + 1) and
+        ``prob_cat`` (max c) [A,N], ``total_loss_rec`` / ``total_likelihood`` [A] (means over batches),
+        ``total_dist_z`` / ``total_dist_qz`` (mean simplex / l2 distance), ``mean_test_rec`` (zeros), ``predicted_label``
+        [A,N], ``data_indx`` [N], ``z_prob`` (c) and ``z_sample`` (c_smp) [A,N,C], ``x_low`` [A,N,L], ``recon_c``
+        (x_rec) [A,N,D], ``prune_indx`` (categories whose fcc bias is zero) and ``cnss`` (between-arm consensus of the
+        labels).  Forward, loss, labels, confusion counts and consensus run on the device; the per-batch outputs are
+        collected in device buffers and copied to the host once."""
+        if self.ref_prior:
+            raise NotImplementedError("ref_prior is rejected by the reference loss (nn_model.py:578)")
+        A, Cc, Dm, L, S = self.n_arm, self.n_categories, self.input_dim, self.lowD_dim, self.state_dim
+        n_rows = len(dl.dataset)
+        B = dl.batch_size
+        if B is None:
+            raise ValueError("error: expected non-None value")            # unwrap(dl.batch_size), cpl_mixvae.py:104-107
+        dev = self.device
+        was_training = self.model.training
+        self.model.eval()
+        bias = self.model.fcc[0].bias.detach().cpu().numpy()
+        pruning_mask = np.where(bias != 0.0)[0]
+        prune_indx = np.where(bias == 0.0)[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        x_recs, s_means = torch.zeros(A, n_rows, Dm, **f32), torch.zeros(A, n_rows, S, **f32)
+        s_logvars, cs = torch.zeros(A, n_rows, S, **f32), torch.zeros(A, n_rows, Cc, **f32)
+        c_smps, x_lows = torch.zeros(A, n_rows, Cc, **f32), torch.zeros(A, n_rows, L, **f32)
+        data_indx = torch.zeros(n_rows, dtype=torch.float64, device=dev)
+        loss_vecs = []
+        from ._utils import confmat_counts, consensus_from_counts
+        for i, (x, data_idx) in enumerate(dl):
+            n_fst, n_lst = i * B, min((i + 1) * B, n_rows)
+            x = x.to(dev)
+            xs = x.expand(A, -1, -1)                                      # xs = [x for _ in range(A)], :1519
+            out = self.model(xs, self.temp, prior_c=0.0, eval=True, mask=pruning_mask)
+            self.model.loss(out[0], out[1], out[2], xs, out[7], out[8], out[4], out[6], 0.0)
+            loss_vecs.append(self.model._engine.loss_buf.clone())         # the 9-tuple's scalars, still on the device
+            for dst, k in ((s_means, 7), (s_logvars, 8), (cs, 4), (c_smps, 6), (x_lows, 3), (x_recs, 0)):
+                dst[:, n_fst:n_lst] = torch.stack(list(out[k]))
+            data_indx[n_fst:n_lst] = torch.as_tensor(data_idx).to(dev).to(torch.int64).to(torch.float64)
+        labels = N.classify(cs)                                            # argmax c, first maximum (np.argmax), [A,N]
+        prob = cs.max(dim=-1).values
+        counts = N.confmat_accumulate(labels, Cc, confmat_counts(A, Cc, dev))
+        cnss = float(np.mean(consensus_from_counts(counts).cpu().numpy())) if A > 1 and n_rows else float("nan")
+        lv = torch.stack(loss_vecs).double().cpu().numpy() if loss_vecs else np.zeros((0, 5 + 3 * A))
+        self.model.train(was_training)
+        to64 = lambda t: t.double().cpu().numpy()
+        lab1 = to64(labels) + 1.0
+        return {
+            "state_mu": to64(s_means),
+            "state_var": to64(s_logvars),
+            "state_cat": lab1.copy(),
+            "prob_cat": to64(prob),
+            "total_loss_rec": lv[:, N.LOSS_REC0:N.LOSS_REC0 + A].mean(axis=0),
+            "total_likelihood": lv[:, N.LOSS_REC0 + 2 * A:N.LOSS_REC0 + 3 * A].mean(axis=0),
+            "total_dist_z": np.mean(lv[:, N.LOSS_CDIST]),
+            "total_dist_qz": np.mean(lv[:, N.LOSS_CL2]),
+            "mean_test_rec": np.zeros(A),
+            "predicted_label": lab1,
+            "data_indx": data_indx.cpu().numpy(),
+            "z_prob": to64(cs),
+            "z_sample": to64(c_smps),
+            "x_low": to64(x_lows),
+            "recon_c": to64(x_recs),
+            "prune_indx": prune_indx,
+            "cnss": cnss,
+        }

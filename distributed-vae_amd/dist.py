@@ -100,6 +100,8 @@ def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
         dist.all_reduce(flat, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
     else:
         allreduce_mean_(flat)
+    if not hasattr(optimizer, "_bind"):      # a stock torch.optim optimizer: it reads the gradients through p.grad
+        model.bind_grads()
     optimizer.step()
     return buf
 

@@ -303,13 +303,14 @@ class mixVAE_model(nn.Module):
         grab = lambda name, w: list(eng.ws_view(name, w).clone().unbind(0))
         out = (list(x_rec.unbind(0)), [], [], grab("x_low", L), grab("c", Cc), grab("s_smp", S), grab("c_smp", Cc),
                grab("s_mean", S), grab("s_logvar", S), grab("c_prob", Cc))
-        self._ctx["outs"] = out           # loss() checks that it is handed exactly these
+        self._ctx["outs"] = out           # loss() checks that it is handed exactly these, unmodified
+        self._ctx["versions"] = {i: [t._version for t in out[i]] for i in (0, 4, 6, 7, 8)}
         self._ctx["x_in"] = x if isinstance(x, torch.Tensor) else list(x)
         return out
 
     @staticmethod
-    def _same(given, kept) -> bool:
-        """Is ``given`` (a list of per-arm tensors, or one stacked tensor) the list ``forward`` returned?"""
+    def _same(given, kept, versions) -> bool:
+        """Is ``given`` (a list of per-arm tensors, or one stacked tensor) the list ``forward`` returned, unmodified?"""
         if isinstance(given, torch.Tensor):
             given = list(given.unbind(0)) if given.dim() == kept[0].dim() + 1 else [given]
         try:
@@ -317,9 +318,8 @@ class mixVAE_model(nn.Module):
         except TypeError:
             return False
         return len(given) == len(kept) and all(
-            isinstance(g, torch.Tensor) and (g is k or (g.data_ptr() == k.data_ptr() and g.shape == k.shape
-                                                         and g._version == k._version))
-            for g, k in zip(given, kept))
+            isinstance(g, torch.Tensor) and g.data_ptr() == k.data_ptr() and g.shape == k.shape and g._version == v
+            for g, k, v in zip(given, kept, versions))
 
     def loss(self, recon_x, p_x, r_x, x, mu, log_sigma, qc, c, prior_c=[]):
         """Same contract as nn_model.py:495-598; returns the reference's 9-tuple.
@@ -336,7 +336,7 @@ class mixVAE_model(nn.Module):
         kept = self._ctx["outs"]
         for name, given, idx in (("recon_x", recon_x, 0), ("mu", mu, 7), ("log_sigma", log_sigma, 8), ("qc", qc, 4),
                                  ("c", c, 6)):
-            if not self._same(given, kept[idx]):
+            if not self._same(given, kept[idx], self._ctx["versions"][idx]):
                 raise ValueError(f"loss(): `{name}` is not the unmodified output {idx} of the preceding forward(); the HIP "
                                  "engine evaluates the loss on the tensors its forward produced")
         x_in = self._ctx["x_in"]

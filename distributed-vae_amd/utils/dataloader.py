@@ -173,6 +173,13 @@ class DeviceLoader:
         self._pin_ev[k] = ev
         return dev
 
+    def row_chunks(self, rows: int):
+        """The loader's rows in base order (no shuffle, no sharding, nothing consumed), gathered ``rows`` at a time:
+        ``loader.dataset.tensors[0]`` piece by piece, for per-cell evaluation over sets too large to gather at once."""
+        n = int(self.index.numel())
+        for i in range(0, n, int(rows)):
+            yield N.gather_rows(self.data, self.index[i:i + int(rows)])
+
     def __iter__(self):
         order = self._upload(self.epoch_order()) if self.host_order else self.epoch_order_device()
         if self._auto_epoch is not None:

@@ -607,7 +607,7 @@ def test_trainer_loop_and_checkpoint(tmp_path):
     t = cpl_mixVAE(saving_folder=str(tmp_path), device=0)
     t.init_model(n_categories=12, state_dim=2, input_dim=Dm, fc_dim=32, lowD_dim=6, x_drop=0.5, s_drop=0.0,
                  lr=1e-3, n_arm=2, temp=1.0, tau=0.005)
-    hist = t.train(tr, te, n_epoch=12, n_epoch_p=0)
+    hist = t.train(tr, te, n_epoch=12, n_epoch_p=0, good_enuf_consensus=2.0)
     assert len(hist["losses"]) == 12 and np.all(np.isfinite(hist["losses"]))
     assert hist["losses"][-1] < hist["losses"][0]
     ck = tmp_path / "model" / "cpl_mixVAE_model_epoch_10.pth"

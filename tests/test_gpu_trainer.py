@@ -1,0 +1,258 @@
+"""-m gpu: the trainer surface (scope rows a13, a15, a16 and the boundary's ``cpl_mixVAE.train`` / ``eval_model``) against
+``tests/golden/epochs_a2.npz`` -- a recording of the reference's OWN ``cpl_mixVAE.train`` and ``eval_model``
+(mmidas/cpl_mixvae.py:323-1448, :1450-1619; ``oracle/gen_golden_epochs.py``): three epochs of three 32-cell batches with
+``torch.optim.Adam``, every random draw of every forward recorded in call order, the per-epoch numbers the reference hands
+to its logger, the final parameters and the dictionary ``eval_model`` returns.
+
+Tolerances (fp32, nine chained Adam steps; losses are ~5e10 because tau = 0.005): epoch means 1e-3 relative (first epoch
+2e-4), consensus values 0.02 absolute (a label at a near-tie may differ), parameters as the Adam trajectory test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "epochs_a2.npz")
+
+
+def _fixture():
+    g = np.load(GOLD)
+    A, B, D, H, L, C, S = (int(v) for v in g["cfg"])
+    return g, (A, B, D, H, L, C, S)
+
+
+def _noise(g, i, dev=DEV):
+    out = {}
+    for k in ("x_mask", "u_gumbel", "u_state", "s_mask"):
+        key = f"noise/{i}/{k}"
+        out[k] = torch.from_numpy(g[key]).to(dev).contiguous() if key in g.files else None
+    return out
+
+
+def _trainer(g, cfg, folder="", sd_prefix="sd0/", save=False):
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    A, B, D, H, L, C, S = cfg
+    t = cpl_mixVAE(saving_folder=folder, device=0, save_flag=save)
+    t.init_model(n_categories=C, state_dim=S, input_dim=D, fc_dim=H, lowD_dim=L, x_drop=0.5, s_drop=0.0,
+                 lr=float(g["lr"]), n_arm=A, temp=1.0, tau=0.005)
+    t.model.load_state_dict({k[len(sd_prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(sd_prefix)})
+    return t
+
+
+def _loaders(g, cfg):
+    from torch.utils.data import DataLoader, TensorDataset
+    B = cfg[1]
+    x_tr, x_te = torch.from_numpy(g["x_train"]), torch.from_numpy(g["x_test"])
+    tr = DataLoader(TensorDataset(x_tr, torch.arange(len(x_tr), dtype=torch.float32)), batch_size=B, shuffle=False, drop_last=True)
+    te = DataLoader(TensorDataset(x_te, torch.arange(len(x_te), dtype=torch.float32)), batch_size=1, shuffle=False)
+    x_all = torch.cat([x_tr, x_te])
+    al = DataLoader(TensorDataset(x_all, torch.arange(len(x_all), dtype=torch.float32)), batch_size=B, shuffle=False)
+    return tr, te, al
+
+
+def _train_schedule(g):
+    """The reference's forwards per epoch: 3 training steps, one eval forward of the whole training set (consensus: this
+    engine's label pass draws nothing that reaches c), one eval forward of the test set (validation loss: u_state)."""
+    n = int(g["n_train_calls"])
+    flags = g["call_training"][:n]
+    sched = []
+    for e in range(n // 5):
+        base = 5 * e
+        assert list(flags[base:base + 5]) == [1, 1, 1, 0, 0]
+        sched += [_noise(g, base + k) for k in (0, 1, 2, 4)]
+    return sched
+
+
+def _close(got, want, tol):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.all(np.abs(got - want) <= tol * np.abs(want) + 1e-12), (got, want)
+
+
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_epochs_match_the_reference_trainer(tmp_path, pipeline):
+    g, cfg = _fixture()
+    A = cfg[0]
+    t = _trainer(g, cfg, folder=str(tmp_path), save=True)
+    t.pipeline = pipeline
+    tr, te, _ = _loaders(g, cfg)
+    t.model.set_explicit_noise(_train_schedule(g))
+    E = int(g["n_epoch"])
+    hist = t.train(tr, te, n_epoch=E, n_epoch_p=0, good_enuf_consensus=2.0)
+    tol = np.array([2e-4] + [1e-3] * (E - 1))
+    for key, name in (("losses", "train/total-loss"), ("loss_joints", "train/joint-loss"), ("c_dists", "train/simplex-distance"),
+                      ("validation_loss", "val/total-loss"), ("validation_rec_loss", "val/rec-loss")):
+        _close(hist[key], g["epoch/" + name], tol)
+    for a in range(A):
+        _close(hist["loss_recs"][a], g[f"epoch/train/rec-loss{a}"], tol)
+    # entropy and l2 distance are O(1) sums of many terms of both signs: absolute tolerance
+    assert np.abs(np.array(hist["c_ents"]) - g["epoch/train/negative-joint-entropy"]).max() < 2e-3
+    assert np.abs(np.array(hist["c_l2_dists"]) - g["epoch/train/l2-distance"]).max() < 2e-3
+    for key, name in (("consensus_train", "train/consensus"), ("consensus_aug", "train/consensus_aug"), ("consensus_val", "val/consensus")):
+        assert np.abs(np.array(hist[key]) - g["epoch/" + name]).max() <= 0.02, (key, hist[key], g["epoch/" + name])
+    assert hist["stopped_at"] == E - 1 and not t.model._explicit_noise            # every recorded draw was consumed
+    # final parameters after 9 Adam steps (median tight, maximum loose: first steps move every parameter by ~lr)
+    sdT = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sdT/")}
+    for k, v in t.model.state_dict().items():
+        ref = sdT[k]
+        if ref.dtype.is_floating_point:
+            d = (v.cpu() - ref).abs()
+            assert float(d.median()) < 2e-5 and float(d.max()) < 2.1e-3, (k, float(d.median()), float(d.max()))
+        else:
+            assert torch.equal(v.cpu(), ref), k
+    # checkpoints the reference writes: the consensus one at the last epoch and the final one (cpl_mixvae.py:851-866, :958-972)
+    kinds = sorted({f.split("_A")[0] for f in os.listdir(tmp_path / "model") if f.endswith(".pth")})
+    assert kinds == sorted(str(s) for s in g["saved_kinds"]), kinds
+
+
+def test_eval_model_matches_the_reference():
+    g, cfg = _fixture()
+    A, B, D, H, L, C, S = cfg
+    t = _trainer(g, cfg, sd_prefix="sdT/")
+    _, _, al = _loaders(g, cfg)
+    n = int(g["n_train_calls"])
+    t.model.set_explicit_noise([_noise(g, i) for i in range(n, n + 4)])
+    out = t.eval_model(al)
+    ref = {k[len("eval_model/"):]: g[k] for k in g.files if k.startswith("eval_model/")}
+    assert sorted(out) == sorted(ref)
+    for k in ref:
+        assert np.asarray(out[k]).shape == ref[k].shape and np.asarray(out[k]).dtype == ref[k].dtype, k
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    for k in ("state_mu", "state_var", "x_low", "recon_c", "total_loss_rec", "total_likelihood", "total_dist_z", "total_dist_qz"):
+        assert rel(out[k], ref[k]) < 1e-4, (k, rel(out[k], ref[k]))
+    for k in ("z_prob", "z_sample", "prob_cat"):
+        assert np.abs(out[k] - ref[k]).max() < 1e-4, k
+    # labels: identical wherever the reference's own top-2 margin is not a rounding tie
+    top2 = np.sort(ref["z_prob"], axis=-1)[..., -2:]
+    sure = (top2[..., 1] - top2[..., 0]) > 1e-3
+    assert sure.mean() > 0.9
+    assert np.array_equal(out["predicted_label"][sure], ref["predicted_label"][sure])
+    assert np.array_equal(out["state_cat"][sure], ref["state_cat"][sure])
+    assert np.array_equal(out["data_indx"], ref["data_indx"]) and np.array_equal(out["prune_indx"], ref["prune_indx"])
+    assert np.array_equal(out["mean_test_rec"], ref["mean_test_rec"])
+    assert abs(out["cnss"] - float(ref["cnss"])) <= 0.02
+
+
+def test_training_stops_at_good_enough_consensus(tmp_path):
+    """cpl_mixvae.py:851-927: once the training-set consensus reaches ``good_enuf_consensus`` the trainer saves
+    ``cns_cpl_mixVAE_model_before_pruning_A{A}_...pth`` and leaves the epoch loop."""
+    g, cfg = _fixture()
+    t = _trainer(g, cfg, folder=str(tmp_path), save=False)
+    tr, te, _ = _loaders(g, cfg)
+    hist = t.train(tr, te, n_epoch=6, good_enuf_consensus=0.0)           # any consensus >= 0 stops after the first epoch
+    assert hist["stopped_at"] == 0 and len(hist["losses"]) == 1
+    files = os.listdir(tmp_path / "model")
+    assert len(files) == 1 and files[0].startswith("cns_cpl_mixVAE_model_before_pruning_A2_")   # save_flag False: no final one
+    ck = torch.load(tmp_path / "model" / files[0], map_location="cpu", weights_only=True)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict"}
+    t2 = _trainer(g, cfg, folder="", save=False)
+    hist2 = t2.train(tr, te, n_epoch=2, good_enuf_consensus=2.0)         # unreachable threshold: runs every epoch
+    assert hist2["stopped_at"] == 1 and len(hist2["losses"]) == 2
+
+
+@pytest.mark.parametrize("opt_kind", ["adam", "adamw"])
+def test_train_with_a_stock_torch_optimizer(opt_kind):
+    """The reference assigns its optimizer from outside (``cplMixVAE.optimizer = optim.Adam(model.parameters())``,
+    train.py:144-147): ``train()`` then runs the fused step without Adam and lets that optimizer step on the gradients."""
+    from distributed_vae_amd.cpl_mixvae import FusedAdam
+    g, cfg = _fixture()
+    tr, te, _ = _loaders(g, cfg)
+    res = []
+    for stock in (False, True):
+        t = _trainer(g, cfg)
+        if opt_kind == "adam":
+            t.optimizer = torch.optim.Adam(t.model.parameters(), lr=1e-3) if stock else FusedAdam(t.model, lr=1e-3)
+        else:
+            t.optimizer = (torch.optim.AdamW(t.model.parameters(), lr=1e-3, weight_decay=0.01) if stock
+                           else FusedAdam(t.model, lr=1e-3, weight_decay=0.01, decoupled=True))
+        t.model.set_explicit_noise(_train_schedule(g)[:4])
+        hist = t.train(tr, te, n_epoch=1, good_enuf_consensus=2.0)
+        res.append((hist["losses"][0], {k: v.detach().cpu().clone() for k, v in t.model.state_dict().items()}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0])
+    moved = 0.0
+    for k, v in res[0][1].items():
+        if v.dtype.is_floating_point:
+            assert float((v - res[1][1][k]).abs().max()) < 2e-6, k
+            moved = max(moved, float((v - torch.from_numpy(g["sd0/" + k])).abs().max()))
+    assert moved > 1e-3                                                    # the optimizer did step
+
+
+def test_loss_rejects_tensors_that_are_not_the_forward_outputs():
+    import distributed_vae_amd  # noqa: F401
+    from tests import gpu_util as U
+    h = R.Hyper(input_dim=64, fc_dim=16, n_categories=7, state_dim=2, lowD_dim=5, n_arm=2)
+    m = U.build_model(h, R.init_state_dict(h, 3))
+    m.train()
+    x = R.synthetic_batch(32, 64).to(DEV)
+    xs = x.expand(2, -1, -1)
+    out = m(xs, 1.0, 0.0)
+    ok = m.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)
+    assert torch.isfinite(ok[0])
+    with pytest.raises(ValueError):
+        m.loss([t.clone() for t in out[0]], [], [], xs, out[7], out[8], out[4], out[6], 0.0)      # copies, not the outputs
+    with pytest.raises(ValueError):
+        m.loss(out[0], [], [], xs, out[8], out[7], out[4], out[6], 0.0)                            # mu / log_sigma swapped
+    with pytest.raises(ValueError):
+        m.loss(out[0], [], [], (x + 1).expand(2, -1, -1), out[7], out[8], out[4], out[6], 0.0)     # another x
+    out[4][0].mul_(2.0)                                                                            # modified in place
+    with pytest.raises(ValueError):
+        m.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)
+
+
+def test_consensus_counts_every_row_including_a_tail_of_one():
+    """A non-drop_last loader whose last batch holds ONE cell (N % batch_size == 1): eval mode classifies it (running
+    statistics need no batch); whole_set=True classifies the rows of ``dataset.tensors`` without consuming a shuffle."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    from distributed_vae_amd._utils import confmat_counts, consensus_from_counts
+    from torch.utils.data import DataLoader, TensorDataset
+    torch.manual_seed(5)
+    N_, Dm, Cc = 65, 48, 6
+    t = cpl_mixVAE(saving_folder="", device=0, save_flag=False)
+    t.init_model(n_categories=Cc, state_dim=2, input_dim=Dm, fc_dim=16, lowD_dim=4, n_arm=3)
+    x = R.synthetic_batch(N_, Dm)
+    ds = TensorDataset(x, torch.arange(N_, dtype=torch.float32))
+    ragged = DataLoader(ds, batch_size=16, shuffle=False)                  # 16 16 16 16 1
+    c_loader = t.consensus(ragged)
+    c_whole = t.consensus(DataLoader(ds, batch_size=16, shuffle=True, drop_last=True), whole_set=True)
+    t.model.eval()
+    counts = confmat_counts(3, Cc, DEV)
+    t.model.eval_labels(x.to(DEV).expand(3, -1, -1), 1.0, counts)          # all 65 rows as one batch
+    want = float(np.mean(consensus_from_counts(counts).cpu().numpy()))
+    assert int(counts.sum()) == 3 * N_                                     # three arm pairs, every row counted once
+    assert c_loader == want and c_whole == want
+
+
+def test_two_engines_in_one_thread_share_nothing():
+    """Two models stepped alternately on one host thread give exactly what each gives alone: the execution context
+    (side stream events, split factors) is per engine, not per thread or per process."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd import _native as N
+    from tests import gpu_util as U
+    hs = [R.Hyper(input_dim=256, fc_dim=100, n_categories=12, state_dim=2, lowD_dim=6, n_arm=2),
+          R.Hyper(input_dim=512, fc_dim=100, n_categories=9, state_dim=2, lowD_dim=5, n_arm=3)]
+    xs = [R.synthetic_batch(192, h.input_dim, seed=i).to(DEV) for i, h in enumerate(hs)]
+
+    def run(interleaved):
+        ms = [U.build_model(h, R.init_state_dict(h, 11 + i)) for i, h in enumerate(hs)]
+        for m in ms:
+            m.train()
+            m._noise_seed = 99
+        outs = [[], []]
+        order = [0, 1, 0, 1, 0, 1] if interleaved else [0, 0, 0, 1, 1, 1]
+        for i in order:
+            buf = ms[i].fused_train_step(xs[i].expand(hs[i].n_arm, -1, -1), 1.0, None, do_adam=False)
+            outs[i].append((buf.clone(), ms[i]._flat_grad.clone()))
+        torch.cuda.synchronize()
+        assert ms[0]._engine.ex.ev[0] != ms[1]._engine.ex.ev[0]            # their own events
+        return outs
+
+    a, b = run(True), run(False)
+    for i in range(2):
+        for (l1, g1), (l2, g2) in zip(a[i], b[i]):
+            assert torch.equal(l1, l2) and torch.equal(g1, g2)

@@ -147,3 +147,41 @@ def test_single_arm_raises_like_reference():
     out = R.forward(sd, [x], h, R.draw_noise(h, 8, 3))
     with pytest.raises(ZeroDivisionError):
         R.loss(out, [x], h)
+
+
+def test_oracle_replays_the_reference_trainer_epochs():
+    """tests/golden/epochs_a2.npz is a recording of the reference's own ``cpl_mixVAE.train`` (oracle/gen_golden_epochs.py):
+    the oracle's train step + Adam, driven with the recorded noise, reproduces the per-epoch means the reference logged
+    (cpl_mixvae.py:469-492), its validation numbers (:741-764) and the final parameters."""
+    import os
+    g = np.load(os.path.join(G.GOLDEN, "epochs_a2.npz"))
+    A, B, D, H, L, C, S = (int(v) for v in g["cfg"])
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, n_arm=A)
+    sd = {k[4:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("sd0/")}
+    x_tr, x_te = torch.from_numpy(g["x_train"]), torch.from_numpy(g["x_test"])
+
+    def noise(i):
+        return {k: ([torch.from_numpy(a) for a in g[f"noise/{i}/{k}"]] if f"noise/{i}/{k}" in g.files else [])
+                for k in ("x_mask", "u_gumbel", "u_state", "s_mask")}
+    opt = None
+    for e in range(int(g["n_epoch"])):
+        base = 5 * e
+        batches = [x_tr[i * B:(i + 1) * B] for i in range(3)]
+        hist, opt = R.train_steps(sd, batches, h, [noise(base + k) for k in range(3)], lr=float(g["lr"]), opt_state=opt)
+        tot = np.float32(0)
+        for lt in hist:
+            tot = np.float32(tot + np.float32(float(lt[0])))
+        tol = 1e-5 if e == 0 else 2e-4
+        assert abs(float(tot) / 3 - g["epoch/train/total-loss"][e]) <= tol * abs(g["epoch/train/total-loss"][e])
+        for a in range(A):
+            rec = sum(float(lt[1][a]) / D for lt in hist) / 3
+            assert abs(rec - g[f"epoch/train/rec-loss{a}"][e]) <= tol * abs(rec)
+        with torch.no_grad():
+            out = R.forward(sd, [x_te] * A, h, noise(base + 4), training=False, eval_flag=True, update_running=False)
+            lt = R.loss(out, [x_te] * A, h)
+        assert abs(float(lt[0]) / len(x_te) - g["epoch/val/total-loss"][e]) <= tol * abs(g["epoch/val/total-loss"][e])
+        val_rec = sum(float(v) / D for v in lt[1]) / len(x_te) / A
+        assert abs(val_rec - g["epoch/val/rec-loss"][e]) <= tol * abs(val_rec)
+    for k in R.param_keys(h):
+        d = (sd[k] - torch.from_numpy(g["sdT/" + k])).abs()
+        assert float(d.median()) < 1e-5 and float(d.max()) < 2.1e-3, k
