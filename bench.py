@@ -5,7 +5,11 @@ Workload (BASELINE.json configs[1], SURVEY.md section 8d "synthetic-10x-v1"): A=
 B=5000 cells x D=5000 genes, H=100, L=10, C=92, S=2, fp32, x_drop=0.5, in-kernel Philox noise, the batch
 already resident in HBM.  A "step" = one batch through mmvae_train_step (cpl_mixvae.py:434-463).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 either runs under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE) or -- when those are
+absent -- starts its own N rank processes (one per GPU, before this process has touched any GPU; the reference does the
+same with mp.spawn, train.py:286) and exits with their status.  Fewer than N visible devices: non-zero exit.
 
 N>1 is plain data parallelism: each rank trains on its own shard of cells, ONE RCCL all-reduce
 (average) of the flat gradient buffer per step, Adam on every rank ("weak" scaling: per-GPU batch fixed).
@@ -59,7 +63,10 @@ def synthetic_rows(n, d, seed, device):
 
 
 def cpu_baseline(args, D, H, L, C, S, A, B):
-    """The oracle timed on the host cores (rank 0, N=1 only); bounded to ~10-30 s."""
+    """The oracle timed on the host cores (rank 0, N=1 only), bounded to ~10-30 s, in the two variants BASELINE.md section 3
+    asks for: "faithful" -- every step draws its dropout keep-masks with ``bernoulli_`` (what ``nn.Dropout`` does inside
+    the reference's forward, nn_model.py:264; 62 % of the reference's CPU step) and its uniforms with ``rand`` -- and
+    "masks precomputed" -- the same step with the noise drawn outside the timed region."""
     from oracle import restatement as R
 
     cores = os.cpu_count() or 1
@@ -72,26 +79,67 @@ def cpu_baseline(args, D, H, L, C, S, A, B):
     cores = min(cores, args.cpu_threads)
     torch.set_num_threads(cores)
     h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, n_arm=A)
-    sd = R.init_state_dict(h, 546)
     x = R.synthetic_batch(B, D)
-    nsteps = args.cpu_steps
-    times = []
-    st = None
-    for s in range(nsteps + 1):
-        t0 = time.time()
-        noise = R.draw_noise(h, B, seed=100 + s)          # dropout mask generation is part of the
-        _, st = R.train_steps(sd, [x], h, [noise], lr=1e-3, opt_state=st)   # reference's step (bernoulli_)
-        dt = time.time() - t0
-        if s > 0:
-            times.append(dt)
-        if sum(times) > 25.0:
-            break
-    times.sort()
-    med = times[len(times) // 2]
+
+    def draw():
+        # the reference's consumption order per arm: bernoulli_[B,D] -> rand[B,C] -> rand_like[B,S]
+        nz = {"x_mask": [], "u_gumbel": [], "u_state": [], "s_mask": []}
+        for _ in range(A):
+            nz["x_mask"].append(torch.empty(B, D).bernoulli_(1.0 - h.x_drop).to(torch.uint8))
+            nz["u_gumbel"].append(torch.rand(B, C))
+            nz["u_state"].append(torch.rand(B, S))
+        return nz
+
+    def run(faithful, budget_s):
+        sd = R.init_state_dict(h, 546)
+        st = None
+        times = []
+        fixed = draw()
+        for s in range(args.cpu_steps + 1):
+            t0 = time.time()
+            noise = draw() if faithful else fixed
+            _, st = R.train_steps(sd, [x], h, [noise], lr=1e-3, opt_state=st)
+            dt = time.time() - t0
+            if s > 0:
+                times.append(dt)
+            if sum(times) > budget_s:
+                break
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    med, n = run(True, 14.0)
+    med_pre, n_pre = run(False, 10.0)
     return {"value": B / med, "unit": "cells/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} full steps of the same workload (A={A}, B={B}, D={D}) after 1 warm-up, median; "
-                      f"includes drawing the dropout masks on the host as the reference does",
-            "ms_per_step": med * 1e3}
+            "sample": f"{n} full steps of the same workload (A={A}, B={B}, D={D}) after 1 warm-up, median; faithful variant: "
+                      f"the dropout masks are drawn with bernoulli_ inside every step, as the reference's nn.Dropout does",
+            "ms_per_step": med * 1e3,
+            "masks_precomputed": {"value": B / med_pre, "unit": "cells/s", "ms_per_step": med_pre * 1e3,
+                                  "sample": f"{n_pre} steps, median; noise drawn once outside the timed region"}}
+
+
+def spawn_ranks(n: int, share_gpu: bool = False) -> int:
+    """--gpus N without a launcher: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment) and wait for them.  This process has not initialised the GPU (counting devices does not), and it never
+    replaces itself: the ranks are children.  Returns the exit status to leave with."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not (share_gpu and have >= 1):
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible: refusing to run the {n}-GPU job on fewer devices",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main():
@@ -108,21 +156,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a box with fewer GPUs: every rank uses cuda:0 and the collectives "
+                         "go through gloo (RCCL refuses two ranks on one device); the line is marked as a rehearsal")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="one rank, but through the data-parallel step (RCCL init, all-reduce(AVG) of the flat gradients, "
                          "separate Adam launch): exercises the N > 1 code path on a one-GPU box")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, args.share_gpu))   # no launcher: be one (before any GPU call in this process)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.share_gpu:
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = None
     if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -131,10 +189,16 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            warm = torch.zeros(8, device=dev)
-            dist.all_reduce(warm)
+            if args.share_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.ones(8, device=dev)
+            dist.all_reduce(warm)                      # a real collective: every rank contributes 1
             torch.cuda.synchronize()
+            rccl_ranks = int(round(float(warm[0])))
+            if rccl_ranks != dist.get_world_size() or rccl_ranks != world:
+                raise SystemExit(f"RCCL all-reduce saw {rccl_ranks} ranks, expected {world}")
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
@@ -173,9 +237,15 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step HIP events on the stream the step is launched on (torch's current stream): the median step period beside
+    # the wall-clock mean that `value` is computed from
+    stream = torch.cuda.current_stream(dev)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    evs[0].record(stream)
     for i in range(args.steps):
         buf = step(args.warmup + i)
+        evs[i + 1].record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -186,6 +256,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     loss_last = float(buf[0])
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    ev_stats = {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
+                "p10": per_step[len(per_step) // 10], "p90": per_step[(9 * len(per_step)) // 10], "n": len(per_step)}
 
     P = 0
     lay = N.param_layout(N.Dims(A, B, D, H, L, C, S))
@@ -212,8 +285,11 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_hip_events": ev_stats,
+        "value_at_median_step": world * B / ev_stats["median"] * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
+        **({"rehearsal": "ranks share one GPU, gloo collectives: NOT a multi-GPU measurement"} if args.share_gpu else {}),
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -222,6 +298,8 @@ def main():
                    "global_batch": world * B, "parallelism": f"dp{world}", "noise": "in-kernel Philox4x32-10",
                    "flop_per_cell": fl_cell, "bytes_per_cell": by_cell, "last_loss": loss_last},
     }
+    if rccl_ranks is not None:
+        out["rccl_ranks"] = rccl_ranks
     if roof is not None:
         out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

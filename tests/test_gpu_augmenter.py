@@ -215,7 +215,10 @@ def test_trainer_train_loop_with_augmenter_loaders_consensus_and_validation(tmp_
     for key in ("losses", "validation_loss", "validation_rec_loss", "consensus_train", "consensus_val"):
         assert len(hist[key]) == 3 and np.isfinite(hist[key]).all(), key
     assert all(0.0 <= v <= 1.0 for v in hist["consensus_train"] + hist["consensus_val"])
-    assert hist["losses"][-1] < hist["losses"][0]                    # it learns
+    # (no "the loss went down" check: the total is dominated by the coupling distance, ~1e10 with tau = 0.005, whose
+    # batch-to-batch spread exceeds what twelve Adam steps move -- the reference's own recorded run, epochs_a2, goes
+    # 5.3e10 -> 5.9e10 -> 5.5e10; the trajectory itself is pinned by tests/test_gpu_trainer.py)
+    assert hist["stopped_at"] == 2 and len(hist["consensus_aug"]) == 3
     ckpts = [f for f in os.listdir(os.path.join(str(tmp_path), "model")) if f.endswith(".pth")]
     assert ckpts
     t2 = cpl_mixVAE(saving_folder=str(tmp_path), device=DEV, save_flag=False)

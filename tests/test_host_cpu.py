@@ -188,3 +188,14 @@ def test_widened_entry_points_validate_arguments_on_the_host():
     h = N.Hyper(0.005, 1.0, 1.0, 1.0, 1e-8, 0.01, 0.5, 0.0, 0, 1, 0)     # training = 1
     one = (C.c_float * 4)()
     assert L.mmvae_eval_classify(C.byref(d), C.byref(h), one, one, one, 0, one, 16, one, None, None, None) in (-2, -4)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """``python bench.py --gpus N`` without a launcher starts its own ranks; with fewer than N devices it must fail
+    loudly instead of running the job on fewer GPUs and printing ``n_gpus: 1``."""
+    import subprocess
+    import sys
+    n = torch.cuda.device_count() + 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True,
+                       timeout=300, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
