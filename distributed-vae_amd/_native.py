@@ -79,7 +79,7 @@ TUNE_ENV = {
     "MMVAE_AUG_TILE": (3, int), "MMVAE_ABLATE_C": (4, int), "MMVAE_ABLATE": (5, int), "MMVAE_PADLDS": (6, int),
     "MMVAE_FC1_V2": (7, int), "MMVAE_FC11_ZG": (8, lambda v: int(int(v) == 0)), "MMVAE_ABLATE_Z": (9, int),
     "MMVAE_FC11_NSZ": (10, int), "MMVAE_GD10_V2": (11, int), "MMVAE_DW1_V2": (12, int), "MMVAE_DW11_V2": (13, int),
-    "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_TICKET": (16, lambda v: int(int(v) == 0)),
+    "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int),
 }
 
 

@@ -147,7 +147,6 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.small_slab = take((int64_t)L.sp.ks_small * A * N_SMALL * NP * SMALL_LD);
     L.xbits = take(A * B * cdiv(d.D, 32));
     L.loss_scratch = take(4096);
-    L.tickets = take(TICK_SLOTS * MMVAE_MAX_ARMS);
     L.total = off;
     return L;
 }

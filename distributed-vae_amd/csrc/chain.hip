@@ -49,11 +49,6 @@ struct ChainFwdArgs {
     int bn_idx;
     float bn_eps, bn_momentum;
     int64_t stats_part_off;             // [A][gridDim.x][2][N_last] or -1
-    // >= 0: the last workgroup to finish combines those partials into the OUTPUT's BatchNorm statistics (ws offsets
-    // [A][N_last]) and updates that BatchNorm's running buffers; the next launch reads them instead of the partials
-    int64_t tick_off, fin_mean_off, fin_rstd_off;
-    int64_t orun_mean_off, orun_var_off;   // inside bn_running (arm stride run_arm_stride)
-    int obn_idx;
     int B, ld, wrows;
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
@@ -152,21 +147,9 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     };
     if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 
-    // ---- the first layer's weights are requested before anything else: they land while the input tile is
-    //      loaded and normalised (one memory round trip in front of the first GEMM instead of three in a row)
-    float4 wq[WQ_N];
-    bool wq_valid = false;
-    {
-        const FwdLayer L0 = a.L[0];
-        wq_valid = w_split_ok(P + L0.w_off, L0.K, rup(L0.N, 32), rup(L0.K, 8));
-        if (wq_valid) w_load(wq, P + L0.w_off, L0.N, L0.K);
-    }
-    // ---- statistics of the input's BatchNorm: final values left in the workspace by the producer's last workgroup
-    //      (training) or by launch_bn_eval_stats (eval); with MMVAE_TUNE_TICKET_OFF recombined here from the
-    //      producer's partials.  Zero beyond K0.
-    const bool bn_in = a.bn_mean_off >= 0;
-    const bool bn_direct = bn_in && a.bn_part_off < 0 && (a.K0 & 3) == 0;   // each thread loads its own columns' values
-    if (bn_in && !bn_direct) {
+    // ---- statistics of the input's BatchNorm: recombined from the producer's partials (training) or
+    //      the running buffers' values left in the workspace (eval); zero beyond K0
+    if (a.bn_mean_off >= 0) {
         const int K0 = a.K0;
         float mean = 0.f, rstd = 0.f;
         if (a.bn_part_off >= 0) {
@@ -200,32 +183,25 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     // ---- input tile (optionally BatchNorm-normalised), zero padded to a multiple of 8 columns
     {
         const float* X = ws + a.x_off + (int64_t)arm * B * a.K0;
-        const float* MU = bn_direct ? ws + a.bn_mean_off + (int64_t)arm * a.K0 : X;
-        const float* RS = bn_direct ? ws + a.bn_rstd_off + (int64_t)arm * a.K0 : X;
+        const bool bn = a.bn_mean_off >= 0;
         const int c4n = rup(a.K0, 8) >> 2;
         const bool vec = (a.K0 & 3) == 0;    // workspace regions are 256-B aligned, widths multiples of 4
         const int part = tid & 7, row = tid >> 3;      // 128 rows x 8 sixteen-byte parts
         auto stage_x = [&](auto tag) __attribute__((always_inline)) {
             constexpr bool V = decltype(tag)::value;
             for (int cb = 0; cb < c4n; cb += 32) {
-                float4 v[4], mq[4], rq[4];
+                float4 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = (cb + part + 8 * j) * 4;
-                    v[j] = ldg4_t<V>(X, a.K0, b0 + row, col, B, a.K0);
-                    // statistics of this thread's four columns (zero beyond K0): same round trip as the tile
-                    mq[j] = bn_direct ? ldg4_t<true>(MU, 0, 0, col, 1, a.K0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    rq[j] = bn_direct ? ldg4_t<true>(RS, 0, 0, col, 1, a.K0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int j = 0; j < 4; ++j) v[j] = ldg4_t<V>(X, a.K0, b0 + row, (cb + part + 8 * j) * 4, B, a.K0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = cb + part + 8 * j;
                     float4 o = v[j];
-                    if (bn_in) {   // padded columns: (0 - 0) * 0 = 0; rows past the batch must stay zero
+                    if (bn) {   // padded columns: (0 - 0) * 0 = 0; rows past the batch must stay zero
                         const bool rok = b0 + row < B;
                         const int cc = min(c, 31) * 4;   // BatchNorm widths are <= 128
-                        const float4 m4 = bn_direct ? mq[j] : *reinterpret_cast<const float4*>(&mean_s[cc]);
-                        const float4 r4 = bn_direct ? rq[j] : *reinterpret_cast<const float4*>(&rstd_s[cc]);
+                        const float4 m4 = *reinterpret_cast<const float4*>(&mean_s[cc]);
+                        const float4 r4 = *reinterpret_cast<const float4*>(&rstd_s[cc]);
                         o.x = rok ? (o.x - m4.x) * r4.x : 0.f;
                         o.y = rok ? (o.y - m4.y) * r4.y : 0.f;
                         o.z = rok ? (o.z - m4.z) * r4.z : 0.f;
@@ -239,6 +215,8 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         else stage_x(ScalarTag{});
     }
     stamp(0);
+    float4 wq[WQ_N];
+    bool wq_valid = false;
     for (int l = 0; l < a.nlayers; ++l) {
         const FwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
@@ -325,28 +303,6 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         stamp(4);
         lds_barrier();
         stamp(2);
-    }
-    if (a.stats_part_off >= 0 && a.tick_off >= 0) {
-        // the last workgroup of this arm combines every workgroup's (mean, M2) into the output's BatchNorm statistics
-        __shared__ unsigned tick_flag;
-        unsigned* counter = reinterpret_cast<unsigned*>(ws + a.tick_off) + arm;
-        if (ticket_is_last(counter, gridDim.x, &tick_flag)) {
-            const int N = a.L[a.nlayers - 1].N;
-            float mean, m2;
-            stats_from_partials<CH_NT>(ws + a.stats_part_off + (int64_t)arm * gridDim.x * 2 * N, gridDim.x, B, CHAIN_ROWS, N,
-                                       Ws, mean, m2);
-            if (tid < N) {
-                ws[a.fin_mean_off + (int64_t)arm * N + tid] = mean;
-                ws[a.fin_rstd_off + (int64_t)arm * N + tid] = 1.0f / sqrtf(m2 / (float)B + a.bn_eps);
-                if (bn_running) {
-                    float* rm = bn_running + a.orun_mean_off + arm * a.run_arm_stride;
-                    float* rv = bn_running + a.orun_var_off + arm * a.run_arm_stride;
-                    rm[tid] = (1.f - a.bn_momentum) * rm[tid] + a.bn_momentum * mean;
-                    rv[tid] = (1.f - a.bn_momentum) * rv[tid] + a.bn_momentum * (m2 / (float)max(B - 1, 1));
-                }
-                if (nbt && tid == 0) nbt[arm * MMVAE_N_BN + a.obn_idx] += 1;
-            }
-        }
     }
     if (stamps && lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);

@@ -33,8 +33,6 @@ struct Splits {
     int ks_gd10;  // gene splits of the d(d10) = dZ11 W11 GEMM (fast path; the fused general kernel uses ns_fc11)
 };
 
-// ticket slots: forward BatchNorm 1..5 (slot i-1), backward batch sums of BatchNorm 5..1 (slot 5 + (5 - i))
-constexpr int TICK_SLOTS = 16;
 constexpr int N_SMALL = 12;  // fc2 fc3 fc4 fc5 fcc musig fc6 fc7 fc8 fc9 fc10 + fc1.bias
 
 struct Layout {
@@ -67,7 +65,6 @@ struct Layout {
     int64_t small_slab;            // [KS][A][N_SMALL][NP*SMALL_LD]
     int64_t xbits;                 // uint32 [A][B][ceil(D/32)] dropout keep-mask, bit-packed (fast path)
     int64_t loss_scratch;          // small
-    int64_t tickets;               // uint32 [TICK_SLOTS][MMVAE_MAX_ARMS] arrival counters of the last-arriver finalisations
     int64_t total;
 };
 
@@ -262,29 +259,6 @@ __device__ __forceinline__ int wave_min_i(int v) {
         return __builtin_bit_cast(float, x < y ? x : y);
     });
     return __builtin_bit_cast(int, f);
-}
-
-// ---- last-arriver ("ticket") finalisation -----------------------------------------------------------------------
-// Batch statistics cross every workgroup of the producing launch.  A grid-wide barrier costs 25 us at 158 workgroups
-// on this part (tools/micro/gridsync.hip: device-scope atomics serialise at ~0.16 us each and pollers contend with
-// them) while a launch boundary costs 2.6 us -- so layers stay separate launches, and the workgroup that finishes
-// LAST combines the per-workgroup partials once, in a fixed order, and leaves the final values for the next launch
-// (which then reads W floats instead of every workgroup re-reading nblk x 2W).  Nobody waits: the others exit.
-// All threads call; true for every thread of the last workgroup, after which the other workgroups' writes (made
-// before their arrival) are visible to it.  `counter` must be zero before the launch; the last arriver re-zeroes it.
-__device__ __forceinline__ bool ticket_is_last(unsigned* counter, unsigned n, unsigned* sh_flag) {
-    __threadfence();      // release: this thread's global stores are visible device-wide (L2 write-back across XCDs)
-    __syncthreads();      // ... for every thread of the workgroup
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = (t + 1u == n);
-        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *sh_flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = *sh_flag != 0u;
-    if (last) __threadfence();   // acquire for the threads that did not issue the atomic: drop stale L2 / L1 lines
-    return last;
 }
 
 // ---- consumer-side recombination of per-row-block partials ---------------------------------

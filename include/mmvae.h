@@ -124,7 +124,6 @@ enum {
     MMVAE_TUNE_DW11_V2,
     MMVAE_TUNE_ABLATE_L,           /* latent kernels: ablations                                       */
     MMVAE_TUNE_LAT_FULLWAVE,       /* latent kernels: one wave per cell instead of the half-wave layout */
-    MMVAE_TUNE_TICKET_OFF,         /* batch statistics recombined by every consumer workgroup (round-1 behaviour) instead of once by the producer's last workgroup */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {

@@ -174,7 +174,9 @@ def test_dominant_kernel_outputs_against_oracle(case):
         assert float((got[a] - own).abs().max()) <= STAGE_TOL * sc, a
         e = ((got[a] - c["gd"][a]).abs() / float(c["gd"][a].abs().max())).flatten()
         p90 = float(e.kthvalue(int(0.9 * e.numel())).values)
-        assert p90 <= tol_dz and float(e.max()) < 5 * GRAD_TOL, (a, p90, float(e.max()))
+        # (the maximum: one flipped ReLU decision of a gene with a large x moves a whole cell's row; the GEMM itself is
+        # pinned exactly above, the flips are classified element by element in the dZ11 check)
+        assert p90 <= tol_dz and float(e.max()) < 2e-2, (a, p90, float(e.max()))
 
 
 def test_loss_rec_counts_every_threshold_decision(case):
