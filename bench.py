@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
+    ap.add_argument("--gemm-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="operand type of the five D x H GEMMs: fp32 (the headline / parity configuration) or bf16 "
+                         "(BASELINE.json configs[2]: bf16 operands, fp32 accumulation, everything else fp32)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a box with fewer GPUs: every rank uses cuda:0 and the collectives "
                          "go through gloo (RCCL refuses two ranks on one device); the line is marked as a rehearsal")
@@ -217,6 +220,7 @@ def main():
                          n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev,
                          eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE").to(dev)
     model.train()
+    model.gemm_dtype = args.gemm_dtype
     opt = FusedAdam(model, lr=1e-3)
     if world > 1:
         DD.broadcast_flat(model.flat_parameters())
@@ -291,7 +295,7 @@ def main():
         "scaling": "weak",
         **({"rehearsal": "ranks share one GPU, gloo collectives: NOT a multi-GPU measurement"} if args.share_gpu else {}),
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.gemm_dtype == "fp32" else "bf16 operands in the five D x H GEMMs, f32 accumulation and everything else",
         "data": "synthetic",
         "config": {"workload": f"cpl_mixVAE A={A} arms, synthetic-10x-v1 {args.cells} cells x {D} genes per GPU, "
                                f"batch {B}/GPU, fp32, H=100 L=10 C=92 S=2, x_drop=0.5, Adam lr=1e-3",

@@ -44,7 +44,7 @@ class Dims(C.Structure):
 class Hyper(C.Structure):
     _fields_ = [("tau", C.c_float), ("temp", C.c_float), ("beta", C.c_float), ("lam", C.c_float),
                 ("eps", C.c_float), ("bn_momentum", C.c_float), ("x_drop", C.c_float), ("s_drop", C.c_float),
-                ("hard", C.c_int32), ("training", C.c_int32), ("eval_flag", C.c_int32)]
+                ("hard", C.c_int32), ("training", C.c_int32), ("eval_flag", C.c_int32), ("gemm_bf16", C.c_int32)]
 
 
 class Noise(C.Structure):

@@ -136,8 +136,9 @@ class cpl_mixVAE:
 
     def init_model(self, n_categories, state_dim, input_dim, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.2,
                    lr=0.001, lam=1, lam_pc=1, n_arm=2, temp=1.0, tau=0.005, beta=1.0, hard=False, variational=True,
-                   ref_prior=False, trained_model="", n_pr=0, momentum=0.01, mode="MSE"):
-        """cpl_mixvae.py:193-286."""
+                   ref_prior=False, trained_model="", n_pr=0, momentum=0.01, mode="MSE", gemm_dtype="fp32"):
+        """cpl_mixvae.py:193-286.  ``gemm_dtype`` (not in the reference): "fp32", or "bf16" for BASELINE.json's bf16
+        configuration (bf16 operands in the five D x H GEMMs, fp32 everywhere else)."""
         self.lowD_dim = lowD_dim
         self.n_categories = n_categories
         self.state_dim = state_dim
@@ -152,6 +153,7 @@ class cpl_mixVAE:
                                   device=self.device, eps=self.eps, ref_prior=ref_prior, momentum=momentum,
                                   loss_mode=mode)
         self.model = self.model.to(self.device)
+        self.model.gemm_dtype = gemm_dtype
         self.optimizer = FusedAdam(self.model, lr=lr)
         if len(trained_model) > 0:
             loaded = torch.load(trained_model, map_location="cpu", weights_only=True)

@@ -573,6 +573,11 @@ int launch_fc1_epi(const Ctx& c, const float* params);
 int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad,
                      int which = 3);
 int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit0 dW1, bit1 dW11*/);
+// bf16-operand variants of the five D x H GEMMs (gemm_bf16.hip; mmvae_hyper.gemm_bf16), same outputs / layouts
+inline bool bf16_gemms(const Ctx& c) { return c.h.gemm_bf16 != 0 && c.d.H <= 124; }
+int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);
+int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);
+int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);
 // evaluation labels / consensus (consensus.hip)
 int launch_classify(const float* cc, int64_t n_cells, int C, int32_t* labels, hipStream_t s);
 int launch_confmat(const int32_t* labels, int A, int64_t n, int C, int64_t* counts, hipStream_t s);

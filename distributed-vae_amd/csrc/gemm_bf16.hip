@@ -1,0 +1,389 @@
+// bf16-operand variants of the five D x H GEMMs of the train step (BASELINE.json configs[2]: "bf16, DP over 8 GPUs";
+// mmvae_hyper.gemm_bf16 != 0).  Operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way
+// into LDS, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense: 16 x the fp32 matrix rate), and
+// everything else of the step -- BatchNorm, the softmaxes, KL / coupling terms, the reconstruction-loss epilogue, the
+// slab reduction, Adam, the parameters themselves -- stays fp32 (SURVEY.md section 7 "Numerical range").  With the
+// matrix pipe 16 x faster these kernels are bound by how fast a CU can pull its tiles out of L2 / HBM, so they share ONE
+// simple tile engine instead of five hand-scheduled instruction streams:
+//
+//   C[m][n] (+ epilogue) = sum_k A(m, k) * B(n, k),  block tile 128 x 128, 256 threads = 2 x 2 waves of 64 x 64
+//   (2 x 2 MFMA tiles of 32 x 32), K tile 64 = 4 MFMA steps of 16; one LDS buffer per operand, [row][k] bf16 with k
+//   contiguous (row stride 144 B), so a lane's MFMA fragment (8 consecutive k of one row) is one ds_read_b128.
+//
+// An operand is described by how (row, k) maps to memory:
+//   KMAJOR   ptr[row * ld + k]   k contiguous in memory   (x, W1, d10, W11 rows, dZ11 rows)
+//   KMINOR   ptr[k * ld + row]   rows contiguous          (the batch-reduced GEMMs: dZ1, x, dZ11, d10 as [b][.];
+//                                                          W11 as [j][h] for d(d10)); transposed while staging:
+//                                                          two k rows are loaded, packed pairwise and scattered
+// plus optional decorations: the bit-packed dropout keep-mask of x (k_make_xbits) and a ones column (bias gradient).
+// fc11's bias is added in fp32 by the epilogue (it is not a GEMM operand of the reference either).
+//
+//   fc1 forward      C[cell][h]  = x~[cell][:] . W1[h][:]            A KMAJOR+mask, B KMAJOR     -> split-K slabs
+//   fc11 + loss      z[cell][j]  = d10[cell][:] . W11[j][:] (+ b11) A KMAJOR, B KMAJOR          -> dZ11, loss partials
+//   d(d10)           g[cell][h]  = dZ11[cell][:] . W11[:][h]         A KMAJOR, B KMINOR          -> gene-split slabs
+//   dW1              G[h][d]     = dZ1[:][h] . x~[:][d]              A KMINOR, B KMINOR+mask     -> batch-split slabs
+//   [dW11 | db11]    G[j][h]     = dZ11[:][j] . [d10 | 1][:][h]      A KMINOR, B KMINOR+ones col -> batch-split slabs
+// The outputs have the layouts of the fp32 kernels (gemm_fast.hip), so k_fc1_epi, the decoder chain and k_reduce are
+// shared.  Reference arithmetic: mmidas/nn_model.py:263-287 (fc1, fc11), :542-546 (loss), autograd of both.
+#include "common.hpp"
+
+namespace mmvae {
+
+#define HIP_LAUNCH_CHECK(what)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            set_error("%s: %s", what, hipGetErrorString(e_));                         \
+            return MMVAE_E_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int BT = 128;          // block tile (both ways)
+constexpr int KT = 64;           // K tile
+constexpr int LDB = 36;          // LDS row stride in dwords: 64 bf16 = 32 dwords + 4 (rows stay 16-byte aligned)
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+struct Operand {
+    const float* ptr;        // this arm's matrix
+    int64_t ld;              // leading dimension (floats)
+    int rows, K;             // rows (m or n) that exist in memory and k extent
+    int kminor;              // 0: ptr[row * ld + k]; 1: ptr[k * ld + row]
+    const uint32_t* bits;    // optional keep-mask of x: bit (col & 31) of bits[cell * wpr + (col >> 5)], cell / col = (row, k) or (k, row)
+    int wpr;
+    int ones_row;            // KMINOR: row index that reads as 1.0 for every k < K (bias gradient), or -1
+};
+
+// stage rows [r0, r0 + 128) x k [k0, k0 + 64) of `o` into `T` ([128][LDB] dwords, bf16 pairs along k), zero outside
+__device__ __forceinline__ void stage_operand(unsigned* __restrict__ T, const Operand& o, int r0, int k0, int kend) {
+    const int tid = threadIdx.x;
+    if (!o.kminor) {
+        // thread: row = tid >> 3 (+32 per pass), k quads (tid & 7) and (tid & 7) + 8
+        const int kq = tid & 7, rr = tid >> 3;
+        float4 v[4][2];
+        uint32_t wd[4][2];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = r0 + rr + 32 * p;
+            const int rc = min(row, o.rows - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + (kq + 8 * h) * 4;
+                const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;     // K % 4 == 0, k0 % 4 == 0
+                v[p][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)rc * o.ld + (ok ? k : 0));
+                wd[p][h] = o.bits ? o.bits[(int64_t)rc * o.wpr + ((ok ? k : 0) >> 5)] : 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = r0 + rr + 32 * p;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + (kq + 8 * h) * 4;
+                const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;
+                const uint32_t nib = wd[p][h] >> (k & 31);
+                float4 q = v[p][h];
+                q.x = (ok && (nib & 1u)) ? q.x : 0.f;
+                q.y = (ok && (nib & 2u)) ? q.y : 0.f;
+                q.z = (ok && (nib & 4u)) ? q.z : 0.f;
+                q.w = (ok && (nib & 8u)) ? q.w : 0.f;
+                uint2 w;
+                w.x = pack_bf16(q.x, q.y);
+                w.y = pack_bf16(q.z, q.w);
+                *reinterpret_cast<uint2*>(&T[(rr + 32 * p) * LDB + (kq + 8 * h) * 2]) = w;
+            }
+        }
+    } else {
+        // thread: rows 4 (tid & 31) .. + 3, k pairs 2 (tid >> 5) + 16 i (i < 4): two k rows -> four packed dwords
+        const int r4 = (tid & 31) * 4, kp = tid >> 5;
+        float4 v[4][2];
+        uint32_t wd[4][2];
+        const bool vec = (o.ld & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + 2 * (kp + 8 * i) + h;
+                const int kc = min(k, o.K - 1);
+                const int row = r0 + r4;
+                if (vec) {   // row % 4 == 0 and ld % 4 == 0: the four floats stay inside the memory row whenever row < ld
+                    v[i][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)kc * o.ld + (row < o.ld ? row : 0));
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = o.ptr[(int64_t)kc * o.ld + min(row + e, o.rows - 1)];
+                    v[i][h] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                wd[i][h] = o.bits ? o.bits[(int64_t)kc * o.wpr + (min(row, o.rows - 1) >> 5)] : 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float e0[4], e1[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + 2 * (kp + 8 * i) + h;
+                const bool kok = k < kend && k < o.K;
+                const uint32_t nib = wd[i][h] >> ((r0 + r4) & 31);
+                const float4 q = v[i][h];
+                const float t[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = r0 + r4 + e;
+                    float x = (kok && row < o.rows && ((nib >> e) & 1u)) ? t[e] : 0.f;
+                    if (kok && row == o.ones_row) x = 1.f;
+                    (h == 0 ? e0 : e1)[e] = x;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[(r4 + e) * LDB + kp + 8 * i] = pack_bf16(e0[e], e1[e]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// epilogues
+// ---------------------------------------------------------------------------------------------------------------
+struct SlabOut {       // C tile -> out[(ks * A + arm)][m][n], m < M, n < N
+    float* out;
+    int64_t ks_stride, arm_stride;
+    int ld, M, N;
+};
+struct Fc11Out {       // z tile -> + bias, dZ11, loss partials (nn_model.py:286, :542-546 and their autograd)
+    const float* bias; // [D], arm stride bias_arm
+    const float* x;    // this arm's [B][D]
+    float* dz;         // this arm's [B][D]
+    float* x_rec;      // this arm's [B][D] or null
+    float* part;       // this arm's loss partial slots [n11][2]
+    float coef;
+    int B, D;
+};
+
+struct GemmArgs {
+    Operand a, b;
+    int64_t a_arm, b_arm;        // arm strides of the operands (floats); mask bits: a_bits_arm / b_bits_arm (words)
+    int64_t a_bits_arm, b_bits_arm;
+    int64_t bias_arm;            // arm stride of fo.bias
+    int M, N, K;
+    int KS;                      // splits of the k range (grid.y) -- or of the n tiles when loop_n
+    int loop_n;                  // 1: grid.y splits the n tiles, the block walks its tiles (fc11)
+    SlabOut so;
+    Fc11Out fo;
+    int64_t fo_arm, fo_x_arm;    // arm strides of dz / x_rec and of x (0: the arms share x)
+    int n11;
+    int A;
+};
+
+template <bool FC11>
+__global__ __launch_bounds__(256) void k_bf16_gemm(const GemmArgs g_in) {
+    const GemmArgs g = g_in;
+    __shared__ __attribute__((aligned(16))) unsigned As[BT * LDB];
+    __shared__ __attribute__((aligned(16))) unsigned Bs[BT * LDB];
+    __shared__ float red[8];
+    const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    Operand oa = g.a, ob = g.b;
+    oa.ptr += (int64_t)arm * g.a_arm;
+    ob.ptr += (int64_t)arm * g.b_arm;
+    if (oa.bits) oa.bits += (int64_t)arm * g.a_bits_arm;
+    if (ob.bits) ob.bits += (int64_t)arm * g.b_bits_arm;
+    const int tiles_n = cdiv(g.N, BT);
+    int m0, nt0, nt1, kb, ke;
+    if (g.loop_n) {
+        m0 = blockIdx.x * BT;
+        nt0 = (int)(((int64_t)blockIdx.y * tiles_n) / g.KS);
+        nt1 = (int)(((int64_t)(blockIdx.y + 1) * tiles_n) / g.KS);
+        kb = 0;
+        ke = g.K;
+    } else {
+        m0 = (blockIdx.x / tiles_n) * BT;
+        nt0 = blockIdx.x % tiles_n;
+        nt1 = nt0 + 1;
+        const int nkt = cdiv(g.K, KT);
+        kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KT;
+        ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
+    }
+    float se = 0.f;
+    int mism = 0;
+    for (int nt = nt0; nt < nt1; ++nt) {
+        const int n0 = nt * BT;
+        f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+        for (int k0 = kb; k0 < ke; k0 += KT) {
+            stage_operand(As, oa, m0, k0, ke);
+            stage_operand(Bs, ob, n0, k0, ke);
+            __syncthreads();
+            const unsigned* pa = As + (wm * 64 + l31) * LDB + 4 * hh;
+            const unsigned* pb = Bs + (wn * 64 + l31) * LDB + 4 * hh;
+#pragma unroll
+            for (int s = 0; s < KT / 16; ++s) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pa + 8 * s));
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pa + 32 * LDB + 8 * s));
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pb + 8 * s));
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pb + 32 * LDB + 8 * s));
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue of this tile: accumulator register r of tile (i, j) is row m0 + 64 wm + 32 i + acc_row(r),
+        //      column n0 + 64 wn + 32 j + (lane & 31)
+        if (!FC11) {
+            float* out = g.so.out + (int64_t)blockIdx.y * g.so.ks_stride + (int64_t)arm * g.so.arm_stride;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + 64 * wn + 32 * j + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
+                        if (row < g.so.M && col < g.so.N) out[(int64_t)row * g.so.ld + col] = acc[i][j][r];
+                    }
+                }
+        } else {
+            const float* xa = g.fo.x + (int64_t)arm * g.fo_x_arm;
+            float* dza = g.fo.dz + (int64_t)arm * g.fo_arm;
+            float* xra = g.fo.x_rec ? g.fo.x_rec + (int64_t)arm * g.fo_arm : nullptr;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + 64 * wn + 32 * j + l31;
+                    const float bj = g.fo.bias[(int64_t)arm * g.bias_arm + min(col, g.fo.D - 1)];
+                    float xin[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
+                        const bool ok = row < g.fo.B && col < g.fo.D;
+                        xin[r] = xa[(int64_t)(ok ? row : 0) * g.fo.D + (ok ? col : 0)];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
+                        const bool ok = row < g.fo.B && col < g.fo.D;
+                        const float xr = fmaxf(acc[i][j][r] + bj, 0.f);
+                        const float er = xr - xin[r];
+                        se += ok ? er * er : 0.f;
+                        mism += (ok && ((xr > 0.1f) != (xin[r] > 0.1f))) ? 1 : 0;
+                        if (ok) {
+                            dza[(int64_t)row * g.fo.D + col] = xr > 0.f ? g.fo.coef * er : 0.f;
+                            if (xra) xra[(int64_t)row * g.fo.D + col] = xr;
+                        }
+                    }
+                }
+        }
+    }
+    if (FC11) {
+        se = wave_sum(se);
+        const float mf = wave_sum((float)mism);
+        if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mf; }
+        __syncthreads();
+        if (tid == 0) {
+            float* p = g.fo.part + ((int64_t)arm * g.n11 + (int64_t)blockIdx.x * g.KS + blockIdx.y) * 2;
+            p[0] = red[0] + red[2] + red[4] + red[6];
+            p[1] = red[1] + red[3] + red[5] + red[7];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host launchers (same workspace layouts and split factors as the fp32 fast path)
+// ---------------------------------------------------------------------------------------------------------------
+static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1}; }
+static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1}; }
+
+int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs) {
+    const mmvae_dims& d = c.d;
+    const bool use_mask = c.h.training && c.h.x_drop > 0.f;
+    GemmArgs g{};
+    g.a = kmajor(x, d.D, d.B, d.D);
+    g.a_arm = xs;
+    if (use_mask) { g.a.bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits); g.a.wpr = cdiv(d.D, 32); g.a_bits_arm = (int64_t)d.B * g.a.wpr; }
+    g.b = kmajor(params + c.po.o[0], d.D, d.H, d.D);
+    g.b_arm = c.po.per_arm;
+    g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A;
+    g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
+    hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+    HIP_LAUNCH_CHECK("k_bf16_gemm<fc1>");
+    return 0;
+}
+
+int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    const int NS = L.sp.ks_gd10;
+    if (which & 1) {
+        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
+        if ((int64_t)cdiv(d.B, BT) * NS > L.n11) { set_error("fc11 bf16: loss partial slots"); return MMVAE_E_LAUNCH; }
+        GemmArgs g{};
+        g.a = kmajor(c.ws + L.Dk[4], d.H, d.B, d.H);          // d10 [B][H]
+        g.a_arm = (int64_t)d.B * d.H;
+        g.b = kmajor(params + c.po.o[26], d.H, d.D, d.H);      // W11 [D][H]
+        g.b_arm = c.po.per_arm;
+        g.bias_arm = c.po.per_arm;
+        g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.loop_n = 1; g.A = d.A; g.n11 = L.n11;
+        g.fo = Fc11Out{params + c.po.o[27], x, c.ws + L.DZ11, x_rec, c.ws + L.fc11_part,
+                       (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D};
+        g.fo_arm = (int64_t)d.B * d.D;
+        g.fo_x_arm = xs;
+        hipLaunchKernelGGL((k_bf16_gemm<true>), dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+        HIP_LAUNCH_CHECK("k_bf16_gemm<fc11>");
+    }
+    if (need_grad && (which & 2)) {
+        GemmArgs g{};
+        g.a = kmajor(c.ws + L.DZ11, d.D, d.B, d.D);            // dZ11 [B][D], k = gene
+        g.a_arm = (int64_t)d.B * d.D;
+        g.b = kminor(params + c.po.o[26], d.H, d.H, d.D);      // W11 [D][H] read as B[n = h][k = j]
+        g.b_arm = c.po.per_arm;
+        g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A;
+        g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
+        hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+        HIP_LAUNCH_CHECK("k_bf16_gemm<gd10>");
+    }
+    return 0;
+}
+
+int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
+    const mmvae_dims& d = c.d;
+    const Layout& L = c.lay;
+    const bool use_mask = c.h.training && c.h.x_drop > 0.f;
+    if (which & 1) {   // dW1[h][d] = sum_b dZ1[b][h] x~[b][d]
+        GemmArgs g{};
+        g.a = kminor(c.ws + L.DZ[1], d.H, d.H, d.B);
+        g.a_arm = (int64_t)d.B * d.H;
+        g.b = kminor(x, d.D, d.D, d.B);
+        g.b_arm = xs;
+        if (use_mask) { g.b.bits = reinterpret_cast<const uint32_t*>(c.ws + L.xbits); g.b.wpr = cdiv(d.D, 32); g.b_bits_arm = (int64_t)d.B * g.b.wpr; }
+        g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A;
+        g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
+        hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+        HIP_LAUNCH_CHECK("k_bf16_gemm<dW1>");
+    }
+    if (which & 2) {   // [dW11 | db11][j][h] = sum_b dZ11[b][j] [d10 | 1][b][h]
+        GemmArgs g{};
+        g.a = kminor(c.ws + L.DZ11, d.D, d.D, d.B);
+        g.a_arm = (int64_t)d.B * d.D;
+        g.b = kminor(c.ws + L.Dk[4], d.H, d.H, d.B);
+        g.b.ones_row = d.H;                                      // logical row H (not in memory) reads 1: the bias gradient
+        g.b_arm = (int64_t)d.B * d.H;
+        g.M = d.D; g.N = d.H + 1; g.K = d.B; g.KS = L.sp.ks_dw11; g.A = d.A;
+        g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
+        hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+        HIP_LAUNCH_CHECK("k_bf16_gemm<dW11>");
+    }
+    return 0;
+}
+
+}  // namespace mmvae

@@ -1406,6 +1406,7 @@ int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
 }
 
 int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64_t xs) {
+    if (bf16_gemms(c)) return launch_fc1_fwd_bf16(c, params, x, xs);
     const mmvae_dims& d = c.d;
     const bool use_mask = c.h.training && c.h.x_drop > 0.f;
     const int KS = c.lay.sp.ks_fc1;
@@ -1436,6 +1437,7 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
 
 int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad,
                      int which /*bit0: x_rec/loss/dZ11 kernel, bit1: d(d10) GEMM*/) {
+    if (bf16_gemms(c)) return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int ldk = rup(d.H, 8) + 4;
@@ -1522,6 +1524,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
 }
 
 int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
+    if (bf16_gemms(c)) return launch_dw_big_bf16(c, x, xs, which);
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const bool use_mask = c.h.training && c.h.x_drop > 0.f;

@@ -127,6 +127,9 @@ class mixVAE_model(nn.Module):
         self._noise_seed = None
         self._noise_offset = 0
         self._exec: Optional[N.Exec] = None   # None: split factors / experiment switches from the environment
+        # operand type of the five D x H GEMMs: "fp32" (the parity configuration) or "bf16" (BASELINE.json's bf16
+        # configuration: operands rounded to bf16, fp32 accumulation; everything else and all parameters stay fp32)
+        self.gemm_dtype = "fp32"
 
     # ------------------------------------------------------------------ flat parameter storage
     def _dims(self, B: int) -> N.Dims:
@@ -236,8 +239,11 @@ class mixVAE_model(nn.Module):
         self._explicit_noise = list(noise) if isinstance(noise, (list, tuple)) else noise
 
     def _hyper(self, temp: float, eval_flag: bool) -> N.Hyper:
+        if self.gemm_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"gemm_dtype must be 'fp32' or 'bf16', got {self.gemm_dtype!r}")
         return N.Hyper(self.tau, float(temp), self.beta, self.lam, self.eps, self.momentum, float(self.x_dp.p),
-                       float(self.s_dp.p), int(bool(self.hard)), int(self.training), int(bool(eval_flag)))
+                       float(self.s_dp.p), int(bool(self.hard)), int(self.training), int(bool(eval_flag)),
+                       int(self.gemm_dtype == "bf16"))
 
     def _next_noise(self) -> N.Noise:
         if isinstance(self._explicit_noise, list):

@@ -67,6 +67,10 @@ typedef struct mmvae_hyper {
     int32_t hard;      /* straight-through one-hot sample, :486-493         */
     int32_t training;  /* module.training: batch-stat BN + dropout active   */
     int32_t eval_flag; /* forward(eval=True): no Gumbel noise, hard sample, :340-343 */
+    int32_t gemm_bf16; /* != 0: the five D x H GEMMs (fc1, fc11, d(d10), dW1, dW11) take bf16 operands (rounded to
+                          nearest even on load) with fp32 accumulation on the bf16 matrix pipe -- BASELINE.json's bf16
+                          configuration; every other computation and all parameters stay fp32.  0: fp32 operands.
+                          Needs the fast path (D % 4 == 0, fc_dim % 4 == 0, fc_dim <= 124), else ignored. */
 } mmvae_hyper;
 
 /* Noise descriptor.  mode 0 = explicit buffers (parity tests; the reference's RNG stream cannot

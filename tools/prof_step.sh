@@ -6,7 +6,7 @@ out=$PWD/gpurun_out/$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $OLDPWD/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-eval --no-roofline > $out/bench.json 2> $out/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $OLDPWD/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-eval --no-roofline $BENCH_ARGS > $out/bench.json 2> $out/prof.err
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" $out/kernel_stats.csv
 python3 - "$out/kernel_stats.csv" <<'PY'
