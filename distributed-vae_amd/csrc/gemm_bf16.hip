@@ -13,8 +13,8 @@
 // An operand is described by how (row, k) maps to memory:
 //   KMAJOR   ptr[row * ld + k]   k contiguous in memory   (x, W1, d10, W11 rows, dZ11 rows)
 //   KMINOR   ptr[k * ld + row]   rows contiguous          (the batch-reduced GEMMs: dZ1, x, dZ11, d10 as [b][.];
-//                                                          W11 as [j][h] for d(d10)); transposed while staging:
-//                                                          two k rows are loaded, packed pairwise and scattered
+//                                                          W11 as [j][h] for d(d10)): staged as they lie, [k][row],
+//                                                          and transposed by the LDS read (ds_read_b64_tr_b16)
 // plus optional decorations: the bit-packed dropout keep-mask of x (k_make_xbits) and a ones column (bias gradient).
 // fc11's bias is added in fp32 by the epilogue (it is not a GEMM operand of the reference either).
 //
@@ -44,7 +44,8 @@ typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int BT = 128;          // block tile (both ways)
 constexpr int KT = 64;           // K tile
-constexpr int LDB = 36;          // LDS row stride in dwords: 64 bf16 = 32 dwords + 4 (rows stay 16-byte aligned)
+constexpr int LDB = 36;          // KMAJOR LDS image [row][k]: row stride in dwords, 64 bf16 = 32 dwords + 4 (16-byte aligned rows)
+constexpr int LDK = 136;         // KMINOR LDS image [k][row]: k-row stride in bf16, 128 rows + 8 (8-byte aligned; 64 x 136 x 2 B fits BT x LDB dwords)
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     bf16x2 v;
@@ -63,14 +64,23 @@ struct Operand {
     int ones_row;            // KMINOR: row index that reads as 1.0 for every k < K (bias gradient), or -1
 };
 
-// stage rows [r0, r0 + 128) x k [k0, k0 + 64) of `o` into `T` ([128][LDB] dwords, bf16 pairs along k), zero outside
-__device__ __forceinline__ void stage_operand(unsigned* __restrict__ T, const Operand& o, int r0, int k0, int kend) {
+// One K tile of an operand in flight: rows [r0, r0 + 128) x k [k0, k0 + 64).  `load` only REQUESTS the data (eight
+// float4 and their mask words per thread; nothing touches the values, so the requests of both operands issue back to
+// back and land while the MFMAs of the previous tile run); `store` masks, rounds to bf16 and writes the LDS image
+// ([128][LDB] dwords, bf16 pairs along k, zero outside the operand).
+template <bool BITS>
+struct TileRegsT {
+    float4 v[4][2];
+    uint32_t wd[BITS ? 4 : 1][2];   // keep-mask words (only operands that carry a mask hold them)
+};
+typedef TileRegsT<true> TileRegs;
+
+template <bool KMINOR, bool BITS = true>
+__device__ __forceinline__ void tile_load(TileRegsT<BITS>& t, const Operand& o, int r0, int k0, int kend) {
     const int tid = threadIdx.x;
-    if (!o.kminor) {
+    if (!KMINOR) {
         // thread: row = tid >> 3 (+32 per pass), k quads (tid & 7) and (tid & 7) + 8
         const int kq = tid & 7, rr = tid >> 3;
-        float4 v[4][2];
-        uint32_t wd[4][2];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = r0 + rr + 32 * p;
@@ -79,10 +89,40 @@ __device__ __forceinline__ void stage_operand(unsigned* __restrict__ T, const Op
             for (int h = 0; h < 2; ++h) {
                 const int k = k0 + (kq + 8 * h) * 4;
                 const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;     // K % 4 == 0, k0 % 4 == 0
-                v[p][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)rc * o.ld + (ok ? k : 0));
-                wd[p][h] = o.bits ? o.bits[(int64_t)rc * o.wpr + ((ok ? k : 0) >> 5)] : 0xFFFFFFFFu;
+                t.v[p][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)rc * o.ld + (ok ? k : 0));
+                if constexpr (BITS) t.wd[p][h] = o.bits ? o.bits[(int64_t)rc * o.wpr + ((ok ? k : 0) >> 5)] : 0xFFFFFFFFu;
             }
         }
+    } else {
+        // thread: rows 4 (tid & 31) .. + 3, k pairs 2 (tid >> 5) + 16 i (i < 4): two k rows -> four packed dwords
+        const int r4 = (tid & 31) * 4, kp = tid >> 5;
+        const bool vec = (o.ld & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = k0 + 2 * (kp + 8 * i) + h;
+                const int kc = min(k, o.K - 1);
+                const int row = r0 + r4;
+                if (vec) {   // row % 4 == 0 and ld % 4 == 0: the four floats stay inside the memory row whenever row < ld
+                    t.v[i][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)kc * o.ld + (row < o.ld ? row : 0));
+                } else {
+                    float q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = o.ptr[(int64_t)kc * o.ld + min(row + e, o.rows - 1)];
+                    t.v[i][h] = make_float4(q[0], q[1], q[2], q[3]);
+                }
+                if constexpr (BITS) t.wd[i][h] = o.bits ? o.bits[(int64_t)kc * o.wpr + (min(row, o.rows - 1) >> 5)] : 0xFFFFFFFFu;
+            }
+        }
+    }
+}
+
+template <bool KMINOR, bool BITS = true>
+__device__ __forceinline__ void tile_store(unsigned* __restrict__ T, const TileRegsT<BITS>& t, const Operand& o, int r0, int k0, int kend) {
+    const int tid = threadIdx.x;
+    if (!KMINOR) {
+        const int kq = tid & 7, rr = tid >> 3;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = r0 + rr + 32 * p;
@@ -90,8 +130,8 @@ __device__ __forceinline__ void stage_operand(unsigned* __restrict__ T, const Op
             for (int h = 0; h < 2; ++h) {
                 const int k = k0 + (kq + 8 * h) * 4;
                 const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;
-                const uint32_t nib = wd[p][h] >> (k & 31);
-                float4 q = v[p][h];
+                const uint32_t nib = BITS ? t.wd[p][h] >> (k & 31) : 0xFu;
+                float4 q = t.v[p][h];
                 q.x = (ok && (nib & 1u)) ? q.x : 0.f;
                 q.y = (ok && (nib & 2u)) ? q.y : 0.f;
                 q.z = (ok && (nib & 4u)) ? q.z : 0.f;
@@ -103,50 +143,56 @@ __device__ __forceinline__ void stage_operand(unsigned* __restrict__ T, const Op
             }
         }
     } else {
-        // thread: rows 4 (tid & 31) .. + 3, k pairs 2 (tid >> 5) + 16 i (i < 4): two k rows -> four packed dwords
+        // natural layout [k][row] (rows contiguous, LDK bf16 per k): one 8-byte store per (k, four rows); the MFMA
+        // fragments come out of it through the transposing LDS read (ds_read_b64_tr_b16, see frag8)
+        unsigned short* Tk = reinterpret_cast<unsigned short*>(T);
         const int r4 = (tid & 31) * 4, kp = tid >> 5;
-        float4 v[4][2];
-        uint32_t wd[4][2];
-        const bool vec = (o.ld & 3) == 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int k = k0 + 2 * (kp + 8 * i) + h;
-                const int kc = min(k, o.K - 1);
-                const int row = r0 + r4;
-                if (vec) {   // row % 4 == 0 and ld % 4 == 0: the four floats stay inside the memory row whenever row < ld
-                    v[i][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)kc * o.ld + (row < o.ld ? row : 0));
-                } else {
-                    float t[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = o.ptr[(int64_t)kc * o.ld + min(row + e, o.rows - 1)];
-                    v[i][h] = make_float4(t[0], t[1], t[2], t[3]);
-                }
-                wd[i][h] = o.bits ? o.bits[(int64_t)kc * o.wpr + (min(row, o.rows - 1) >> 5)] : 0xFFFFFFFFu;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float e0[4], e1[4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = k0 + 2 * (kp + 8 * i) + h;
+                const int kl = 2 * (kp + 8 * i) + h, k = k0 + kl;
                 const bool kok = k < kend && k < o.K;
-                const uint32_t nib = wd[i][h] >> ((r0 + r4) & 31);
-                const float4 q = v[i][h];
-                const float t[4] = {q.x, q.y, q.z, q.w};
+                const uint32_t nib = BITS ? t.wd[i][h] >> ((r0 + r4) & 31) : 0xFu;
+                const float4 q = t.v[i][h];
+                const float qq[4] = {q.x, q.y, q.z, q.w};
+                float x[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int row = r0 + r4 + e;
-                    float x = (kok && row < o.rows && ((nib >> e) & 1u)) ? t[e] : 0.f;
-                    if (kok && row == o.ones_row) x = 1.f;
-                    (h == 0 ? e0 : e1)[e] = x;
+                    x[e] = (kok && row < o.rows && ((nib >> e) & 1u)) ? qq[e] : 0.f;
+                    if (kok && row == o.ones_row) x[e] = 1.f;
                 }
+                uint2 w;
+                w.x = pack_bf16(x[0], x[1]);
+                w.y = pack_bf16(x[2], x[3]);
+                *reinterpret_cast<uint2*>(&Tk[kl * LDK + r4]) = w;
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) T[(r4 + e) * LDB + kp + 8 * i] = pack_bf16(e0[e], e1[e]);
         }
+    }
+}
+
+// MFMA fragment of a 32-row tile (rows rb .. rb + 31 of the block tile), K step s (16 k's): lane l holds row l % 32,
+// k = 16 s + 8 (l / 32) .. + 7.  KMAJOR image: one ds_read_b128.  KMINOR image ([k][row]): two transposing reads -- per
+// group of 16 lanes the hardware reads a 4 (k) x 16 (rows) block and hands lane i of the group column i, i.e. four
+// consecutive k of row i; lane 4 q + p supplies the address of block row q, columns 4 p .. 4 p + 3.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <bool MINOR>
+__device__ __forceinline__ bf16x8 frag8(const unsigned* T, int rb, int s, int lane) {
+    if (!MINOR) {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(T + (rb + (lane & 31)) * LDB + 4 * (lane >> 5) + 8 * s));
+    } else {
+        const unsigned short* Tk = reinterpret_cast<const unsigned short*>(T);
+        const int grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const unsigned short* a = Tk + (16 * s + 8 * (grp >> 1) + q) * LDK + rb + 16 * (grp & 1) + 4 * p;
+        typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * LDK));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 r;
+        r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
+        r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
+        return __builtin_bit_cast(bf16x8, r);
     }
 }
 
@@ -175,7 +221,6 @@ struct GemmArgs {
     int64_t bias_arm;            // arm stride of fo.bias
     int M, N, K;
     int KS;                      // splits of the k range (grid.y) -- or of the n tiles when loop_n
-    int loop_n;                  // 1: grid.y splits the n tiles, the block walks its tiles (fc11)
     SlabOut so;
     Fc11Out fo;
     int64_t fo_arm, fo_x_arm;    // arm strides of dz / x_rec and of x (0: the arms share x)
@@ -183,12 +228,29 @@ struct GemmArgs {
     int A;
 };
 
-template <bool FC11>
-__global__ __launch_bounds__(256) void k_bf16_gemm(const GemmArgs g_in) {
+// 16 MFMAs of one K tile: this wave's 64 x 64 of the block tile
+template <bool AMINOR, bool BMINOR>
+__device__ __forceinline__ void mfma_ktile(f32x16 (&acc)[2][2], const unsigned* As, const unsigned* Bs, int wm, int wn, int lane) {
+#pragma unroll
+    for (int s = 0; s < KT / 16; ++s) {
+        const bf16x8 a0 = frag8<AMINOR>(As, wm * 64, s, lane);
+        const bf16x8 a1 = frag8<AMINOR>(As, wm * 64 + 32, s, lane);
+        const bf16x8 b0 = frag8<BMINOR>(Bs, wn * 64, s, lane);
+        const bf16x8 b1 = frag8<BMINOR>(Bs, wn * 64 + 32, s, lane);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// C tile -> slab.  grid (tiles_m * tiles_n, KS, A): block (m tile, n tile) x k range ks x arm.  Tile t + 1 is requested
+// from memory before tile t's MFMAs and written to LDS after them: two barriers per K tile, loads always in flight.
+template <bool AMINOR, bool BMINOR>
+__global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const GemmArgs g = g_in;
     __shared__ __attribute__((aligned(16))) unsigned As[BT * LDB];
     __shared__ __attribute__((aligned(16))) unsigned Bs[BT * LDB];
-    __shared__ float red[8];
     const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
     const int l31 = lane & 31, hh = lane >> 5;
     Operand oa = g.a, ob = g.b;
@@ -197,103 +259,138 @@ __global__ __launch_bounds__(256) void k_bf16_gemm(const GemmArgs g_in) {
     if (oa.bits) oa.bits += (int64_t)arm * g.a_bits_arm;
     if (ob.bits) ob.bits += (int64_t)arm * g.b_bits_arm;
     const int tiles_n = cdiv(g.N, BT);
-    int m0, nt0, nt1, kb, ke;
-    if (g.loop_n) {
-        m0 = blockIdx.x * BT;
-        nt0 = (int)(((int64_t)blockIdx.y * tiles_n) / g.KS);
-        nt1 = (int)(((int64_t)(blockIdx.y + 1) * tiles_n) / g.KS);
-        kb = 0;
-        ke = g.K;
-    } else {
-        m0 = (blockIdx.x / tiles_n) * BT;
-        nt0 = blockIdx.x % tiles_n;
-        nt1 = nt0 + 1;
-        const int nkt = cdiv(g.K, KT);
-        kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KT;
-        ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
+    const int m0 = (blockIdx.x / tiles_n) * BT, n0 = (blockIdx.x % tiles_n) * BT;
+    const int nkt = cdiv(g.K, KT);
+    const int kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KT;
+    const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
+    f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+    TileRegs ta, tb;
+    if (kb < ke) {
+        tile_load<AMINOR>(ta, oa, m0, kb, ke);
+        tile_load<BMINOR>(tb, ob, n0, kb, ke);
+    }
+    for (int k0 = kb; k0 < ke; k0 += KT) {
+        tile_store<AMINOR>(As, ta, oa, m0, k0, ke);
+        tile_store<BMINOR>(Bs, tb, ob, n0, k0, ke);
+        __syncthreads();
+        if (k0 + KT < ke) {
+            tile_load<AMINOR>(ta, oa, m0, k0 + KT, ke);
+            tile_load<BMINOR>(tb, ob, n0, k0 + KT, ke);
+        }
+        mfma_ktile<AMINOR, BMINOR>(acc, As, Bs, wm, wn, lane);
+        __syncthreads();
+    }
+    // accumulator register r of tile (i, j) is row m0 + 64 wm + 32 i + acc_row(r), column n0 + 64 wn + 32 j + (lane & 31)
+    float* out = g.so.out + (int64_t)blockIdx.y * g.so.ks_stride + (int64_t)arm * g.so.arm_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
+                if (row < g.so.M && col < g.so.N) out[(int64_t)row * g.so.ld + col] = acc[i][j][r];
+            }
+        }
+}
+
+// fc11 forward + bias + reconstruction loss + dZ11.  The product is computed TRANSPOSED, z^T = W11 d10^T: MFMA rows are
+// genes and columns are cells, so a lane's four consecutive accumulator registers are four consecutive genes of one
+// cell -- 16 contiguous bytes of x, dZ11 and x_rec.  grid (cell tiles, gene splits NS, A): a block keeps its 128 cells'
+// d10 (both K tiles, bf16) in LDS and walks the 128-gene tiles of its gene range; the next W11 tile is requested from
+// memory before the epilogue of the current one.  K = fc_dim <= 128.
+__global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
+    const GemmArgs g = g_in;
+    __shared__ __attribute__((aligned(16))) unsigned Ws[2][BT * LDB];   // W11 tile: [gene][k], two K tiles
+    __shared__ __attribute__((aligned(16))) unsigned Ds[2][BT * LDB];   // d10 tile: [cell][k], two K tiles
+    __shared__ float red[8];
+    const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    Operand od = g.a, ow = g.b;                       // a: d10 [B][H]; b: W11 [D][H]
+    od.ptr += (int64_t)arm * g.a_arm;
+    ow.ptr += (int64_t)arm * g.b_arm;
+    const int c0 = blockIdx.x * BT;                    // cells of this block
+    const int tiles = cdiv(g.N, BT);                   // gene tiles
+    const int t0 = (int)(((int64_t)blockIdx.y * tiles) / g.KS), t1 = (int)(((int64_t)(blockIdx.y + 1) * tiles) / g.KS);
+    const int K = g.K;
+    const float* xa = g.fo.x + (int64_t)arm * g.fo_x_arm;
+    float* dza = g.fo.dz + (int64_t)arm * g.fo_arm;
+    float* xra = g.fo.x_rec ? g.fo.x_rec + (int64_t)arm * g.fo_arm : nullptr;
+    const float* bias = g.fo.bias + (int64_t)arm * g.bias_arm;
+    const int B = g.fo.B, D = g.fo.D;
+    {
+        TileRegsT<false> t0r, t1r;
+        tile_load<false, false>(t0r, od, c0, 0, K);
+        tile_load<false, false>(t1r, od, c0, KT, K);
+        tile_store<false, false>(Ds[0], t0r, od, c0, 0, K);
+        tile_store<false, false>(Ds[1], t1r, od, c0, KT, K);
+    }
+    TileRegsT<false> w0, w1;
+    if (t0 < t1) {
+        tile_load<false, false>(w0, ow, t0 * BT, 0, K);
+        tile_load<false, false>(w1, ow, t0 * BT, KT, K);
     }
     float se = 0.f;
     int mism = 0;
-    for (int nt = nt0; nt < nt1; ++nt) {
-        const int n0 = nt * BT;
-        f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
-        for (int k0 = kb; k0 < ke; k0 += KT) {
-            stage_operand(As, oa, m0, k0, ke);
-            stage_operand(Bs, ob, n0, k0, ke);
-            __syncthreads();
-            const unsigned* pa = As + (wm * 64 + l31) * LDB + 4 * hh;
-            const unsigned* pb = Bs + (wn * 64 + l31) * LDB + 4 * hh;
-#pragma unroll
-            for (int s = 0; s < KT / 16; ++s) {
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pa + 8 * s));
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pa + 32 * LDB + 8 * s));
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pb + 8 * s));
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(pb + 32 * LDB + 8 * s));
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-        // ---- epilogue of this tile: accumulator register r of tile (i, j) is row m0 + 64 wm + 32 i + acc_row(r),
-        //      column n0 + 64 wn + 32 j + (lane & 31)
-        if (!FC11) {
-            float* out = g.so.out + (int64_t)blockIdx.y * g.so.ks_stride + (int64_t)arm * g.so.arm_stride;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + 64 * wn + 32 * j + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
-                        if (row < g.so.M && col < g.so.N) out[(int64_t)row * g.so.ld + col] = acc[i][j][r];
-                    }
-                }
-        } else {
-            const float* xa = g.fo.x + (int64_t)arm * g.fo_x_arm;
-            float* dza = g.fo.dz + (int64_t)arm * g.fo_arm;
-            float* xra = g.fo.x_rec ? g.fo.x_rec + (int64_t)arm * g.fo_arm : nullptr;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + 64 * wn + 32 * j + l31;
-                    const float bj = g.fo.bias[(int64_t)arm * g.bias_arm + min(col, g.fo.D - 1)];
-                    float xin[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
-                        const bool ok = row < g.fo.B && col < g.fo.D;
-                        xin[r] = xa[(int64_t)(ok ? row : 0) * g.fo.D + (ok ? col : 0)];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
-                        const bool ok = row < g.fo.B && col < g.fo.D;
-                        const float xr = fmaxf(acc[i][j][r] + bj, 0.f);
-                        const float er = xr - xin[r];
-                        se += ok ? er * er : 0.f;
-                        mism += (ok && ((xr > 0.1f) != (xin[r] > 0.1f))) ? 1 : 0;
-                        if (ok) {
-                            dza[(int64_t)row * g.fo.D + col] = xr > 0.f ? g.fo.coef * er : 0.f;
-                            if (xra) xra[(int64_t)row * g.fo.D + col] = xr;
-                        }
-                    }
-                }
-        }
-    }
-    if (FC11) {
-        se = wave_sum(se);
-        const float mf = wave_sum((float)mism);
-        if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mf; }
+    for (int t = t0; t < t1; ++t) {
+        const int j0 = t * BT;
+        tile_store<false, false>(Ws[0], w0, ow, j0, 0, K);
+        tile_store<false, false>(Ws[1], w1, ow, j0, KT, K);
         __syncthreads();
-        if (tid == 0) {
-            float* p = g.fo.part + ((int64_t)arm * g.n11 + (int64_t)blockIdx.x * g.KS + blockIdx.y) * 2;
-            p[0] = red[0] + red[2] + red[4] + red[6];
-            p[1] = red[1] + red[3] + red[5] + red[7];
+        if (t + 1 < t1) {
+            tile_load<false, false>(w0, ow, j0 + BT, 0, K);
+            tile_load<false, false>(w1, ow, j0 + BT, KT, K);
         }
+        f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+        mfma_ktile<false, false>(acc, Ws[0], Ds[0], wm, wn, lane);
+        if (K > KT) mfma_ktile<false, false>(acc, Ws[1], Ds[1], wm, wn, lane);
+        // acc[i][j][4 q + e]: gene j0 + 64 wm + 32 i + 8 q + 4 hh + e, cell c0 + 64 wn + 32 j + (lane & 31)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cell = c0 + 64 * wn + 32 * j + l31;
+                const int64_t rowoff = (int64_t)min(cell, B - 1) * D;
+                float4 xin[4], b4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gene = j0 + 64 * wm + 32 * i + 8 * q + 4 * hh;
+                    const int gc = min(gene, D - 4);                      // D % 4 == 0
+                    xin[q] = *reinterpret_cast<const float4*>(xa + rowoff + gc);
+                    b4[q] = *reinterpret_cast<const float4*>(bias + gc);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gene = j0 + 64 * wm + 32 * i + 8 * q + 4 * hh;
+                    const bool ok = cell < B && gene < D;
+                    const float xv[4] = {xin[q].x, xin[q].y, xin[q].z, xin[q].w};
+                    const float bv[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
+                    float xr[4], dz[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        xr[e] = fmaxf(acc[i][j][4 * q + e] + bv[e], 0.f);
+                        const float er = xr[e] - xv[e];
+                        dz[e] = xr[e] > 0.f ? g.fo.coef * er : 0.f;
+                        se += ok ? er * er : 0.f;
+                        mism += (ok && ((xr[e] > 0.1f) != (xv[e] > 0.1f))) ? 1 : 0;
+                    }
+                    if (ok) {
+                        *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+                        if (xra) *reinterpret_cast<float4*>(xra + (int64_t)cell * D + gene) = make_float4(xr[0], xr[1], xr[2], xr[3]);
+                    }
+                }
+            }
+        __syncthreads();
+    }
+    se = wave_sum(se);
+    const float mf = wave_sum((float)mism);
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mf; }
+    __syncthreads();
+    if (tid == 0) {
+        float* p = g.fo.part + ((int64_t)arm * g.n11 + (int64_t)blockIdx.x * g.KS + blockIdx.y) * 2;
+        p[0] = red[0] + red[2] + red[4] + red[6];
+        p[1] = red[1] + red[3] + red[5] + red[7];
     }
 }
 
@@ -314,7 +411,7 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
     g.b_arm = c.po.per_arm;
     g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A;
     g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
-    hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+    hipLaunchKernelGGL((k_bf16_gemm<false, false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
     HIP_LAUNCH_CHECK("k_bf16_gemm<fc1>");
     return 0;
 }
@@ -333,13 +430,13 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.b = kmajor(params + c.po.o[26], d.H, d.D, d.H);      // W11 [D][H]
         g.b_arm = c.po.per_arm;
         g.bias_arm = c.po.per_arm;
-        g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.loop_n = 1; g.A = d.A; g.n11 = L.n11;
+        g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.A = d.A; g.n11 = L.n11;
         g.fo = Fc11Out{params + c.po.o[27], x, c.ws + L.DZ11, x_rec, c.ws + L.fc11_part,
                        (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D};
         g.fo_arm = (int64_t)d.B * d.D;
         g.fo_x_arm = xs;
-        hipLaunchKernelGGL((k_bf16_gemm<true>), dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
-        HIP_LAUNCH_CHECK("k_bf16_gemm<fc11>");
+        hipLaunchKernelGGL(k_bf16_fc11, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+        HIP_LAUNCH_CHECK("k_bf16_fc11");
     }
     if (need_grad && (which & 2)) {
         GemmArgs g{};
@@ -349,7 +446,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.b_arm = c.po.per_arm;
         g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A;
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
-        hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+        hipLaunchKernelGGL((k_bf16_gemm<false, true>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), NS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<gd10>");
     }
     return 0;
@@ -368,7 +465,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         if (use_mask) { g.b.bits = reinterpret_cast<const uint32_t*>(c.ws + L.xbits); g.b.wpr = cdiv(d.D, 32); g.b_bits_arm = (int64_t)d.B * g.b.wpr; }
         g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A;
         g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
-        hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+        hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW1>");
     }
     if (which & 2) {   // [dW11 | db11][j][h] = sum_b dZ11[b][j] [d10 | 1][b][h]
@@ -380,7 +477,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.b_arm = (int64_t)d.B * d.H;
         g.M = d.D; g.N = d.H + 1; g.K = d.B; g.KS = L.sp.ks_dw11; g.A = d.A;
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
-        hipLaunchKernelGGL((k_bf16_gemm<false>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+        hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW11>");
     }
     return 0;
