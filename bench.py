@@ -117,6 +117,80 @@ def cpu_baseline(args, D, H, L, C, S, A, B):
                                   "sample": f"{n_pre} steps, median; noise drawn once outside the timed region"}}
 
 
+def P_count(N, A, B, D, H, L, C, S):
+    lay = N.param_layout(N.Dims(A, B, D, H, L, C, S))
+    return sum(int(lay.rows[t]) * int(lay.cols[t]) for t in range(N.N_PARAM_TENSORS))
+
+
+def bf16_config(args, model_args, batches, nb, A, B, D, H, L, C, S, P, world, rank, dev, timed, DD, FusedAdam, mixVAE_model):
+    """BASELINE.json configs[2] (bf16 GEMM operands, data parallel over the node's GPUs): the same K timed steps with
+    ``gemm_dtype = "bf16"`` on a fresh model.  With the matrix pipe 16 x faster the step is priced against HBM: SURVEY.md
+    section 8(d)'s algorithmic bytes per cell with bf16 operands, A (10 D + 80 H + 36 P / B), times cells/s, over 8 TB/s."""
+    torch.manual_seed(546)
+    m = mixVAE_model(**model_args).to(dev)
+    m.train()
+    m.gemm_dtype = "bf16"
+    opt = FusedAdam(m, lr=1e-3)
+    if world > 1:
+        DD.broadcast_flat(m.flat_parameters())
+
+    def step(i):
+        xs = batches[i % nb].expand(A, -1, -1)
+        if world > 1 or args.rehearse_dp:
+            return DD.dp_train_step(m, xs, 1.0, opt, rehearse=args.rehearse_dp)
+        return m.fused_train_step(xs, 1.0, opt, do_adam=True)
+
+    dt, ev, loss = timed(step)
+    cells = world * B * args.steps / dt
+    by_cell = A * (10 * D + 80 * H + 36 * P / B)
+    out = {"value": cells, "unit": "cells/s", "ms_per_step": dt / args.steps * 1e3, "ms_per_step_hip_events": ev,
+           "dtype": "bf16 operands in the five D x H GEMMs, f32 accumulation and everything else", "n_gpus": world,
+           "last_loss": loss, "bytes_per_cell_algorithmic": by_cell,
+           "roofline": {"bound": "hbm", "achieved": cells / world * by_cell / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": cells / world * by_cell / 1e9 / PEAK_HBM_GBS,
+                        "note": "whole step, per GPU: algorithmic bytes per cell (SURVEY.md 8d, bf16 operands) x cells/s; "
+                                "this build keeps x and dZ11 in fp32 in HBM and rounds on load, so it moves more than that"}}
+    if rank == 0 and not args.no_roofline and (A, B, D, H) == (2, 5000, 5000, 100):
+        out["roofline"]["stages"] = measure_bf16_stages(m, batches[0], A, B, D, H)
+    return out
+
+
+def measure_bf16_stages(model, x, A, B, D, H):
+    """Per-launch duration of the five bf16 GEMM kernels (HIP events on the launch stream, mmvae_debug_stage replays) and
+    the HBM traffic they are priced by: fp32 bytes actually streamed per launch (x, dZ11, slabs) / duration."""
+    from distributed_vae_amd import _native as N
+    eng = model._engine
+    hyper = model._hyper(1.0, False)
+    noise = N.make_noise(None, 99, 1)
+    eng.forward(hyper, noise, model._flat, model._bn_flat, None, x, 0, None, True)
+    eng.loss(hyper)
+    eng.backward(hyper, noise, model._flat, x, 0, model._flat_grad)
+    stream = torch.cuda.current_stream()
+    sp = eng.splits()
+    # stage id: (kernel, bytes streamed per launch: inputs read once + outputs written once, x shared by the arms)
+    stages = {
+        14: ("k_bf16_gemm<fc1>", 4.0 * B * D + A * 4.0 * H * D + sp[0] * A * 4.0 * B * 128),
+        10: ("k_bf16_fc11", 4.0 * B * D + A * 4.0 * B * D + A * 4.0 * D * H),
+        11: ("k_bf16_gemm<d(d10)>", A * 4.0 * B * D + A * 4.0 * D * H + sp[4] * A * 4.0 * B * H),
+        12: ("k_bf16_gemm<dW1>", 4.0 * B * D + A * 4.0 * B * H + sp[2] * A * 4.0 * H * D),
+        13: ("k_bf16_gemm<dW11>", A * 4.0 * B * D + A * 4.0 * B * H + sp[5] * A * 4.0 * D * 132),
+    }
+    res = {}
+    for sid, (name, by) in stages.items():
+        for _ in range(3):
+            eng.debug_stage(sid, hyper, noise, model._flat, x, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(20):
+            eng.debug_stage(sid, hyper, noise, model._flat, x, 0)
+        e1.record(stream)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        res[name] = {"avg_launch_ms": ms, "streamed_GBs": by / ms / 1e6, "frac_of_hbm_peak": by / ms / 1e6 / PEAK_HBM_GBS,
+                     "tflops": A * 2.0 * B * D * H / ms / 1e9}
+    return res
+
+
 def spawn_ranks(n: int, share_gpu: bool = False) -> int:
     """--gpus N without a launcher: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
     environment) and wait for them.  This process has not initialised the GPU (counting devices does not), and it never
@@ -155,6 +229,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-operand configuration measured beside the headline")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
     ap.add_argument("--gemm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="operand type of the five D x H GEMMs: fp32 (the headline / parity configuration) or bf16 "
@@ -216,9 +291,10 @@ def main():
     A, B, D = args.arms, args.batch, args.genes
     H, L, C, S = 100, 10, 92, 2
     torch.manual_seed(546)
-    model = mixVAE_model(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0,
-                         n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev,
-                         eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE").to(dev)
+    model_args = dict(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0,
+                      n_arm=A, lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev,
+                      eps=1e-8, momentum=0.01, ref_prior=False, loss_mode="MSE")
+    model = mixVAE_model(**model_args).to(dev)
     model.train()
     model.gemm_dtype = args.gemm_dtype
     opt = FusedAdam(model, lr=1e-3)
@@ -235,34 +311,37 @@ def main():
             return DD.dp_train_step(model, xs, 1.0, opt, rehearse=args.rehearse_dp)
         return model.fused_train_step(xs, 1.0, opt, do_adam=True)
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # per-step HIP events on the stream the step is launched on (torch's current stream): the median step period beside
-    # the wall-clock mean that `value` is computed from
-    stream = torch.cuda.current_stream(dev)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    evs[0].record(stream)
-    for i in range(args.steps):
-        buf = step(args.warmup + i)
-        evs[i + 1].record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
-    loss_last = float(buf[0])
-    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
-    ev_stats = {"median": per_step[len(per_step) // 2], "min": per_step[0], "max": per_step[-1],
-                "p10": per_step[len(per_step) // 10], "p90": per_step[(9 * len(per_step)) // 10], "n": len(per_step)}
+    def timed(step_fn):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for i in range(args.warmup):
+            step_fn(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # per-step HIP events on the stream the step is launched on (torch's current stream): the median step period
+        # beside the wall-clock mean that `value` is computed from (SURVEY.md section 8d)
+        stream = torch.cuda.current_stream(dev)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for i in range(args.steps):
+            buf_ = step_fn(args.warmup + i)
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        stats = {"median": per[len(per) // 2], "min": per[0], "max": per[-1], "p10": per[len(per) // 10],
+                 "p90": per[(9 * len(per)) // 10], "n": len(per)}
+        return float(tmax), stats, float(buf_[0])
+
+    dt, ev_stats, loss_last = timed(step)
 
     P = 0
     lay = N.param_layout(N.Dims(A, B, D, H, L, C, S))
@@ -304,6 +383,13 @@ def main():
     }
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks
+    if args.gemm_dtype == "fp32" and not args.no_bf16:
+        # BASELINE.json configs[2] beside the headline: the same step with bf16 operands in the five D x H GEMMs
+        try:
+            out["bf16_config"] = bf16_config(args, model_args, batches, nb, A, B, D, H, L, C, S, P_count(N, A, B, D, H, L, C, S),
+                                             world, rank, dev, timed, DD, FusedAdam, mixVAE_model)
+        except Exception as e:   # noqa: BLE001
+            out["bf16_config"] = {"error": f"{type(e).__name__}: {e}"}
     if roof is not None:
         out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -544,37 +630,52 @@ def measure_stages(model, x, A, B, D, H):
     return out
 
 
-def pmc_mfma_busy(kernel, A, B, D, H):
-    """Matrix-pipe utilisation of `kernel` from the committed PMC pass (profiles/r01_pmc_mfma_summary.csv):
-    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), and the shader clock the kernel ran at
-    (SQ_BUSY_CU_CYCLES / 256 CUs / its duration in the same pass is not recorded there, so the clock is derived from
-    this run's launch time).  Only for the shape the pass was collected on."""
+PMC_ROUND = "r02"
+
+
+def _pmc_rows(kind, A, B, D, H):
+    """Rows of the committed PMC summary of this round (profiles/<round>_pmc_<kind>_summary.csv), or None when it was
+    not collected on this shape or -- checked through the hash the collection recorded in profiles/<round>_pmc_meta.json
+    -- with different kernel sources than the ones being run (counters cannot be read from inside the process, so a
+    stale file would otherwise be reported as if it described the current kernels)."""
     import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mfma_summary.csv")
-    if (A, B, D, H) != (2, 5000, 5000, 100) or not os.path.exists(path):
-        return None
-    for r in csv.DictReader(open(path)):
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(root, "profiles", f"{PMC_ROUND}_pmc_{kind}_summary.csv")
+    meta = os.path.join(root, "profiles", f"{PMC_ROUND}_pmc_meta.json")
+    if (A, B, D, H) != (2, 5000, 5000, 100) or not os.path.exists(path) or not os.path.exists(meta):
+        return None, None
+    want = json.load(open(meta)).get("sources_sha256", {})
+    for rel, sha in want.items():
+        f = os.path.join(root, rel)
+        if not os.path.exists(f) or hashlib.sha256(open(f, "rb").read()).hexdigest() != sha:
+            return None, None
+    return list(csv.DictReader(open(path))), f"profiles/{PMC_ROUND}_pmc_{kind}_summary.csv"
+
+
+def pmc_mfma_busy(kernel, A, B, D, H):
+    """Matrix-pipe utilisation of `kernel` from the committed PMC pass: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x
+    SQ_BUSY_CU_CYCLES).  Only for the shape and the kernel sources the pass was collected on."""
+    rows, src = _pmc_rows("mfma", A, B, D, H)
+    for r in rows or []:
         if r["kernel"].startswith(kernel) and r.get("SQ_VALU_MFMA_BUSY_CYCLES") and r.get("SQ_BUSY_CU_CYCLES"):
             cu = float(r["SQ_BUSY_CU_CYCLES"])
             return {"pipe_busy_frac": float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * cu), "busy_cu_cycles_per_launch": cu,
-                    "source": "profiles/r01_pmc_mfma_summary.csv"}
+                    "source": src}
     return None
 
 
 def pmc_traffic(kernel, A, B, D, H):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_hbm_summary.csv, made
-    by tools/pmc_summary.py from two separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this
-    bench command). PMC counters cannot be read from inside the process, so the number is only reported for
-    the shape it was collected on; FETCH_SIZE (KB) is doubled as the gfx950 guide prescribes for 16-byte-per-
-    lane loads -- which is how k_fc11_zg and k_fc1_fwd_v3 read x and the weights -- and WRITE_SIZE (KB) is
-    taken as is.  Other kernels: null (their load widths are uncalibrated)."""
-    import csv
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_summary.csv")
-    if (A, B, D, H) != (2, 5000, 5000, 100) or kernel not in ("k_fc11_zg", "k_fc1_fwd_v3") or not os.path.exists(path):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (two separate `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` runs of this bench command, summarised by tools/pmc_summary.py).  FETCH_SIZE (KB) is doubled as
+    the gfx950 guide prescribes for 16-byte-per-lane loads -- which is how k_fc11_zg and k_fc1_fwd_v3 read x and the
+    weights -- and WRITE_SIZE (KB) is taken as is.  Other kernels: null (their load widths are uncalibrated)."""
+    if kernel not in ("k_fc11_zg", "k_fc1_fwd_v3"):
         return None, None
-    for r in csv.DictReader(open(path)):
+    rows, src = _pmc_rows("hbm", A, B, D, H)
+    for r in rows or []:
         if r["kernel"].startswith(kernel) and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
-            return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0, "profiles/r01_pmc_hbm_summary.csv"
+            return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0, src
     return None, None
 
 

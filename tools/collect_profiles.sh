@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collect this round's measurement artefacts ON the GPU box (run from the repo root through gpurun); writes
+# gpurun_out/<round>/..., which the builder then copies into profiles/.
+#   tools/collect_profiles.sh r02
+R=${1:-r02}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-eval --no-roofline --no-bf16"
+# 1. kernel stats of the fp32 train step and of the bf16 configuration
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_fp32 -- $BENCH > $OUT/kstats_fp32.json 2> $OUT/kstats_fp32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_bf16 -- $BENCH --gemm-dtype bf16 > $OUT/kstats_bf16.json 2> $OUT/kstats_bf16.err
+cp $(find $OUT/kstats_fp32 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
+cp $(find $OUT/kstats_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_bf16_kernel_stats.csv
+# 2. PMC passes (own runs, counters only): HBM traffic, matrix-pipe utilisation
+SHORT="python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval --no-roofline --no-bf16"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $SHORT > /dev/null 2> $OUT/pmc_$c.err
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmcb_$c -- $SHORT --gemm-dtype bf16 > /dev/null 2> $OUT/pmcb_$c.err
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_mfma1 -- $SHORT > /dev/null 2> $OUT/pmc_mfma1.err
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma2 -- $SHORT > /dev/null 2> $OUT/pmc_mfma2.err
+cd $ROOT
+python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE > $OUT/${R}_pmc_hbm_summary.csv
+python3 tools/pmc_summary.py $OUT/pmcb_FETCH_SIZE $OUT/pmcb_WRITE_SIZE > $OUT/${R}_pmc_hbm_bf16_summary.csv
+python3 tools/pmc_summary.py $OUT/pmc_mfma1 $OUT/pmc_mfma2 > $OUT/${R}_pmc_mfma_summary.csv
+python3 - <<PY
+import hashlib, json
+srcs = ["distributed-vae_amd/csrc/gemm_fast.hip", "distributed-vae_amd/csrc/common.hpp"]
+json.dump({"sources_sha256": {s: hashlib.sha256(open(s, "rb").read()).hexdigest() for s in srcs},
+           "command": "tools/collect_profiles.sh $R"}, open("$OUT/${R}_pmc_meta.json", "w"), indent=1)
+PY
+# drop the bulky raw traces from what travels back (keep the summaries)
+rm -rf $OUT/kstats_fp32 $OUT/kstats_bf16 $OUT/pmc_* $OUT/pmcb_*
+ls -la $OUT
