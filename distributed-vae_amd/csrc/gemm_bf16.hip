@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
                         if (xra) *reinterpret_cast<float4*>(xra + (int64_t)cell * D + gene) = make_float4(xr[0], xr[1], xr[2], xr[3]);
                     }
                 }
+                // piece fence: without it the scheduler requests the x / bias values of all four (i, j) pieces up front
+                // (128 registers on top of the accumulators and the W11 tile in flight) and spills
+                asm volatile("" : "+v"(mism), "+v"(se));
+                __builtin_amdgcn_sched_barrier(0);
             }
         __syncthreads();
     }
