@@ -79,7 +79,7 @@ TUNE_ENV = {
     "MMVAE_AUG_TILE": (3, int), "MMVAE_ABLATE_C": (4, int), "MMVAE_ABLATE": (5, int), "MMVAE_PADLDS": (6, int),
     "MMVAE_FC1_V2": (7, int), "MMVAE_FC11_ZG": (8, lambda v: int(int(v) == 0)), "MMVAE_ABLATE_Z": (9, int),
     "MMVAE_FC11_NSZ": (10, int), "MMVAE_GD10_V2": (11, int), "MMVAE_DW1_V2": (12, int), "MMVAE_DW11_V2": (13, int),
-    "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int),
+    "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_ABLATE_B": (16, int),
 }
 
 
@@ -156,7 +156,7 @@ def lib():
     L.mmvae_aug_workspace_bytes.argtypes = [C.POINTER(AugDims), i32]
     L.mmvae_aug_workspace_bytes.restype = C.c_size_t
     L.mmvae_aug_pack.argtypes = [C.POINTER(AugDims), C.POINTER(AugTensors), vp, vp]
-    L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, ex, vp]
+    L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, i32, ex, vp]
     L.mmvae_gather_rows.argtypes = [vp, i64, i64, vp, i64, i32, vp, vp]
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_splits", "mmvae_forward", "mmvae_loss",
                "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",

@@ -42,6 +42,7 @@ class Augmenter_smartseq(nn.Module):
             setattr(self, "batch_" + name, bn(o))
         self.fc11 = nn.Linear(n1, input_dim)
         self._dims = (input_dim, n1, n_dim, n5, latent_dim, noise_dim)
+        self.gemm_dtype = "fp32"          # "bf16": bf16 operands in the ten large Linear layers (fp32 accumulation)
         self._packed: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._explicit = None
@@ -147,7 +148,8 @@ class Augmenter_smartseq(nn.Module):
             out = torch.empty(A, B, D, dtype=torch.float32, device=xt.device)
         N.check(N.lib().mmvae_augment(C.byref(dims), N._ptr(self._packed), N._ptr(xt), xs, N._ptr(z0), N._ptr(eps),
                                       float(scale), N._ptr(self._ws), self._ws.numel() * 4, N._ptr(s), N._ptr(out),
-                                      C.byref(self._exec()), N._stream(xt.device)), "mmvae_augment")
+                                      int(self.gemm_dtype == "bf16"), C.byref(self._exec()), N._stream(xt.device)),
+                "mmvae_augment")
         return (s, out) if batched else (s[0], out[0])
 
 

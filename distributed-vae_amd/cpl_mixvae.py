@@ -133,6 +133,8 @@ class cpl_mixVAE:
         """Install an ``Augmenter_smartseq`` (distributed_vae_amd.augmentation) in eval mode on the trainer's device,
         as cpl_mixvae.py:184; ``None`` returns to raw ``x.expand``."""
         self.netA = None if netA is None else netA.to(self.device).eval()
+        if self.netA is not None and getattr(self, "model", None) is not None:
+            self.netA.gemm_dtype = self.model.gemm_dtype     # the bf16 configuration covers the augmenter's GEMMs too
 
     def init_model(self, n_categories, state_dim, input_dim, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.2,
                    lr=0.001, lam=1, lam_pc=1, n_arm=2, temp=1.0, tau=0.005, beta=1.0, hard=False, variational=True,
@@ -154,6 +156,8 @@ class cpl_mixVAE:
                                   loss_mode=mode)
         self.model = self.model.to(self.device)
         self.model.gemm_dtype = gemm_dtype
+        if self.netA is not None:
+            self.netA.gemm_dtype = gemm_dtype
         self.optimizer = FusedAdam(self.model, lr=lr)
         if len(trained_model) > 0:
             loaded = torch.load(trained_model, map_location="cpu", weights_only=True)

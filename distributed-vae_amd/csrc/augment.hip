@@ -377,6 +377,8 @@ static int aug_gemm(hipStream_t s, int force_tile, bool relu, bool affine, const
     const float* W = pk + g.w;
     const float* sc = pk + g.sc;
     const float* sh = pk + g.sh;
+    if (force_tile == 99)   // bf16 operands (mmvae_augment's gemm_bf16): the shared bf16 tile engine, fp32 epilogue
+        return launch_bf16_affine(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.ldw, sc, sh, C, ldc, ncols);
     // the largest tile that still leaves two workgroups per CU (256 CUs); MMVAE_AUG_TILE=<BM><BN> code forces one
     const int force = force_tile;   // 11 12 21 22 (1 = 64, 2 = 128), 0 = automatic
     auto count = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(ncols, bn); };
@@ -469,7 +471,7 @@ int mmvae_aug_pack(const mmvae_aug_dims* d, const mmvae_aug_tensors* t, float* p
 
 int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, int64_t x_arm_stride, const float* z0,
                   const float* eps_n, float scale, void* ws, size_t ws_bytes, float* s_out, float* x_aug,
-                  const mmvae_exec* ex, void* stream) {
+                  int gemm_bf16, const mmvae_exec* ex, void* stream) {
     if (int rc = aug_check_dims(d)) return rc;
     if (!packed || !x || !z0 || !eps_n || !ws || !s_out || !x_aug) { set_error("augment: null argument"); return MMVAE_E_BADARG; }
     const bool shared = x_arm_stride == 0;
@@ -483,7 +485,7 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     const AugPacked L = aug_packed_layout(*d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* w = reinterpret_cast<float*>(ws);
-    const int ft = ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0;
+    const int ft = gemm_bf16 ? 99 : (ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0);
     int rc;
     // trunk: once per cell when the arms share x
     if ((rc = aug_gemm(s, ft, true, true, x, d->D, T, packed, L.g[0], w + W.h1, W.ld1))) return rc;

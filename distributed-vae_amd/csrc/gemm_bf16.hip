@@ -214,6 +214,12 @@ struct Fc11Out {       // z tile -> + bias, dZ11, loss partials (nn_model.py:286
     int B, D;
 };
 
+struct AffineOut {     // C tile -> out[m][n] = act(C * scale[n] + shift[n]) (the augmenter's Linear + folded BatchNorm + ReLU);
+    const float *scale, *shift;   // columns N .. ld - 1 (the next layer's K padding) are written as zeros
+    float* out;
+    int ld, M, N, relu, affine;
+};
+
 struct GemmArgs {
     Operand a, b;
     int64_t a_arm, b_arm;        // arm strides of the operands (floats); mask bits: a_bits_arm / b_bits_arm (words)
@@ -223,6 +229,8 @@ struct GemmArgs {
     int KS;                      // splits of the k range (grid.y) -- or of the n tiles when loop_n
     SlabOut so;
     Fc11Out fo;
+    AffineOut ao;
+    int ablate;                  // timing experiments (MMVAE_TUNE_ABLATE_B): 1 no MFMAs, 2 no global loads, 4 no LDS stores
     int64_t fo_arm, fo_x_arm;    // arm strides of dz / x_rec and of x (0: the arms share x)
     int n11;
     int A;
@@ -246,7 +254,7 @@ __device__ __forceinline__ void mfma_ktile(f32x16 (&acc)[2][2], const unsigned* 
 
 // C tile -> slab.  grid (tiles_m * tiles_n, KS, A): block (m tile, n tile) x k range ks x arm.  Tile t + 1 is requested
 // from memory before tile t's MFMAs and written to LDS after them: two barriers per K tile, loads always in flight.
-template <bool AMINOR, bool BMINOR>
+template <bool AMINOR, bool BMINOR, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const GemmArgs g = g_in;
     __shared__ __attribute__((aligned(16))) unsigned As[BT * LDB];
@@ -259,28 +267,63 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     if (oa.bits) oa.bits += (int64_t)arm * g.a_bits_arm;
     if (ob.bits) ob.bits += (int64_t)arm * g.b_bits_arm;
     const int tiles_n = cdiv(g.N, BT);
-    const int m0 = (blockIdx.x / tiles_n) * BT, n0 = (blockIdx.x % tiles_n) * BT;
+    int wg = blockIdx.x;
+    if (EPI == 1) {   // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x a contiguous range of tiles
+        const int nwg = gridDim.x;
+        if (nwg % 8 == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+    }
+    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * BT;
     const int nkt = cdiv(g.K, KT);
     const int kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KT;
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegs ta, tb;
-    if (kb < ke) {
+    if (g.ablate & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { ta.v[i][h] = tb.v[i][h] = make_float4(1.f, 2.f, 3.f, 4.f); ta.wd[i][h] = tb.wd[i][h] = ~0u; }
+    }
+    if (kb < ke && !(g.ablate & 2)) {
         tile_load<AMINOR>(ta, oa, m0, kb, ke);
         tile_load<BMINOR>(tb, ob, n0, kb, ke);
     }
     for (int k0 = kb; k0 < ke; k0 += KT) {
-        tile_store<AMINOR>(As, ta, oa, m0, k0, ke);
-        tile_store<BMINOR>(Bs, tb, ob, n0, k0, ke);
+        if (!(g.ablate & 4)) {
+            tile_store<AMINOR>(As, ta, oa, m0, k0, ke);
+            tile_store<BMINOR>(Bs, tb, ob, n0, k0, ke);
+        }
         __syncthreads();
-        if (k0 + KT < ke) {
+        if (k0 + KT < ke && !(g.ablate & 2)) {
             tile_load<AMINOR>(ta, oa, m0, k0 + KT, ke);
             tile_load<BMINOR>(tb, ob, n0, k0 + KT, ke);
         }
-        mfma_ktile<AMINOR, BMINOR>(acc, As, Bs, wm, wn, lane);
+        if (!(g.ablate & 1)) mfma_ktile<AMINOR, BMINOR>(acc, As, Bs, wm, wn, lane);
         __syncthreads();
     }
     // accumulator register r of tile (i, j) is row m0 + 64 wm + 32 i + acc_row(r), column n0 + 64 wn + 32 j + (lane & 31)
+    if (EPI == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + l31;
+            if (col >= g.ao.ld) continue;
+            const bool real = col < g.ao.N;
+            const float sc = (g.ao.affine && real) ? g.ao.scale[col] : 1.f;
+            const float sh = (g.ao.affine && real) ? g.ao.shift[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + 64 * wm + 32 * i + acc_row(r, lane);
+                    if (row < g.ao.M) {
+                        float v = acc[i][j][r] * sc + sh;
+                        if (g.ao.relu) v = fmaxf(v, 0.f);
+                        g.ao.out[(int64_t)row * g.ao.ld + col] = real ? v : 0.f;
+                    }
+                }
+        }
+        return;
+    }
     float* out = g.so.out + (int64_t)blockIdx.y * g.so.ks_stride + (int64_t)arm * g.so.arm_stride;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -413,7 +456,7 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
     if (use_mask) { g.a.bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits); g.a.wpr = cdiv(d.D, 32); g.a_bits_arm = (int64_t)d.B * g.a.wpr; }
     g.b = kmajor(params + c.po.o[0], d.D, d.H, d.D);
     g.b_arm = c.po.per_arm;
-    g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A;
+    g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
     g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
     hipLaunchKernelGGL((k_bf16_gemm<false, false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
     HIP_LAUNCH_CHECK("k_bf16_gemm<fc1>");
@@ -448,7 +491,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.a_arm = (int64_t)d.B * d.D;
         g.b = kminor(params + c.po.o[26], d.H, d.H, d.D);      // W11 [D][H] read as B[n = h][k = j]
         g.b_arm = c.po.per_arm;
-        g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A;
+        g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
         hipLaunchKernelGGL((k_bf16_gemm<false, true>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), NS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<gd10>");
@@ -467,7 +510,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.b = kminor(x, d.D, d.D, d.B);
         g.b_arm = xs;
         if (use_mask) { g.b.bits = reinterpret_cast<const uint32_t*>(c.ws + L.xbits); g.b.wpr = cdiv(d.D, 32); g.b_bits_arm = (int64_t)d.B * g.b.wpr; }
-        g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A;
+        g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
         g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
         hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW1>");
@@ -479,11 +522,24 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.b = kminor(c.ws + L.Dk[4], d.H, d.H, d.B);
         g.b.ones_row = d.H;                                      // logical row H (not in memory) reads 1: the bias gradient
         g.b_arm = (int64_t)d.B * d.H;
-        g.M = d.D; g.N = d.H + 1; g.K = d.B; g.KS = L.sp.ks_dw11; g.A = d.A;
+        g.M = d.D; g.N = d.H + 1; g.K = d.B; g.KS = L.sp.ks_dw11; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
         hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW11>");
     }
+    return 0;
+}
+
+// C[M][ld] = act((A[M][K] . W[N][K]^T) * scale + shift): the augmenter's layers with bf16 operands (augment.hip)
+int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw, int N,
+                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols) {
+    GemmArgs g{};
+    g.a = kmajor(A, lda, M, Kpad);        // rows are zero-padded to Kpad = pad4(K) floats on both sides
+    g.b = kmajor(W, ldw, N, Kpad);
+    g.M = M; g.N = ncols; g.K = Kpad; g.KS = 1; g.A = 1;
+    g.ao = AffineOut{sc, sh, C, ldc, M, N, relu ? 1 : 0, affine ? 1 : 0};
+    hipLaunchKernelGGL((k_bf16_gemm<false, false, 1>), dim3(cdiv(M, BT) * cdiv(ncols, BT), 1, 1), dim3(256), 0, s, g);
+    HIP_LAUNCH_CHECK("k_bf16_gemm<affine>");
     return 0;
 }
 

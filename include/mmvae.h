@@ -128,6 +128,7 @@ enum {
     MMVAE_TUNE_DW11_V2,
     MMVAE_TUNE_ABLATE_L,           /* latent kernels: ablations                                       */
     MMVAE_TUNE_LAT_FULLWAVE,       /* latent kernels: one wave per cell instead of the half-wave layout */
+    MMVAE_TUNE_ABLATE_B,           /* bf16 GEMM engine: 1 no MFMAs, 2 no global loads, 4 no LDS stores (results wrong)  */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {
@@ -305,10 +306,12 @@ int mmvae_aug_pack(const mmvae_aug_dims *d, const mmvae_aug_tensors *t, float *p
 /* x: [B,D] shared by the arms (x_arm_stride == 0, as x.expand) or [A,B,D] contiguous (x_arm_stride == B*D).
  * z0: [A,B,NZ] and eps: [A,B,Z] standard-normal draws (the reference's torch.randn / randn_like); scale: the
  * noise scale (0.1 in the trainer).  Outputs: s_out [A,B,Z] (forward out 0), x_aug [A,B,D] (forward out 1),
- * ready as the per-arm input of mmvae_train_step (x_arm_stride = B*D). */
+ * ready as the per-arm input of mmvae_train_step (x_arm_stride = B*D).  gemm_bf16 != 0: the ten large Linear layers
+ * take bf16 operands with fp32 accumulation (BASELINE.json's bf16 configuration); the latent block, the folded
+ * BatchNorm / ReLU epilogues and all stored activations stay fp32. */
 int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, int64_t x_arm_stride,
                   const float *z0, const float *eps, float scale, void *ws, size_t ws_bytes, float *s_out,
-                  float *x_aug, const mmvae_exec *ex, void *stream);
+                  float *x_aug, int gemm_bf16, const mmvae_exec *ex, void *stream);
 
 /* ---- device-resident data path ------------------------------------
  * out[i, :] = data[idx[i], :], i < n: the batch assembly of the reference's DataLoader

@@ -38,21 +38,37 @@ def _lin(v, sd, name):
     return F.linear(v, sd[name + ".weight"], b)
 
 
-def forward_eval(sd: Dict[str, torch.Tensor], x: torch.Tensor, z0: torch.Tensor, eps: torch.Tensor, scale: float = 1.0):
-    """x: [..., D]; z0: [..., noise_dim]; eps: [..., latent_dim] -> (s [..., latent_dim], x_aug [..., D])."""
+def forward_eval(sd: Dict[str, torch.Tensor], x: torch.Tensor, z0: torch.Tensor, eps: torch.Tensor, scale: float = 1.0,
+                 gemm_round=None):
+    """x: [..., D]; z0: [..., noise_dim]; eps: [..., latent_dim] -> (s [..., latent_dim], x_aug [..., D]).
+
+    ``gemm_round`` (None = the reference's arithmetic): a function applied to BOTH operands of the ten large Linear
+    products -- fc1..fc4, the activation part of fc5, fc7..fc11 -- to state what the bf16-operand configuration of the
+    HIP path computes (operands rounded to bf16, exact products, wide accumulation); biases, BatchNorm, the noise branch,
+    the noise part of fc5, the heads and fc6 are untouched."""
+    def lin(v, name):
+        if gemm_round is None:
+            return _lin(v, sd, name)
+        return F.linear(gemm_round(v), gemm_round(sd[name + ".weight"]), sd.get(name + ".bias"))
     z = F.elu(_bn(_lin(scale * z0, sd, "noise"), sd, "bnz", EPS_BNZ, affine=True))
     h = x
     for i in (1, 2, 3, 4):
-        h = F.relu(_bn(_lin(h, sd, f"fc{i}"), sd, f"batch_fc{i}", EPS_BN))
-    h = torch.cat((h, z), dim=-1)
-    h = F.relu(_bn(_lin(h, sd, "fc5"), sd, "batch_fc5", EPS_BN))
+        h = F.relu(_bn(lin(h, f"fc{i}"), sd, f"batch_fc{i}", EPS_BN))
+    if gemm_round is None:
+        h = torch.cat((h, z), dim=-1)
+        h5 = _lin(h, sd, "fc5")
+    else:
+        n = h.shape[-1]
+        w5 = sd["fc5.weight"]
+        h5 = F.linear(gemm_round(h), gemm_round(w5[:, :n])) + F.linear(z, w5[:, n:]) + sd["fc5.bias"]
+    h = F.relu(_bn(h5, sd, "batch_fc5", EPS_BN))
     mu = _bn(_lin(h, sd, "fc_mu"), sd, "batch_fc_mu", EPS_BN)
     sigma = torch.sigmoid(_lin(h, sd, "fc_sigma"))
     s = eps * sigma + mu
-    h = s
-    for i in (6, 7, 8, 9, 10):
-        h = F.relu(_bn(_lin(h, sd, f"fc{i}"), sd, f"batch_fc{i}", EPS_BN))
-    return s, F.relu(_lin(h, sd, "fc11"))
+    h = F.relu(_bn(_lin(s, sd, "fc6"), sd, "batch_fc6", EPS_BN))
+    for i in (7, 8, 9, 10):
+        h = F.relu(_bn(lin(h, f"fc{i}"), sd, f"batch_fc{i}", EPS_BN))
+    return s, F.relu(lin(h, "fc11"))
 
 
 def random_state_dict(noise_dim, latent_dim, input_dim, n_dim, seed=0, dtype=torch.float32):

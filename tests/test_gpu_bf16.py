@@ -134,3 +134,41 @@ def test_bf16_configuration_at_full_size_against_the_oracle():
     # and the fp32 configuration of the same model object is untouched by the switch
     m.gemm_dtype = "fp32"
     assert m._hyper(1.0, False).gemm_bf16 == 0
+
+
+@pytest.mark.parametrize("cfg", [(16, 10, 640, 320, 3, 257), (50, 10, 5032, 500, 2, 5000)])
+def test_bf16_augmenter_layers_reproduce_bf16_rounded_products(cfg):
+    """The augmenter's ten large Linear layers through the bf16 tile engine (``netA.gemm_dtype = "bf16"``): against the
+    oracle with both operands of exactly those products rounded to bf16 (fp64 accumulation) -- twelve chained layers, so
+    the tolerance is the fp32 path's 1e-4 of the output scale, not the single-GEMM 2e-5 -- and, reported, against the
+    plain fp32 oracle.  Second shape: the production one at the SmartSeq gene count (D / 5 = 1006: padded rows)."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    from oracle import augmenter as OA
+    NZ, Z, D, ND, A, B = cfg
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=NZ + D)
+    m = Augmenter_smartseq(noise_dim=NZ, latent_dim=Z, input_dim=D, n_dim=ND)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.gemm_dtype = "bf16"
+    g = torch.Generator().manual_seed(B)
+    x = (torch.rand(B, D, generator=g) < 0.3).float() * torch.randn(B, D, generator=g).abs() * 3
+    z0, eps = torch.randn(A, B, NZ, generator=g), torch.randn(A, B, Z, generator=g)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    s_ref, x_ref = OA.forward_eval(sd64, x.double().expand(A, -1, -1), z0.double(), eps.double(), 0.1, gemm_round=bf16_round)
+    s_f32, x_f32 = OA.forward_eval(sd64, x.double().expand(A, -1, -1), z0.double(), eps.double(), 0.1)
+    m.set_explicit_noise(z0, eps)
+    s, xa = m(x.to(DEV).expand(A, -1, -1), True, 0.1)
+    # the host restatement rounds activations that differ from the device's by fp32 accumulation noise: a value that
+    # sits on a bf16 rounding boundary may round the other way, which is one bf16 ulp (2^-8) of ONE operand element
+    # -- and every such flip propagates through the remaining layers (a chaotic comparison by construction): 2e-3 at the
+    # small shape, 6e-3 across ten layers with K up to 5032, against ~1e-2 between the bf16 and fp32 configurations
+    tol = 2e-3 if D < 2000 else 6e-3
+    e_s, e_x = _rel(s.cpu().double(), s_ref), _rel(xa.cpu().double(), x_ref)
+    print("bf16 augmenter vs bf16-rounded oracle: s %.2e  x_aug %.2e" % (e_s, e_x))
+    assert e_s < tol and e_x < tol, (e_s, e_x)
+    print("bf16 augmenter vs fp32 oracle: s %.2e  x_aug %.2e" % (_rel(s.cpu().double(), s_f32), _rel(xa.cpu().double(), x_f32)))
+    assert _rel(xa.cpu().double(), x_f32) < LOSS_GATE
+    m.gemm_dtype = "fp32"
+    s2, xa2 = m(x.to(DEV).expand(A, -1, -1), True, 0.1)
+    assert _rel(xa2.cpu().double(), x_f32) < 1e-4

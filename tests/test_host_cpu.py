@@ -180,7 +180,7 @@ def test_widened_entry_points_validate_arguments_on_the_host():
     assert L.mmvae_aug_packed_floats(C.byref(N.AugDims(2, 100, 5000, 1000, 1000, 200, 10, 50))) == 0     # n/5 > 128
     assert L.mmvae_aug_packed_floats(C.byref(N.AugDims(2, 100, 400, 80, 640, 128, 64, 128))) == 0        # LDS
     assert L.mmvae_aug_pack(C.byref(ok), None, None, None) == -1
-    assert L.mmvae_augment(C.byref(ok), None, None, 0, None, None, 0.1, None, 0, None, None, None, None) == -1
+    assert L.mmvae_augment(C.byref(ok), None, None, 0, None, None, 0.1, None, 0, None, None, 0, None, None) == -1
     # data path
     assert L.mmvae_gather_rows(None, 8, 4, None, 2, 8, None, None) == -1
     # eval labels: needs eval mode
