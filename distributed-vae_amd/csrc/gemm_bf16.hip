@@ -75,101 +75,110 @@ struct TileRegsT {
 };
 typedef TileRegsT<true> TileRegs;
 
+// quad q of a tile (q < 8): KMAJOR row pass p = q >> 1, k half h = q & 1; KMINOR k-pair group i = q >> 1, k parity h = q & 1
+// Loads go through buffer instructions: the operand's base sits in an SGPR descriptor and a piece is addressed by ONE
+// 32-bit per-lane byte offset computed where it is used (two integer ops), so no 64-bit pointers stay live across the
+// pipeline (sixteen of them per thread cost 32 VGPRs and pushed the kernel into scratch).  Offsets are clamped into the
+// matrix; what must read as zero is selected at the LDS store.  Every operand has ld % 4 == 0 and < 4 GB per arm.
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_t;
+struct OperandDev {
+    __amdgpu_buffer_rsrc_t rs, rb;   // matrix, mask words
+    int ld, rows, K, wpr, ones_row;
+    bool bits;
+};
+template <bool KMINOR>
+__device__ __forceinline__ OperandDev make_operand_dev(const Operand& o) {
+    OperandDev d;
+    const int64_t n = KMINOR ? (int64_t)o.K * o.ld : (int64_t)o.rows * o.ld;
+    d.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.ptr), 0, (int)(n * 4), 0x00020000);
+    d.bits = o.bits != nullptr;
+    const int64_t nb = (KMINOR ? (int64_t)o.K : (int64_t)o.rows) * o.wpr;
+    d.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(d.bits ? o.bits : reinterpret_cast<const uint32_t*>(o.ptr)), 0,
+                                             (int)((d.bits ? nb : 1) * 4), 0x00020000);
+    d.ld = (int)o.ld; d.rows = o.rows; d.K = o.K; d.wpr = o.wpr; d.ones_row = o.ones_row;
+    return d;
+}
+
+// quad q of a tile (q < 8): KMAJOR row pass p = q >> 1, k half h = q & 1; KMINOR k-pair group p = q >> 1, k parity h = q & 1
 template <bool KMINOR, bool BITS = true>
-__device__ __forceinline__ void tile_load(TileRegsT<BITS>& t, const Operand& o, int r0, int k0, int kend) {
+__device__ __forceinline__ void quad_load(TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0, int kend, int q) {
     const int tid = threadIdx.x;
+    const int p = q >> 1, h = q & 1;
+    int off, woff;
     if (!KMINOR) {
         // thread: row = tid >> 3 (+32 per pass), k quads (tid & 7) and (tid & 7) + 8
-        const int kq = tid & 7, rr = tid >> 3;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = r0 + rr + 32 * p;
-            const int rc = min(row, o.rows - 1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = k0 + (kq + 8 * h) * 4;
-                const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;     // K % 4 == 0, k0 % 4 == 0
-                t.v[p][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)rc * o.ld + (ok ? k : 0));
-                if constexpr (BITS) t.wd[p][h] = o.bits ? o.bits[(int64_t)rc * o.wpr + ((ok ? k : 0) >> 5)] : 0xFFFFFFFFu;
-            }
-        }
+        const int row = r0 + (tid >> 3) + 32 * p;
+        const int rc = min(row, o.rows - 1);
+        const int k = k0 + ((tid & 7) + 8 * h) * 4;
+        const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;     // K % 4 == 0, k0 % 4 == 0
+        off = rc * o.ld + (ok ? k : 0);
+        woff = rc * o.wpr + ((ok ? k : 0) >> 5);
     } else {
-        // thread: rows 4 (tid & 31) .. + 3, k pairs 2 (tid >> 5) + 16 i (i < 4): two k rows -> four packed dwords
-        const int r4 = (tid & 31) * 4, kp = tid >> 5;
-        const bool vec = (o.ld & 3) == 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = k0 + 2 * (kp + 8 * i) + h;
-                const int kc = min(k, o.K - 1);
-                const int row = r0 + r4;
-                if (vec) {   // row % 4 == 0 and ld % 4 == 0: the four floats stay inside the memory row whenever row < ld
-                    t.v[i][h] = *reinterpret_cast<const float4*>(o.ptr + (int64_t)kc * o.ld + (row < o.ld ? row : 0));
-                } else {
-                    float q[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) q[e] = o.ptr[(int64_t)kc * o.ld + min(row + e, o.rows - 1)];
-                    t.v[i][h] = make_float4(q[0], q[1], q[2], q[3]);
-                }
-                if constexpr (BITS) t.wd[i][h] = o.bits ? o.bits[(int64_t)kc * o.wpr + (min(row, o.rows - 1) >> 5)] : 0xFFFFFFFFu;
-            }
-        }
+        // thread: rows 4 (tid & 31) .. + 3, k = 2 (tid >> 5) + 16 p + h; row % 4 == 0 and ld % 4 == 0: the four floats
+        // stay inside the memory row whenever row < ld
+        const int k = k0 + 2 * ((tid >> 5) + 8 * p) + h;
+        const int kc = min(k, o.K - 1);
+        const int row = r0 + (tid & 31) * 4;
+        off = kc * o.ld + (row < o.ld ? row : 0);
+        woff = kc * o.wpr + (min(row, o.rows - 1) >> 5);
     }
+    t.v[p][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 4, 0, 0));
+    if constexpr (BITS) t.wd[p][h] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
 }
 
 template <bool KMINOR, bool BITS = true>
-__device__ __forceinline__ void tile_store(unsigned* __restrict__ T, const TileRegsT<BITS>& t, const Operand& o, int r0, int k0, int kend) {
+__device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0,
+                                           int kend, int q) {
     const int tid = threadIdx.x;
+    const int p = q >> 1, h = q & 1;
     if (!KMINOR) {
         const int kq = tid & 7, rr = tid >> 3;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = r0 + rr + 32 * p;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = k0 + (kq + 8 * h) * 4;
-                const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;
-                const uint32_t nib = BITS ? t.wd[p][h] >> (k & 31) : 0xFu;
-                float4 q = t.v[p][h];
-                q.x = (ok && (nib & 1u)) ? q.x : 0.f;
-                q.y = (ok && (nib & 2u)) ? q.y : 0.f;
-                q.z = (ok && (nib & 4u)) ? q.z : 0.f;
-                q.w = (ok && (nib & 8u)) ? q.w : 0.f;
-                uint2 w;
-                w.x = pack_bf16(q.x, q.y);
-                w.y = pack_bf16(q.z, q.w);
-                *reinterpret_cast<uint2*>(&T[(rr + 32 * p) * LDB + (kq + 8 * h) * 2]) = w;
-            }
-        }
+        const int row = r0 + rr + 32 * p;
+        const int k = k0 + (kq + 8 * h) * 4;
+        const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;
+        const uint32_t nib = BITS ? t.wd[p][h] >> (k & 31) : 0xFu;
+        float4 v = t.v[p][h];
+        v.x = (ok && (nib & 1u)) ? v.x : 0.f;
+        v.y = (ok && (nib & 2u)) ? v.y : 0.f;
+        v.z = (ok && (nib & 4u)) ? v.z : 0.f;
+        v.w = (ok && (nib & 8u)) ? v.w : 0.f;
+        uint2 w;
+        w.x = pack_bf16(v.x, v.y);
+        w.y = pack_bf16(v.z, v.w);
+        *reinterpret_cast<uint2*>(&T[(rr + 32 * p) * LDB + (kq + 8 * h) * 2]) = w;
     } else {
         // natural layout [k][row] (rows contiguous, LDK bf16 per k): one 8-byte store per (k, four rows); the MFMA
         // fragments come out of it through the transposing LDS read (ds_read_b64_tr_b16, see frag8)
         unsigned short* Tk = reinterpret_cast<unsigned short*>(T);
         const int r4 = (tid & 31) * 4, kp = tid >> 5;
+        const int kl = 2 * (kp + 8 * p) + h, k = k0 + kl;
+        const bool kok = k < kend && k < o.K;
+        const uint32_t nib = BITS ? t.wd[p][h] >> ((r0 + r4) & 31) : 0xFu;
+        const float4 v = t.v[p][h];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kl = 2 * (kp + 8 * i) + h, k = k0 + kl;
-                const bool kok = k < kend && k < o.K;
-                const uint32_t nib = BITS ? t.wd[i][h] >> ((r0 + r4) & 31) : 0xFu;
-                const float4 q = t.v[i][h];
-                const float qq[4] = {q.x, q.y, q.z, q.w};
-                float x[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = r0 + r4 + e;
-                    x[e] = (kok && row < o.rows && ((nib >> e) & 1u)) ? qq[e] : 0.f;
-                    if (kok && row == o.ones_row) x[e] = 1.f;
-                }
-                uint2 w;
-                w.x = pack_bf16(x[0], x[1]);
-                w.y = pack_bf16(x[2], x[3]);
-                *reinterpret_cast<uint2*>(&Tk[kl * LDK + r4]) = w;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int row = r0 + r4 + e;
+            x[e] = (kok && row < o.rows && ((nib >> e) & 1u)) ? vv[e] : 0.f;
+            if (kok && row == o.ones_row) x[e] = 1.f;
         }
+        uint2 w;
+        w.x = pack_bf16(x[0], x[1]);
+        w.y = pack_bf16(x[2], x[3]);
+        *reinterpret_cast<uint2*>(&Tk[kl * LDK + r4]) = w;
     }
+}
+
+template <bool KMINOR, bool BITS = true>
+__device__ __forceinline__ void tile_load(TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0, int kend) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) quad_load<KMINOR, BITS>(t, o, r0, k0, kend, q);
+}
+template <bool KMINOR, bool BITS = true>
+__device__ __forceinline__ void tile_store(unsigned* __restrict__ T, const TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0, int kend) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) quad_store<KMINOR, BITS>(T, t, o, r0, k0, kend, q);
 }
 
 // MFMA fragment of a 32-row tile (rows rb .. rb + 31 of the block tile), K step s (16 k's): lane l holds row l % 32,
@@ -230,7 +239,6 @@ struct GemmArgs {
     SlabOut so;
     Fc11Out fo;
     AffineOut ao;
-    int ablate;                  // timing experiments (MMVAE_TUNE_ABLATE_B): 1 no MFMAs, 2 no global loads, 4 no LDS stores
     int64_t fo_arm, fo_x_arm;    // arm strides of dz / x_rec and of x (0: the arms share x)
     int n11;
     int A;
@@ -257,15 +265,16 @@ __device__ __forceinline__ void mfma_ktile(f32x16 (&acc)[2][2], const unsigned* 
 template <bool AMINOR, bool BMINOR, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const GemmArgs g = g_in;
-    __shared__ __attribute__((aligned(16))) unsigned As[BT * LDB];
-    __shared__ __attribute__((aligned(16))) unsigned Bs[BT * LDB];
+    __shared__ __attribute__((aligned(16))) unsigned As[2][BT * LDB];   // two K tiles in LDS: tile t is multiplied while tile
+    __shared__ __attribute__((aligned(16))) unsigned Bs[2][BT * LDB];   // t + 1 is written and tile t + 2 is in flight
     const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
-    const int l31 = lane & 31, hh = lane >> 5;
-    Operand oa = g.a, ob = g.b;
-    oa.ptr += (int64_t)arm * g.a_arm;
-    ob.ptr += (int64_t)arm * g.b_arm;
-    if (oa.bits) oa.bits += (int64_t)arm * g.a_bits_arm;
-    if (ob.bits) ob.bits += (int64_t)arm * g.b_bits_arm;
+    const int l31 = lane & 31;
+    Operand oa_h = g.a, ob_h = g.b;
+    oa_h.ptr += (int64_t)arm * g.a_arm;
+    ob_h.ptr += (int64_t)arm * g.b_arm;
+    if (oa_h.bits) oa_h.bits += (int64_t)arm * g.a_bits_arm;
+    if (ob_h.bits) ob_h.bits += (int64_t)arm * g.b_bits_arm;
+    const OperandDev oa = make_operand_dev<AMINOR>(oa_h), ob = make_operand_dev<BMINOR>(ob_h);
     const int tiles_n = cdiv(g.N, BT);
     int wg = blockIdx.x;
     if (EPI == 1) {   // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x a contiguous range of tiles
@@ -278,28 +287,36 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegs ta, tb;
-    if (g.ablate & 2) {
+    // Software pipeline at the granularity of one 16-byte piece: a piece of tile t + 1 is rounded and written to LDS
+    // and the SAME registers immediately request the piece of tile t + 2, so sixteen loads per thread are in flight
+    // all the time and every load has a whole iteration (the other fifteen pieces, the MFMAs, the barrier) to land.
+    auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
+        constexpr bool LOAD = decltype(load_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { ta.v[i][h] = tb.v[i][h] = make_float4(1.f, 2.f, 3.f, 4.f); ta.wd[i][h] = tb.wd[i][h] = ~0u; }
-    }
-    if (kb < ke && !(g.ablate & 2)) {
+        for (int q = 0; q < 8; ++q) {
+            // (no run-time condition around a load: hipcc then waits for every load separately)
+            quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
+            if constexpr (LOAD) quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
+            quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
+            if constexpr (LOAD) quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
+        }
+    };
+    if (kb < ke) {
         tile_load<AMINOR>(ta, oa, m0, kb, ke);
         tile_load<BMINOR>(tb, ob, n0, kb, ke);
     }
+    if (kb < ke) {
+        if (kb + KT < ke) stage(As[0], Bs[0], kb, kb + KT, VecTag{});
+        else stage(As[0], Bs[0], kb, kb, ScalarTag{});
+    }
+    __syncthreads();
+    int cur = 0;
     for (int k0 = kb; k0 < ke; k0 += KT) {
-        if (!(g.ablate & 4)) {
-            tile_store<AMINOR>(As, ta, oa, m0, k0, ke);
-            tile_store<BMINOR>(Bs, tb, ob, n0, k0, ke);
-        }
+        mfma_ktile<AMINOR, BMINOR>(acc, As[cur], Bs[cur], wm, wn, lane);
+        if (k0 + 2 * KT < ke) stage(As[cur ^ 1], Bs[cur ^ 1], k0 + KT, k0 + 2 * KT, VecTag{});
+        else if (k0 + KT < ke) stage(As[cur ^ 1], Bs[cur ^ 1], k0 + KT, k0 + KT, ScalarTag{});
         __syncthreads();
-        if (k0 + KT < ke && !(g.ablate & 2)) {
-            tile_load<AMINOR>(ta, oa, m0, k0 + KT, ke);
-            tile_load<BMINOR>(tb, ob, n0, k0 + KT, ke);
-        }
-        if (!(g.ablate & 1)) mfma_ktile<AMINOR, BMINOR>(acc, As, Bs, wm, wn, lane);
-        __syncthreads();
+        cur ^= 1;
     }
     // accumulator register r of tile (i, j) is row m0 + 64 wm + 32 i + acc_row(r), column n0 + 64 wn + 32 j + (lane & 31)
     if (EPI == 1) {
@@ -350,9 +367,10 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
     __shared__ float red[8];
     const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
     const int l31 = lane & 31, hh = lane >> 5;
-    Operand od = g.a, ow = g.b;                       // a: d10 [B][H]; b: W11 [D][H]
-    od.ptr += (int64_t)arm * g.a_arm;
-    ow.ptr += (int64_t)arm * g.b_arm;
+    Operand od_h = g.a, ow_h = g.b;                   // a: d10 [B][H]; b: W11 [D][H]
+    od_h.ptr += (int64_t)arm * g.a_arm;
+    ow_h.ptr += (int64_t)arm * g.b_arm;
+    const OperandDev od = make_operand_dev<false>(od_h), ow = make_operand_dev<false>(ow_h);
     const int c0 = blockIdx.x * BT;                    // cells of this block
     const int tiles = cdiv(g.N, BT);                   // gene tiles
     const int t0 = (int)(((int64_t)blockIdx.y * tiles) / g.KS), t1 = (int)(((int64_t)(blockIdx.y + 1) * tiles) / g.KS);
@@ -456,7 +474,7 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
     if (use_mask) { g.a.bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits); g.a.wpr = cdiv(d.D, 32); g.a_bits_arm = (int64_t)d.B * g.a.wpr; }
     g.b = kmajor(params + c.po.o[0], d.D, d.H, d.D);
     g.b_arm = c.po.per_arm;
-    g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
+    g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A;
     g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
     hipLaunchKernelGGL((k_bf16_gemm<false, false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
     HIP_LAUNCH_CHECK("k_bf16_gemm<fc1>");
@@ -491,7 +509,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.a_arm = (int64_t)d.B * d.D;
         g.b = kminor(params + c.po.o[26], d.H, d.H, d.D);      // W11 [D][H] read as B[n = h][k = j]
         g.b_arm = c.po.per_arm;
-        g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
+        g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A;
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
         hipLaunchKernelGGL((k_bf16_gemm<false, true>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), NS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<gd10>");
@@ -510,7 +528,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.b = kminor(x, d.D, d.D, d.B);
         g.b_arm = xs;
         if (use_mask) { g.b.bits = reinterpret_cast<const uint32_t*>(c.ws + L.xbits); g.b.wpr = cdiv(d.D, 32); g.b_bits_arm = (int64_t)d.B * g.b.wpr; }
-        g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
+        g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A;
         g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
         hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW1>");
@@ -522,7 +540,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.b = kminor(c.ws + L.Dk[4], d.H, d.H, d.B);
         g.b.ones_row = d.H;                                      // logical row H (not in memory) reads 1: the bias gradient
         g.b_arm = (int64_t)d.B * d.H;
-        g.M = d.D; g.N = d.H + 1; g.K = d.B; g.KS = L.sp.ks_dw11; g.A = d.A; g.ablate = c.tune(MMVAE_TUNE_ABLATE_B);
+        g.M = d.D; g.N = d.H + 1; g.K = d.B; g.KS = L.sp.ks_dw11; g.A = d.A;
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
         hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW11>");
