@@ -256,3 +256,36 @@ def test_two_engines_in_one_thread_share_nothing():
     for i in range(2):
         for (l1, g1), (l2, g2) in zip(a[i], b[i]):
             assert torch.equal(l1, l2) and torch.equal(g1, g2)
+
+
+def test_cfg5_stand_in_through_the_trainer():
+    """BASELINE.json configs[4] (A = 3 arms on the SmartSeq loader) with the loader's stand-in: N = 22 365 cells x
+    D = 5 032 genes, device-resident loaders (90 / 10 split, batches of 5000, drop_last), one epoch
+    through ``train``: four fused steps at D % 64 = 40, the whole-training-set consensus in chunks with a ragged tail,
+    the validation block on the 2 237-cell test set as ONE batch (eval forward + loss at an odd batch size), checkpoint."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    from distributed_vae_amd.utils import dataloader as DL
+    N_, D, A = 22365, 5032, 3
+    g = torch.Generator(device=DEV).manual_seed(546)
+    X = (torch.rand(N_, D, generator=g, device=DEV) < 0.2).float() * torch.randn(N_, D, generator=g, device=DEV).abs() * 3.0
+    tr, te, al = DL.get_loaders(X, seed=546, batch_size=5000, device=DEV)
+    assert len(tr) == 4 and len(te.dataset) == N_ - int(0.9 * N_)
+    torch.manual_seed(546)
+    t = cpl_mixVAE(saving_folder="", device=DEV, save_flag=False)
+    t.init_model(n_categories=92, state_dim=2, input_dim=D, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A)
+    hist = t.train(tr, te, n_epoch=1, good_enuf_consensus=2.0)
+    for key in ("losses", "validation_loss", "validation_rec_loss", "consensus_train", "consensus_aug", "consensus_val"):
+        assert len(hist[key]) == 1 and np.isfinite(hist[key][0]), key
+    assert t.optimizer.step_count == 4 and 0.0 <= hist["consensus_train"][0] <= 1.0
+    # the same epoch means from the step's own loss vectors, recomputed by hand (cpl_mixvae.py:485-492)
+    t2 = cpl_mixVAE(saving_folder="", device=DEV, save_flag=False)
+    torch.manual_seed(546)
+    t2.init_model(n_categories=92, state_dim=2, input_dim=D, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A)
+    tr2, _, _ = DL.get_loaders(X, seed=546, batch_size=5000, device=DEV)
+    t2.model.train()
+    bufs = torch.stack([b.clone() for b in t2.epoch_steps(tr2)]).double().cpu().numpy()
+    assert bufs.shape[0] == 4
+    assert abs(bufs[:, 0].sum() / 4 - hist["losses"][0]) <= 1e-5 * abs(hist["losses"][0])
+    for a in range(A):
+        assert abs(bufs[:, 5 + a].sum() / D / 4 - hist["loss_recs"][a][0]) <= 1e-5 * abs(hist["loss_recs"][a][0])
