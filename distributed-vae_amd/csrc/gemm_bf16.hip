@@ -403,49 +403,59 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
             tile_load<false, false>(w0, ow, j0 + BT, 0, K);
             tile_load<false, false>(w1, ow, j0 + BT, KT, K);
         }
+        // the epilogue walks the four 32 x 32 pieces (i, j) of this wave's tile with the NEXT piece's x and bias in flight:
+        // piece 0 is requested before the MFMAs, piece p + 1 before piece p is processed (140 -> 131 us; swapping
+        // registers between the half-waves for 32-byte runs per lane, v_permlane32_swap, measured slower: 146 us)
+        float4 xin[2][4], b4[2][4];
+        auto request = [&](int pc, float4 (&X)[4], float4 (&Bq)[4]) __attribute__((always_inline)) {
+            const int i = pc >> 1, j = pc & 1;
+            const int cell = c0 + 64 * wn + 32 * j + l31;
+            const int64_t rowoff = (int64_t)min(cell, B - 1) * D;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gene = j0 + 64 * wm + 32 * i + 8 * q + 4 * hh;
+                const int gc = min(gene, D - 4);                      // D % 4 == 0
+                X[q] = *reinterpret_cast<const float4*>(xa + rowoff + gc);
+                Bq[q] = *reinterpret_cast<const float4*>(bias + gc);
+            }
+        };
+        request(0, xin[0], b4[0]);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
         mfma_ktile<false, false>(acc, Ws[0], Ds[0], wm, wn, lane);
         if (K > KT) mfma_ktile<false, false>(acc, Ws[1], Ds[1], wm, wn, lane);
         // acc[i][j][4 q + e]: gene j0 + 64 wm + 32 i + 8 q + 4 hh + e, cell c0 + 64 wn + 32 j + (lane & 31)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int pc = 0; pc < 4; ++pc) {
+            const int i = pc >> 1, j = pc & 1;
+            if (pc + 1 < 4) request(pc + 1, xin[(pc + 1) & 1], b4[(pc + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int cell = c0 + 64 * wn + 32 * j + l31;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int cell = c0 + 64 * wn + 32 * j + l31;
-                const int64_t rowoff = (int64_t)min(cell, B - 1) * D;
-                float4 xin[4], b4[4];
+            for (int q = 0; q < 4; ++q) {
+                const int gene = j0 + 64 * wm + 32 * i + 8 * q + 4 * hh;
+                const bool ok = cell < B && gene < D;
+                const float4 xq = xin[pc & 1][q], bq = b4[pc & 1][q];
+                const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+                const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+                float xr[4], dz[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int gene = j0 + 64 * wm + 32 * i + 8 * q + 4 * hh;
-                    const int gc = min(gene, D - 4);                      // D % 4 == 0
-                    xin[q] = *reinterpret_cast<const float4*>(xa + rowoff + gc);
-                    b4[q] = *reinterpret_cast<const float4*>(bias + gc);
+                for (int e = 0; e < 4; ++e) {
+                    xr[e] = fmaxf(acc[i][j][4 * q + e] + bv[e], 0.f);
+                    const float er = xr[e] - xv[e];
+                    dz[e] = xr[e] > 0.f ? g.fo.coef * er : 0.f;
+                    se += ok ? er * er : 0.f;
+                    mism += (ok && ((xr[e] > 0.1f) != (xv[e] > 0.1f))) ? 1 : 0;
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int gene = j0 + 64 * wm + 32 * i + 8 * q + 4 * hh;
-                    const bool ok = cell < B && gene < D;
-                    const float xv[4] = {xin[q].x, xin[q].y, xin[q].z, xin[q].w};
-                    const float bv[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
-                    float xr[4], dz[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        xr[e] = fmaxf(acc[i][j][4 * q + e] + bv[e], 0.f);
-                        const float er = xr[e] - xv[e];
-                        dz[e] = xr[e] > 0.f ? g.fo.coef * er : 0.f;
-                        se += ok ? er * er : 0.f;
-                        mism += (ok && ((xr[e] > 0.1f) != (xv[e] > 0.1f))) ? 1 : 0;
-                    }
-                    if (ok) {
-                        *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) = make_float4(dz[0], dz[1], dz[2], dz[3]);
-                        if (xra) *reinterpret_cast<float4*>(xra + (int64_t)cell * D + gene) = make_float4(xr[0], xr[1], xr[2], xr[3]);
-                    }
+                if (ok) {
+                    *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+                    if (xra) *reinterpret_cast<float4*>(xra + (int64_t)cell * D + gene) = make_float4(xr[0], xr[1], xr[2], xr[3]);
                 }
-                // piece fence: without it the scheduler requests the x / bias values of all four (i, j) pieces up front
-                // (128 registers on top of the accumulators and the W11 tile in flight) and spills
-                asm volatile("" : "+v"(mism), "+v"(se));
-                __builtin_amdgcn_sched_barrier(0);
             }
+            // piece fence: keeps the requests one piece ahead (all four up front cost 128 registers and spill)
+            asm volatile("" : "+v"(mism), "+v"(se));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
     }
     se = wave_sum(se);
