@@ -556,6 +556,37 @@ def augmenter_forward(args, batches, A, B, D, with_cpu):
         e1.synchronize()
         out["augmented_step_ms_pipelined" if pipe else "augmented_step_ms_back_to_back"] = e0.elapsed_time(e1) / n
     out["augmented_cells_per_s"] = B / out["augmented_step_ms_pipelined"] * 1e3
+    # the bf16 configuration (BASELINE.json configs[2]) covers the augmenter's ten large Linear layers too
+    try:
+        net.gemm_dtype = "bf16"
+        for b in batches[:2]:
+            net(b.expand(A, -1, -1), True, 0.1)
+        e0.record()
+        for _ in range(reps):
+            for b in batches:
+                net(b.expand(A, -1, -1), True, 0.1)
+        e1.record()
+        e1.synchronize()
+        ms16 = e0.elapsed_time(e1) / (reps * len(batches))
+        tr.init_model(n_categories=92, state_dim=2, input_dim=D, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A,
+                      gemm_dtype="bf16")
+        tr.set_augmenter(net)
+        tr.pipeline = True
+        for _ in tr.epoch_steps(batches[:3]):
+            pass
+        e0.record()
+        n = 0
+        for _ in range(2):
+            for _b in tr.epoch_steps(batches):
+                n += 1
+        e1.record()
+        e1.synchronize()
+        out["bf16_config"] = {"ms_per_batch": ms16, "tflops": fl_exec / ms16 / 1e9, "augmented_step_ms_pipelined": e0.elapsed_time(e1) / n,
+                              "augmented_cells_per_s": B / (e0.elapsed_time(e1) / n) * 1e3}
+    except Exception as e:   # noqa: BLE001
+        out["bf16_config"] = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        net.gemm_dtype = "fp32"
     if with_cpu:
         from oracle import augmenter as OA
         sd = OA.random_state_dict(NZ, Z, D, ND, seed=1)
