@@ -170,8 +170,7 @@ def measure_bf16_stages(model, x, A, B, D, H):
     # stage id: (kernel, bytes streamed per launch: inputs read once + outputs written once, x shared by the arms)
     stages = {
         14: ("k_bf16_gemm<fc1>", 4.0 * B * D + A * 4.0 * H * D + sp[0] * A * 4.0 * B * 128),
-        10: ("k_bf16_fc11", 4.0 * B * D + A * 4.0 * B * D + A * 4.0 * D * H),
-        11: ("k_bf16_gemm<d(d10)>", A * 4.0 * B * D + A * 4.0 * D * H + sp[4] * A * 4.0 * B * H),
+        1: ("k_bf16_fc11g (fc11 + loss + dZ11 + d(d10))", 4.0 * B * D + A * 4.0 * B * D + A * 4.0 * D * H + sp[4] * A * 4.0 * B * H),
         12: ("k_bf16_gemm<dW1>", 4.0 * B * D + A * 4.0 * B * H + sp[2] * A * 4.0 * H * D),
         13: ("k_bf16_gemm<dW11>", A * 4.0 * B * D + A * 4.0 * B * H + sp[5] * A * 4.0 * D * 132),
     }
@@ -187,7 +186,7 @@ def measure_bf16_stages(model, x, A, B, D, H):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 20
         res[name] = {"avg_launch_ms": ms, "streamed_GBs": by / ms / 1e6, "frac_of_hbm_peak": by / ms / 1e6 / PEAK_HBM_GBS,
-                     "tflops": A * 2.0 * B * D * H / ms / 1e9}
+                     "tflops": A * (4.0 if sid == 1 else 2.0) * B * D * H / ms / 1e9}
     return res
 
 

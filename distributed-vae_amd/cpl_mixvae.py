@@ -358,6 +358,11 @@ class cpl_mixVAE:
             os.makedirs(os.path.join(self.folder, "model"), exist_ok=True)
             self.save_checkpoint(os.path.join(self.folder, "model",
                                               f"cpl_mixVAE_model_before_pruning_A{A}_{self.current_time}.pth"))
+        # Pruning phase (:996-1444): upstream forces ``stop_prune = True`` at :1007 whatever ``n_epoch_p`` is, so its
+        # ``while not stop_prune`` body never runs; what remains of the phase are these two lines of output.
+        if rank in (None, 0, dev) or not D.is_dist():
+            print("warning: stopping pruning")                              # :1008
+            print("Training is done!")                                      # :1446
         return hist
 
     @torch.no_grad()

@@ -469,6 +469,173 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
     }
 }
 
+// fc11 forward + bias + reconstruction loss + dZ11 + d(d10), train step: k_bf16_fc11 with the second GEMM folded in, so
+// dZ11 is not read back from HBM (200 MB per step at the benchmark shape) and one launch disappears.  Wave w of the four
+// owns cells [32 w, 32 w + 32) of the block's 128 and ALL 128 genes of the current gene tile (four 32 x 32 accumulators,
+// computed and consumed two at a time).  The dZ11 piece a wave has just formed IS the next MFMA's operand: the
+// accumulator layout has the cell on the lane and four genes per register group, which is the A operand of
+// d(d10)[cell][h] += sum_gene dZ11[cell][gene] W11[gene][h] once the sixteen genes of a K step are taken in the order
+// the registers hold them (lower half-wave: genes 0-3, 8-11; upper: 4-7, 12-15 of the block of 16) -- no LDS round trip,
+// no lane movement.  The B operand uses the same order: W11[gene][h] for four consecutive genes and one h per lane comes
+// out of the [gene][h] image that is in LDS anyway through the transposing read (two ds_read_b64_tr_b16).  The d(d10)
+// accumulators (32 cells x 128 h per wave) live across the whole gene range and are written once, to the gene-split slab.
+__global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
+    const GemmArgs g = g_in;
+    __shared__ __attribute__((aligned(16))) unsigned Ws[2][BT * LDB];   // W11 tile: [gene][k = h], two K tiles
+    __shared__ __attribute__((aligned(16))) unsigned Ds[2][BT * LDB];   // d10 tile: [cell][k = h], two K tiles
+    __shared__ __attribute__((aligned(16))) float bias_s[BT];
+    __shared__ float red[8];
+    const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    Operand od_h = g.a, ow_h = g.b;                   // a: d10 [B][H]; b: W11 [D][H]
+    od_h.ptr += (int64_t)arm * g.a_arm;
+    ow_h.ptr += (int64_t)arm * g.b_arm;
+    const OperandDev od = make_operand_dev<false>(od_h), ow = make_operand_dev<false>(ow_h);
+    const int c0 = blockIdx.x * BT;
+    const int tiles = cdiv(g.N, BT);
+    const int t0 = (int)(((int64_t)blockIdx.y * tiles) / g.KS), t1 = (int)(((int64_t)(blockIdx.y + 1) * tiles) / g.KS);
+    const int K = g.K;
+    const int ksteps1 = K > KT ? cdiv(K - KT, 16) : 0;      // MFMA steps of the second K tile that hold any k < K
+    const float* xa = g.fo.x + (int64_t)arm * g.fo_x_arm;
+    float* dza = g.fo.dz + (int64_t)arm * g.fo_arm;
+    const float* bias = g.fo.bias + (int64_t)arm * g.bias_arm;
+    const int B = g.fo.B, D = g.fo.D;
+    {
+        TileRegsT<false> t0r, t1r;
+        tile_load<false, false>(t0r, od, c0, 0, K);
+        tile_load<false, false>(t1r, od, c0, KT, K);
+        tile_store<false, false>(Ds[0], t0r, od, c0, 0, K);
+        tile_store<false, false>(Ds[1], t1r, od, c0, KT, K);
+    }
+    TileRegsT<false> w0, w1;
+    float bnext = 0.f;
+    if (t0 < t1) {
+        tile_load<false, false>(w0, ow, t0 * BT, 0, K);
+        tile_load<false, false>(w1, ow, t0 * BT, KT, K);
+        if (tid < BT) bnext = bias[min(t0 * BT + tid, D - 1)];
+    }
+    f32x16 gd[4] = {zero16(), zero16(), zero16(), zero16()};   // d(d10)[cell = 32 wv + row][h = 32 nt + (lane & 31)]
+    float se = 0.f;
+    int mism = 0;
+    const int cell = c0 + 32 * wv + l31;
+    const int64_t rowoff = (int64_t)min(cell, B - 1) * D;
+    const unsigned short* Wk16[2] = {reinterpret_cast<const unsigned short*>(Ws[0]), reinterpret_cast<const unsigned short*>(Ws[1])};
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    // transposing-read address of this lane inside a (4 genes x 16 h) block: row (lane & 15) >> 2, columns 4 (lane & 3) ..
+    const int tr_off = ((lane & 15) >> 2) * (2 * LDB) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    for (int t = t0; t < t1; ++t) {
+        const int j0 = t * BT;
+        tile_store<false, false>(Ws[0], w0, ow, j0, 0, K);
+        tile_store<false, false>(Ws[1], w1, ow, j0, KT, K);
+        if (tid < BT) bias_s[tid] = bnext;
+        __syncthreads();
+        if (t + 1 < t1) {
+            tile_load<false, false>(w0, ow, j0 + BT, 0, K);
+            tile_load<false, false>(w1, ow, j0 + BT, KT, K);
+            if (tid < BT) bnext = bias[min(j0 + BT + tid, D - 1)];
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // x of the two gene sub-tiles of this half (requested before the MFMAs that produce their z)
+            float4 xin[2][4];
+#pragma unroll
+            for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gene = j0 + 32 * (2 * half + gl) + 8 * q + 4 * hh;
+                    xin[gl][q] = *reinterpret_cast<const float4*>(xa + rowoff + min(gene, D - 4));      // D % 4 == 0
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[2] = {zero16(), zero16()};       // z^T[gene sub-tile 2 half + gl][this wave's 32 cells]
+#pragma unroll
+            for (int s = 0; s < KT / 16; ++s) {
+                const bf16x8 b = frag8<false>(Ds[0], 32 * wv, s, lane);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8<false>(Ws[0], 32 * (2 * half), s, lane), b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8<false>(Ws[0], 32 * (2 * half + 1), s, lane), b, acc[1], 0, 0, 0);
+            }
+            for (int s = 0; s < ksteps1; ++s) {
+                const bf16x8 b = frag8<false>(Ds[1], 32 * wv, s, lane);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8<false>(Ws[1], 32 * (2 * half), s, lane), b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8<false>(Ws[1], 32 * (2 * half + 1), s, lane), b, acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int gl = 0; gl < 2; ++gl) {
+                const int gi = 2 * half + gl;
+                // acc[gl][4 q + e]: gene j0 + 32 gi + 8 q + 4 hh + e of cell `cell`
+                float dzr[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gene = j0 + 32 * gi + 8 * q + 4 * hh;
+                    const bool ok = cell < B && gene < D;
+                    const float4 xq = xin[gl][q];
+                    const float4 bq = *reinterpret_cast<const float4*>(&bias_s[32 * gi + 8 * q + 4 * hh]);
+                    const float xv[4] = {xq.x, xq.y, xq.z, xq.w};
+                    const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xr = fmaxf(acc[gl][4 * q + e] + bv[e], 0.f);
+                        const float er = xr - xv[e];
+                        dzr[4 * q + e] = (ok && xr > 0.f) ? g.fo.coef * er : 0.f;
+                        se += ok ? er * er : 0.f;
+                        mism += (ok && ((xr > 0.1f) != (xv[e] > 0.1f))) ? 1 : 0;
+                    }
+                    if (ok) *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) =
+                        make_float4(dzr[4 * q], dzr[4 * q + 1], dzr[4 * q + 2], dzr[4 * q + 3]);
+                }
+                // d(d10) += dZ11 piece (registers) x W11 rows 32 gi .. + 31 (LDS): two K steps of sixteen genes
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    u32x4v au;
+                    au[0] = pack_bf16(dzr[8 * c + 0], dzr[8 * c + 1]);
+                    au[1] = pack_bf16(dzr[8 * c + 2], dzr[8 * c + 3]);
+                    au[2] = pack_bf16(dzr[8 * c + 4], dzr[8 * c + 5]);
+                    au[3] = pack_bf16(dzr[8 * c + 6], dzr[8 * c + 7]);
+                    const bf16x8 afr = __builtin_bit_cast(bf16x8, au);
+                    const int grow = 32 * gi + 16 * c + 4 * hh;            // first of this lane's two gene groups (second: + 8)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const unsigned short* a = Wk16[nt >> 1] + grow * (2 * LDB) + 32 * (nt & 1) + tr_off;
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * (2 * LDB)));
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        s16x8 r;
+                        r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
+                        r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
+                        gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, __builtin_bit_cast(bf16x8, r), gd[nt], 0, 0, 0);
+                    }
+                }
+                asm volatile("" : "+v"(mism), "+v"(se));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- d(d10) partial of this gene range: slab [NS][A][B][H]; gd[nt][r]: cell row acc_row(r), h = 32 nt + (lane & 31)
+    {
+        const int H = g.K;
+        float* out = g.so.out + (int64_t)blockIdx.y * g.so.ks_stride + (int64_t)arm * g.so.arm_stride;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int h = 32 * nt + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + 32 * wv + acc_row(r, lane);
+                if (row < B && h < H) out[(int64_t)row * H + h] = gd[nt][r];
+            }
+        }
+    }
+    se = wave_sum(se);
+    const float mf = wave_sum((float)mism);
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = mf; }
+    __syncthreads();
+    if (tid == 0) {
+        float* p = g.fo.part + ((int64_t)arm * g.n11 + (int64_t)blockIdx.x * g.KS + blockIdx.y) * 2;
+        p[0] = red[0] + red[2] + red[4] + red[6];
+        p[1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers (same workspace layouts and split factors as the fp32 fast path)
 // ---------------------------------------------------------------------------------------------------------------
@@ -495,6 +662,9 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int NS = L.sp.ks_gd10;
+    // forward for gradients without x_rec (the train step, mmvae_forward(need_grad) for backward): one fused kernel, and
+    // the call for d(d10) (which & 2) has nothing left to do; with x_rec wanted (or MMVAE_TUNE_FC11_ZG_OFF) two kernels
+    const bool fused = need_grad && !x_rec && !c.tune(MMVAE_TUNE_FC11_ZG_OFF);
     if (which & 1) {
         hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
@@ -510,10 +680,16 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
                        (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D};
         g.fo_arm = (int64_t)d.B * d.D;
         g.fo_x_arm = xs;
-        hipLaunchKernelGGL(k_bf16_fc11, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
-        HIP_LAUNCH_CHECK("k_bf16_fc11");
+        if (fused) {   // train step: d(d10) comes out of the same launch (which & 2 is then a no-op)
+            g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
+            hipLaunchKernelGGL(k_bf16_fc11g, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+            HIP_LAUNCH_CHECK("k_bf16_fc11g");
+        } else {
+            hipLaunchKernelGGL(k_bf16_fc11, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+            HIP_LAUNCH_CHECK("k_bf16_fc11");
+        }
     }
-    if (need_grad && (which & 2)) {
+    if (need_grad && (which & 2) && !fused) {
         GemmArgs g{};
         g.a = kmajor(c.ws + L.DZ11, d.D, d.B, d.D);            // dZ11 [B][D], k = gene
         g.a_arm = (int64_t)d.B * d.D;

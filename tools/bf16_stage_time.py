@@ -15,9 +15,9 @@ m.train(); m.gemm_dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 eng = m._ensure(B); hyper = m._hyper(1.0, False); noise = N.make_noise(None, 99, 1)
 eng.forward(hyper, noise, m._flat, m._bn_flat, None, x, 0, None, True); eng.loss(hyper); eng.backward(hyper, noise, m._flat, x, 0, m._flat_grad)
 torch.cuda.synchronize()
-names = {14: "fc1", 10: "fc11", 11: "gd10", 12: "dW1", 13: "dW11"}
+names = {14: "fc1", 1: "fc11+gd10", 10: "fc11 alone", 11: "gd10 alone", 12: "dW1", 13: "dW11"}
 out = []
-for sid in (14, 10, 11, 12, 13):
+for sid in (14, 1, 12, 13):
     for _ in range(3): eng.debug_stage(sid, hyper, noise, m._flat, x, 0, m._flat_grad)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
