@@ -172,3 +172,32 @@ def test_bf16_augmenter_layers_reproduce_bf16_rounded_products(cfg):
     m.gemm_dtype = "fp32"
     s2, xa2 = m(x.to(DEV).expand(A, -1, -1), True, 0.1)
     assert _rel(xa2.cpu().double(), x_f32) < 1e-4
+
+
+def test_bf16_step_is_bit_reproducible_at_full_size():
+    """Every reduction of the bf16 kernels has a fixed order too (split slabs, no float atomics, the fused d(d10)
+    accumulates per wave in program order): identical state and noise give bit-identical losses and gradients."""
+    from tests import gpu_util as U
+    from distributed_vae_amd import _native as N
+    A, B, D = 2, 5000, 5000
+    h = R.Hyper(input_dim=D, n_arm=A)
+    torch.manual_seed(546)
+    m = U.build_model(h, None)
+    m.train()
+    m.gemm_dtype = "bf16"
+    x = R.synthetic_batch(B, D).to(DEV)
+    eng = m._ensure(B)
+    hyper, noise = m._hyper(1.0, False), N.make_noise(None, 7, 3)
+    assert hyper.gemm_bf16 == 1
+    bn0, nbt0 = m._bn_flat.clone(), m._nbt.clone()
+    ref = None
+    for it in range(8):
+        m._bn_flat.copy_(bn0)
+        m._nbt.copy_(nbt0)
+        buf = eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, m._flat_grad, False, None, None, 1, 0.0)
+        cur = (m._flat_grad.clone(), buf.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), f"iteration {it} differs"
+    assert torch.isfinite(ref[0]).all() and float(ref[0].abs().max()) > 0
