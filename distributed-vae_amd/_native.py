@@ -404,3 +404,24 @@ def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tenso
                                       _stream(data.device)),
               "mmvae_gather_rows")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# operand type of the large GEMMs (mmvae_hyper.gemm_bf16 / mmvae_augment's gemm_bf16 argument)
+#   "fp32"       fp32 results; the library's fastest fp32-grade engine (see FP32_ENGINE below)
+#   "fp32_mfma"  fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: an exact fmaf chain)
+#   "fp32x3"     fp32 operands split exactly into three bf16 slices, six slice products per product on the bf16 matrix
+#                pipe, fp32 accumulation: truncation <= 2^-26 per product, below the fp32 rounding of the accumulation
+#   "bf16"       operands rounded to bf16 (BASELINE.json's bf16 configuration)
+# MMVAE_FP32_ENGINE=fp32_mfma|fp32x3 picks what "fp32" means (A/B timing, and running the parity suite on either).
+# ---------------------------------------------------------------------------------------------------------------
+FP32_ENGINE = os.environ.get("MMVAE_FP32_ENGINE", "fp32_mfma")
+_GEMM_MODES = {"fp32_mfma": 0, "bf16": 1, "fp32x3": 2}
+
+
+def gemm_mode(dtype: str) -> int:
+    if dtype == "fp32":
+        dtype = FP32_ENGINE
+    if dtype not in _GEMM_MODES:
+        raise ValueError(f"gemm_dtype must be 'fp32', 'fp32_mfma', 'fp32x3' or 'bf16', got {dtype!r}")
+    return _GEMM_MODES[dtype]

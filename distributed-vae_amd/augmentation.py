@@ -148,7 +148,7 @@ class Augmenter_smartseq(nn.Module):
             out = torch.empty(A, B, D, dtype=torch.float32, device=xt.device)
         N.check(N.lib().mmvae_augment(C.byref(dims), N._ptr(self._packed), N._ptr(xt), xs, N._ptr(z0), N._ptr(eps),
                                       float(scale), N._ptr(self._ws), self._ws.numel() * 4, N._ptr(s), N._ptr(out),
-                                      int(self.gemm_dtype == "bf16"), C.byref(self._exec()), N._stream(xt.device)),
+                                      N.gemm_mode(self.gemm_dtype), C.byref(self._exec()), N._stream(xt.device)),
                 "mmvae_augment")
         return (s, out) if batched else (s[0], out[0])
 

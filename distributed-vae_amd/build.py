@@ -21,6 +21,11 @@ HEADERS = ["common.hpp", os.path.join("..", "..", "include", "mmvae.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
+# per-source extra flags.  gemm_bf16.hip: hipcc's SLP vectoriser packs the fp32 subtractions of the operand split into
+# v_pk_add_f32, which issues very slowly beside a partner wave's MFMAs (stage phase 3100 -> 1780 cycles without it)
+EXTRA = {"gemm_bf16.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -45,7 +50,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -146,6 +146,13 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.dw11_slab = take((int64_t)max(L.sp.ks_dw, L.sp.ks_dw11) * A * D * DW11_LD);
     L.small_slab = take((int64_t)L.sp.ks_small * A * N_SMALL * NP * SMALL_LD);
     L.xbits = take(A * B * cdiv(d.D, 32));
+    {   // slice planes (bf16: two per float)
+        const int64_t Dk = cdiv64(D, 32) * 32, Dr = cdiv64(D, 128) * 128, Br = cdiv64(B, 128) * 128;
+        L.pl_w1 = take(A * 3 * 128 * Dk / 2);
+        L.pl_w11 = take(A * 3 * Dr * 128 / 2);
+        L.pl_dz1 = take(A * 3 * Br * 128 / 2);
+        L.pl_d10 = take(A * 3 * Br * 128 / 2);
+    }
     L.loss_scratch = take(4096);
     L.total = off;
     return L;

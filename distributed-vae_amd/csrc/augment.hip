@@ -377,8 +377,9 @@ static int aug_gemm(hipStream_t s, int force_tile, bool relu, bool affine, const
     const float* W = pk + g.w;
     const float* sc = pk + g.sc;
     const float* sh = pk + g.sh;
-    if (force_tile == 99)   // bf16 operands (mmvae_augment's gemm_bf16): the shared bf16 tile engine, fp32 epilogue
-        return launch_bf16_affine(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.ldw, sc, sh, C, ldc, ncols);
+    if (force_tile == 99 || force_tile == 98)   // bf16 operands (mmvae_augment's gemm_bf16 = 1) or fp32 operands split into
+        // three bf16 slices (gemm_bf16 = 2): the shared tile engine of gemm_bf16.hip, fp32 epilogue
+        return launch_bf16_affine(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.ldw, sc, sh, C, ldc, ncols, force_tile == 98);
     // the largest tile that still leaves two workgroups per CU (256 CUs); MMVAE_AUG_TILE=<BM><BN> code forces one
     const int force = force_tile;   // 11 12 21 22 (1 = 64, 2 = 128), 0 = automatic
     auto count = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(ncols, bn); };
@@ -485,7 +486,7 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     const AugPacked L = aug_packed_layout(*d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* w = reinterpret_cast<float*>(ws);
-    const int ft = gemm_bf16 ? 99 : (ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0);
+    const int ft = gemm_bf16 == 2 ? 98 : gemm_bf16 ? 99 : (ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0);
     int rc;
     // trunk: once per cell when the arms share x
     if ((rc = aug_gemm(s, ft, true, true, x, d->D, T, packed, L.g[0], w + W.h1, W.ld1))) return rc;

@@ -64,6 +64,12 @@ struct Layout {
     int64_t dw11_slab;             // [KS][A][D][DW11_LD]
     int64_t small_slab;            // [KS][A][N_SMALL][NP*SMALL_LD]
     int64_t xbits;                 // uint32 [A][B][ceil(D/32)] dropout keep-mask, bit-packed (fast path)
+    // bf16 slice planes of the SMALL operands of the large GEMMs (fp32x3 engine, gemm_bf16.hip): [A][3][rows][cols] bf16,
+    // zero-padded to whole tiles so that the GEMMs copy them into LDS without bounds checks or arithmetic
+    int64_t pl_w1;                 // W1   [H -> 128][D -> rup 32]
+    int64_t pl_w11;                // W11  [D -> rup 128][H -> 128]
+    int64_t pl_dz1;                // dZ1  [B -> rup 128][H -> 128]
+    int64_t pl_d10;                // [d10 | 1]  [B -> rup 128][H + 1 -> 128]
     int64_t loss_scratch;          // small
     int64_t total;
 };
@@ -574,12 +580,15 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
                      int which = 3);
 int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit0 dW1, bit1 dW11*/);
 // bf16-operand variants of the five D x H GEMMs (gemm_bf16.hip; mmvae_hyper.gemm_bf16), same outputs / layouts
+// gemm_bf16 == 2: fp32 operands split exactly into three bf16 slices each (six slice products per product: fp32-grade
+// results on the bf16 matrix pipe); the same tile engine with three LDS planes per operand
 inline bool bf16_gemms(const Ctx& c) { return c.h.gemm_bf16 != 0 && c.d.H <= 124; }
+inline bool split3_gemms(const Ctx& c) { return c.h.gemm_bf16 == 2 && c.d.H <= 124; }
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);
 int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);
 int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw, int N,
-                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols);
+                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3 = 0);
 // evaluation labels / consensus (consensus.hip)
 int launch_classify(const float* cc, int64_t n_cells, int C, int32_t* labels, hipStream_t s);
 int launch_confmat(const int32_t* labels, int A, int64_t n, int C, int64_t* counts, hipStream_t s);

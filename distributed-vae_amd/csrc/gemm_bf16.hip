@@ -42,16 +42,50 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
+
 constexpr int BT = 128;          // block tile (both ways)
-constexpr int KT = 64;           // K tile
-constexpr int LDB = 36;          // KMAJOR LDS image [row][k]: row stride in dwords, 64 bf16 = 32 dwords + 4 (16-byte aligned rows)
-constexpr int LDK = 136;         // KMINOR LDS image [k][row]: k-row stride in bf16, 128 rows + 8 (8-byte aligned; 64 x 136 x 2 B fits BT x LDB dwords)
+constexpr int KT = 64;           // K tile of the one-plane engine (the fc11 kernels below use it directly)
+constexpr int LDB = 36;          // its KMAJOR LDS image [row][k]: row stride in dwords, 64 bf16 = 32 dwords + 4 (16-byte aligned rows)
+constexpr int LDK = 136;         // KMINOR LDS image [k][row]: k-row stride in bf16, 128 rows + 8 (8-byte aligned)
+
+// The engine exists in two precisions, selected by the number of bf16 PLANES an operand has in LDS:
+//   NP = 1  bf16 operands (BASELINE configs[2]): K tile 64, two K tiles in LDS.
+//   NP = 3  fp32 operands, split exactly into three bf16 slices on their way into LDS, x = x1 + x2 + x3 with
+//           x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (8 + 8 + 8 significand bits; both differences are exact
+//           in fp32, and x3 is exact).  The product a b is formed from six of the nine slice products, a1 b1 + (a1 b2 + a2 b1)
+//           + (a1 b3 + a2 b2 + a3 b1); each is exact in the fp32 accumulator's input (8 x 8 bits), the dropped ones are
+//           <= 2^-26 |a b|, below the fp32 rounding of the accumulation itself.  Six v_mfma_f32_32x32x16_bf16 do the work
+//           of eight v_mfma_f32_32x32x2_f32 in 6/64 of their time (the bf16 matrix rate is 16 x the fp32 one), so the
+//           fp32 configuration's large GEMMs leave the matrix pipe's roof and become memory-bound like the bf16 ones.
+//           K tile 32, one K tile in LDS (3 planes x 2 operands x 10 KB = 60 KB: two workgroups per CU).
+template <int NP>
+struct Eng {
+    static constexpr int KT = NP == 1 ? 64 : 32;
+    static constexpr int NQ = KT / 8;            // 16-byte pieces per thread per operand and K tile
+    static constexpr int LDB = KT / 2 + 4;       // KMAJOR image row stride in dwords (36 / 20: conflict-free ds_read_b128)
+    static constexpr int PLANE = BT * LDB;       // dwords of one plane's image (the KMINOR image, KT x LDK bf16, fits in it)
+    static constexpr int NBUF = NP == 1 ? 2 : 1;
+};
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     bf16x2 v;
     v[0] = (__bf16)a;
     v[1] = (__bf16)b;
     return __builtin_bit_cast(unsigned, v);
+}
+// the three bf16 slices of two fp32 values (low half: a, high half: b)
+__device__ __forceinline__ void split3(float a, float b, unsigned (&w)[3]) {
+    w[0] = pack_bf16(a, b);
+#ifdef X3_NOSPLIT
+    w[1] = w[2] = w[0];
+    return;
+#endif
+    a -= __uint_as_float(w[0] << 16);
+    b -= __uint_as_float(w[0] & 0xFFFF0000u);
+    w[1] = pack_bf16(a, b);
+    a -= __uint_as_float(w[1] << 16);
+    b -= __uint_as_float(w[1] & 0xFFFF0000u);
+    w[2] = pack_bf16(a, b);
 }
 
 struct Operand {
@@ -62,25 +96,28 @@ struct Operand {
     const uint32_t* bits;    // optional keep-mask of x: bit (col & 31) of bits[cell * wpr + (col >> 5)], cell / col = (row, k) or (k, row)
     int wpr;
     int ones_row;            // KMINOR: row index that reads as 1.0 for every k < K (bias gradient), or -1
+    // fp32x3 engine only: the operand's three bf16 slice planes, prepared once per step by k_presplit for the SMALL operand
+    // of each large GEMM (W1, W11, dZ1, [d10 | 1]; every block tile of the GEMM would otherwise split the same values
+    // again): [3][R][C] bf16 in the orientation of the fp32 matrix, zero-padded to whole tiles
+    const unsigned short* pl;
+    int64_t pl_plane, pl_arm;    // elements per plane / per arm
+    int pl_ld;                   // row pitch (elements)
 };
 
-// One K tile of an operand in flight: rows [r0, r0 + 128) x k [k0, k0 + 64).  `load` only REQUESTS the data (eight
+// One K tile of an operand in flight: rows [r0, r0 + 128) x k [k0, k0 + KT).  `load` only REQUESTS the data (NQ
 // float4 and their mask words per thread; nothing touches the values, so the requests of both operands issue back to
-// back and land while the MFMAs of the previous tile run); `store` masks, rounds to bf16 and writes the LDS image
-// ([128][LDB] dwords, bf16 pairs along k, zero outside the operand).
-template <bool BITS>
+// back and land while the MFMAs of the previous tile run); `store` masks, rounds to bf16 (or splits into the three
+// slices) and writes the LDS image(s) ([128][LDB] dwords, bf16 pairs along k, zero outside the operand).
+template <bool BITS, int NQ = 8>
 struct TileRegsT {
-    float4 v[4][2];
-    uint32_t wd[BITS ? 4 : 1][2];   // keep-mask words (only operands that carry a mask hold them)
+    float4 v[NQ];
+    uint32_t wd[BITS ? NQ : 1];   // keep-mask words (only operands that carry a mask hold them)
 };
-typedef TileRegsT<true> TileRegs;
 
-// quad q of a tile (q < 8): KMAJOR row pass p = q >> 1, k half h = q & 1; KMINOR k-pair group i = q >> 1, k parity h = q & 1
 // Loads go through buffer instructions: the operand's base sits in an SGPR descriptor and a piece is addressed by ONE
 // 32-bit per-lane byte offset computed where it is used (two integer ops), so no 64-bit pointers stay live across the
 // pipeline (sixteen of them per thread cost 32 VGPRs and pushed the kernel into scratch).  Offsets are clamped into the
 // matrix; what must read as zero is selected at the LDS store.  Every operand has ld % 4 == 0 and < 4 GB per arm.
-typedef __attribute__((__vector_size__(4 * sizeof(int)))) int rsrc_t;
 struct OperandDev {
     __amdgpu_buffer_rsrc_t rs, rb;   // matrix, mask words
     int ld, rows, K, wpr, ones_row;
@@ -99,14 +136,21 @@ __device__ __forceinline__ OperandDev make_operand_dev(const Operand& o) {
     return d;
 }
 
-// quad q of a tile (q < 8): KMAJOR row pass p = q >> 1, k half h = q & 1; KMINOR k-pair group p = q >> 1, k parity h = q & 1
-template <bool KMINOR, bool BITS = true>
-__device__ __forceinline__ void quad_load(TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0, int kend, int q) {
-    const int tid = threadIdx.x;
-    const int p = q >> 1, h = q & 1;
+// piece q of a tile (q < NQ).  KMAJOR: thread = row tid >> 3 (+ 32 per row pass p), 16-byte k quad tid & 7 (+ 8 h for the
+// second half of a 64-wide tile): K tile 64 -> p = q >> 1, h = q & 1; K tile 32 -> p = q, h = 0.  KMINOR: rows 4 (tid & 31)
+// .. + 3 of k = 2 (tid >> 5 + 8 p) + h with p = q >> 1, h = q & 1 (K tile 32: p < 2).
+template <bool KMINOR, int NP>
+__device__ __forceinline__ void piece_ph(int q, int& p, int& h) {
+    if (!KMINOR && NP != 1) { p = q; h = 0; }
+    else { p = q >> 1; h = q & 1; }
+}
+template <bool KMINOR, bool BITS = true, int NP = 1>
+__device__ __forceinline__ void quad_load(TileRegsT<BITS, Eng<NP>::NQ>& t, const OperandDev& o, int r0, int k0, int kend, int q) {
+    const int tid = threadIdx.x & 255;     // (the ping-pong kernel runs two 256-thread groups per workgroup)
+    int p, h;
+    piece_ph<KMINOR, NP>(q, p, h);
     int off, woff;
     if (!KMINOR) {
-        // thread: row = tid >> 3 (+32 per pass), k quads (tid & 7) and (tid & 7) + 8
         const int row = r0 + (tid >> 3) + 32 * p;
         const int rc = min(row, o.rows - 1);
         const int k = k0 + ((tid & 7) + 8 * h) * 4;
@@ -114,71 +158,88 @@ __device__ __forceinline__ void quad_load(TileRegsT<BITS>& t, const OperandDev& 
         off = rc * o.ld + (ok ? k : 0);
         woff = rc * o.wpr + ((ok ? k : 0) >> 5);
     } else {
-        // thread: rows 4 (tid & 31) .. + 3, k = 2 (tid >> 5) + 16 p + h; row % 4 == 0 and ld % 4 == 0: the four floats
-        // stay inside the memory row whenever row < ld
+        // row % 4 == 0 and ld % 4 == 0: the four floats stay inside the memory row whenever row < ld
         const int k = k0 + 2 * ((tid >> 5) + 8 * p) + h;
         const int kc = min(k, o.K - 1);
         const int row = r0 + (tid & 31) * 4;
         off = kc * o.ld + (row < o.ld ? row : 0);
         woff = kc * o.wpr + (min(row, o.rows - 1) >> 5);
     }
-    t.v[p][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 4, 0, 0));
-    if constexpr (BITS) t.wd[p][h] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
+#ifdef X3_NOLOAD
+    if (NP == 3 && k0 > 64) return;
+#endif
+    t.v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 4, 0, 0));
+    if constexpr (BITS) t.wd[q] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
 }
 
-template <bool KMINOR, bool BITS = true>
-__device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0,
-                                           int kend, int q) {
-    const int tid = threadIdx.x;
-    const int p = q >> 1, h = q & 1;
+template <bool KMINOR, bool BITS = true, int NP = 1>
+__device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileRegsT<BITS, Eng<NP>::NQ>& t, const OperandDev& o, int r0,
+                                           int k0, int kend, int q) {
+    constexpr int LDBv = Eng<NP>::LDB, PLANE = Eng<NP>::PLANE;
+    const int tid = threadIdx.x & 255;
+    int p, h;
+    piece_ph<KMINOR, NP>(q, p, h);
+    float x[4];
+    int idx;        // dword index of the 8-byte LDS store inside a plane
     if (!KMINOR) {
         const int kq = tid & 7, rr = tid >> 3;
         const int row = r0 + rr + 32 * p;
         const int k = k0 + (kq + 8 * h) * 4;
         const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;
-        const uint32_t nib = BITS ? t.wd[p][h] >> (k & 31) : 0xFu;
-        float4 v = t.v[p][h];
-        v.x = (ok && (nib & 1u)) ? v.x : 0.f;
-        v.y = (ok && (nib & 2u)) ? v.y : 0.f;
-        v.z = (ok && (nib & 4u)) ? v.z : 0.f;
-        v.w = (ok && (nib & 8u)) ? v.w : 0.f;
-        uint2 w;
-        w.x = pack_bf16(v.x, v.y);
-        w.y = pack_bf16(v.z, v.w);
-        *reinterpret_cast<uint2*>(&T[(rr + 32 * p) * LDB + (kq + 8 * h) * 2]) = w;
+        // keep bit e of nib -> an all-ones / all-zeros word (v_bfe_i32) ANDed onto the value: two VALU instructions per
+        // element and no compare -> SGPR -> select chains
+        const int nib = ok ? (BITS ? (int)(t.wd[q] >> (k & 31)) : 0xF) : 0;
+        const float4 v = t.v[q];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = __uint_as_float(__float_as_uint(vv[e]) & (unsigned)__builtin_amdgcn_sbfe(nib, e, 1));
+        idx = (rr + 32 * p) * LDBv + (kq + 8 * h) * 2;
     } else {
         // natural layout [k][row] (rows contiguous, LDK bf16 per k): one 8-byte store per (k, four rows); the MFMA
         // fragments come out of it through the transposing LDS read (ds_read_b64_tr_b16, see frag8)
-        unsigned short* Tk = reinterpret_cast<unsigned short*>(T);
         const int r4 = (tid & 31) * 4, kp = tid >> 5;
         const int kl = 2 * (kp + 8 * p) + h, k = k0 + kl;
         const bool kok = k < kend && k < o.K;
-        const uint32_t nib = BITS ? t.wd[p][h] >> ((r0 + r4) & 31) : 0xFu;
-        const float4 v = t.v[p][h];
+        const int nrow = min(max(o.rows - (r0 + r4), 0), 4);          // rows of this piece that exist
+        const int nib = kok ? ((BITS ? (int)(t.wd[q] >> ((r0 + r4) & 31)) : 0xF) & ((1 << nrow) - 1)) : 0;
+        const float4 v = t.v[q];
         const float vv[4] = {v.x, v.y, v.z, v.w};
-        float x[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = r0 + r4 + e;
-            x[e] = (kok && row < o.rows && ((nib >> e) & 1u)) ? vv[e] : 0.f;
-            if (kok && row == o.ones_row) x[e] = 1.f;
+        for (int e = 0; e < 4; ++e) x[e] = __uint_as_float(__float_as_uint(vv[e]) & (unsigned)__builtin_amdgcn_sbfe(nib, e, 1));
+        if (o.ones_row >= 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (kok && r0 + r4 + e == o.ones_row) x[e] = 1.f;
         }
+        idx = (kl * LDK + r4) >> 1;     // LDK and r4 are multiples of 4 bf16
+    }
+    if constexpr (NP == 1) {
         uint2 w;
         w.x = pack_bf16(x[0], x[1]);
         w.y = pack_bf16(x[2], x[3]);
-        *reinterpret_cast<uint2*>(&Tk[kl * LDK + r4]) = w;
+        *reinterpret_cast<uint2*>(&T[idx]) = w;
+    } else {
+        unsigned w0[3], w1[3];
+        split3(x[0], x[1], w0);
+        split3(x[2], x[3], w1);
+#ifdef X3_NOLDSW
+        if (k0 > 64) { if (w0[0] + w0[1] + w0[2] + w1[0] + w1[1] + w1[2] == 0x12345u) T[idx] = 1; return; }
+#endif
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(&T[pl * PLANE + idx]) = make_uint2(w0[pl], w1[pl]);
     }
 }
 
-template <bool KMINOR, bool BITS = true>
-__device__ __forceinline__ void tile_load(TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0, int kend) {
+template <bool KMINOR, bool BITS = true, int NP = 1>
+__device__ __forceinline__ void tile_load(TileRegsT<BITS, Eng<NP>::NQ>& t, const OperandDev& o, int r0, int k0, int kend) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) quad_load<KMINOR, BITS>(t, o, r0, k0, kend, q);
+    for (int q = 0; q < Eng<NP>::NQ; ++q) quad_load<KMINOR, BITS, NP>(t, o, r0, k0, kend, q);
 }
-template <bool KMINOR, bool BITS = true>
-__device__ __forceinline__ void tile_store(unsigned* __restrict__ T, const TileRegsT<BITS>& t, const OperandDev& o, int r0, int k0, int kend) {
+template <bool KMINOR, bool BITS = true, int NP = 1>
+__device__ __forceinline__ void tile_store(unsigned* __restrict__ T, const TileRegsT<BITS, Eng<NP>::NQ>& t, const OperandDev& o, int r0,
+                                           int k0, int kend) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) quad_store<KMINOR, BITS>(T, t, o, r0, k0, kend, q);
+    for (int q = 0; q < Eng<NP>::NQ; ++q) quad_store<KMINOR, BITS, NP>(T, t, o, r0, k0, kend, q);
 }
 
 // MFMA fragment of a 32-row tile (rows rb .. rb + 31 of the block tile), K step s (16 k's): lane l holds row l % 32,
@@ -186,10 +247,10 @@ __device__ __forceinline__ void tile_store(unsigned* __restrict__ T, const TileR
 // group of 16 lanes the hardware reads a 4 (k) x 16 (rows) block and hands lane i of the group column i, i.e. four
 // consecutive k of row i; lane 4 q + p supplies the address of block row q, columns 4 p .. 4 p + 3.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-template <bool MINOR>
+template <bool MINOR, int LDBv = LDB>
 __device__ __forceinline__ bf16x8 frag8(const unsigned* T, int rb, int s, int lane) {
     if (!MINOR) {
-        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(T + (rb + (lane & 31)) * LDB + 4 * (lane >> 5) + 8 * s));
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(T + (rb + (lane & 31)) * LDBv + 4 * (lane >> 5) + 8 * s));
     } else {
         const unsigned short* Tk = reinterpret_cast<const unsigned short*>(T);
         const int grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
@@ -202,6 +263,64 @@ __device__ __forceinline__ bf16x8 frag8(const unsigned* T, int rb, int s, int la
         r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
         r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
         return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+// A K tile of an operand that exists as slice planes: 3 planes x 128 x 32 bf16 = 1536 sixteen-byte pieces, six per thread
+// of a 256-thread group; a piece is copied global -> register -> LDS untouched (no bounds, no arithmetic).
+struct PlaneRegs { u32x4v v[6]; };
+struct PlaneDev { __amdgpu_buffer_rsrc_t rs; int plane, ld; };
+__device__ __forceinline__ PlaneDev make_plane_dev(const Operand& o, int arm) {
+    PlaneDev d;
+    d.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(o.pl + (int64_t)arm * o.pl_arm), 0, (int)(3 * o.pl_plane * 2), 0x00020000);
+    d.plane = (int)o.pl_plane; d.ld = o.pl_ld;
+    return d;
+}
+template <bool KMINOR>
+__device__ __forceinline__ void plane_load(PlaneRegs& t, const PlaneDev& o, int r0, int k0, int j) {
+    const int tid = threadIdx.x & 255, pl = j >> 1, id = tid + 256 * (j & 1);
+    int off;   // elements
+    if (!KMINOR) off = pl * o.plane + (r0 + (id >> 2)) * o.ld + k0 + 8 * (id & 3);      // row id >> 2, k octet id & 3
+    else off = pl * o.plane + (k0 + (id >> 4)) * o.ld + r0 + 8 * (id & 15);              // k id >> 4, row octet id & 15
+    t.v[j] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 2, 0, 0));
+}
+template <bool KMINOR>
+__device__ __forceinline__ void plane_store(unsigned* __restrict__ T, const PlaneRegs& t, int j) {
+    const int tid = threadIdx.x & 255, pl = j >> 1, id = tid + 256 * (j & 1);
+    int idx;   // dwords
+    if (!KMINOR) idx = pl * Eng<3>::PLANE + (id >> 2) * Eng<3>::LDB + 4 * (id & 3);
+    else idx = pl * Eng<3>::PLANE + (((id >> 4) * LDK + 8 * (id & 15)) >> 1);
+    *reinterpret_cast<u32x4v*>(&T[idx]) = t.v[j];
+}
+
+// fp32 [R][C] (row pitch ld) -> three bf16 slice planes [3][Rp][Cp], zeros outside, column `ones_col` reads 1.0 on the
+// rows that exist (the bias-gradient column of [d10 | 1]).  One thread: eight consecutive columns of one row.
+struct SplitJob {
+    const float* src; int64_t ld, src_arm;
+    int R, C, Rp, Cp, ones_col;
+    unsigned short* dst; int64_t dst_arm;
+};
+struct SplitJobs { SplitJob j[4]; };
+__global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
+    const SplitJob& J = js.j[blockIdx.y];
+    const float* src = J.src + (int64_t)blockIdx.z * J.src_arm;
+    unsigned short* dst = J.dst + (int64_t)blockIdx.z * J.dst_arm;
+    const int c8n = J.Cp >> 3;
+    const int64_t n = (int64_t)J.Rp * c8n, plane = (int64_t)J.Rp * J.Cp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / c8n), c0 = (int)(i % c8n) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            v[e] = (r < J.R && c < J.C) ? src[(int64_t)r * J.ld + c] : ((r < J.R && c == J.ones_col) ? 1.f : 0.f);
+        }
+        unsigned w[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(v[2 * e], v[2 * e + 1], w[e]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint4*>(dst + pl * plane + (int64_t)r * J.Cp + c0) = make_uint4(w[0][pl], w[1][pl], w[2][pl], w[3][pl]);
     }
 }
 
@@ -242,83 +361,45 @@ struct GemmArgs {
     int64_t fo_arm, fo_x_arm;    // arm strides of dz / x_rec and of x (0: the arms share x)
     int n11;
     int A;
+    long long* dbg;              // diagnostic phase counters (builds with -DX3_STAMPS only), else unused
 };
 
-// 16 MFMAs of one K tile: this wave's 64 x 64 of the block tile
-template <bool AMINOR, bool BMINOR>
+// the MFMAs of one K tile: this wave's 64 x 64 of the block tile (NP = 3: six slice products per pair of fragments, the
+// small ones first)
+template <bool AMINOR, bool BMINOR, int NP = 1>
 __device__ __forceinline__ void mfma_ktile(f32x16 (&acc)[2][2], const unsigned* As, const unsigned* Bs, int wm, int wn, int lane) {
+    constexpr int LDBv = Eng<NP>::LDB, PLANE = Eng<NP>::PLANE;
 #pragma unroll
-    for (int s = 0; s < KT / 16; ++s) {
-        const bf16x8 a0 = frag8<AMINOR>(As, wm * 64, s, lane);
-        const bf16x8 a1 = frag8<AMINOR>(As, wm * 64 + 32, s, lane);
-        const bf16x8 b0 = frag8<BMINOR>(Bs, wn * 64, s, lane);
-        const bf16x8 b1 = frag8<BMINOR>(Bs, wn * 64 + 32, s, lane);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    for (int s = 0; s < Eng<NP>::KT / 16; ++s) {
+        bf16x8 a[2][NP], b[2][NP];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            a[0][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64, s, lane);
+            a[1][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64 + 32, s, lane);
+            b[0][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64, s, lane);
+            b[1][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64 + 32, s, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (NP == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            }
     }
 }
 
-// C tile -> slab.  grid (tiles_m * tiles_n, KS, A): block (m tile, n tile) x k range ks x arm.  Tile t + 1 is requested
-// from memory before tile t's MFMAs and written to LDS after them: two barriers per K tile, loads always in flight.
-template <bool AMINOR, bool BMINOR, int EPI = 0>
-__global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
-    const GemmArgs g = g_in;
-    __shared__ __attribute__((aligned(16))) unsigned As[2][BT * LDB];   // two K tiles in LDS: tile t is multiplied while tile
-    __shared__ __attribute__((aligned(16))) unsigned Bs[2][BT * LDB];   // t + 1 is written and tile t + 2 is in flight
-    const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+// The tile epilogues: accumulator register r of tile (i, j) is row m0 + 64 wm + 32 i + acc_row(r), column
+// n0 + 64 wn + 32 j + (lane & 31).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane, int arm) {
     const int l31 = lane & 31;
-    Operand oa_h = g.a, ob_h = g.b;
-    oa_h.ptr += (int64_t)arm * g.a_arm;
-    ob_h.ptr += (int64_t)arm * g.b_arm;
-    if (oa_h.bits) oa_h.bits += (int64_t)arm * g.a_bits_arm;
-    if (ob_h.bits) ob_h.bits += (int64_t)arm * g.b_bits_arm;
-    const OperandDev oa = make_operand_dev<AMINOR>(oa_h), ob = make_operand_dev<BMINOR>(ob_h);
-    const int tiles_n = cdiv(g.N, BT);
-    int wg = blockIdx.x;
-    if (EPI == 1) {   // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x a contiguous range of tiles
-        const int nwg = gridDim.x;
-        if (nwg % 8 == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-    }
-    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * BT;
-    const int nkt = cdiv(g.K, KT);
-    const int kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KT;
-    const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
-    f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
-    TileRegs ta, tb;
-    // Software pipeline at the granularity of one 16-byte piece: a piece of tile t + 1 is rounded and written to LDS
-    // and the SAME registers immediately request the piece of tile t + 2, so sixteen loads per thread are in flight
-    // all the time and every load has a whole iteration (the other fifteen pieces, the MFMAs, the barrier) to land.
-    auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
-        constexpr bool LOAD = decltype(load_tag)::value;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            // (no run-time condition around a load: hipcc then waits for every load separately)
-            quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
-            if constexpr (LOAD) quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
-            quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
-            if constexpr (LOAD) quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
-        }
-    };
-    if (kb < ke) {
-        tile_load<AMINOR>(ta, oa, m0, kb, ke);
-        tile_load<BMINOR>(tb, ob, n0, kb, ke);
-    }
-    if (kb < ke) {
-        if (kb + KT < ke) stage(As[0], Bs[0], kb, kb + KT, VecTag{});
-        else stage(As[0], Bs[0], kb, kb, ScalarTag{});
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kb; k0 < ke; k0 += KT) {
-        mfma_ktile<AMINOR, BMINOR>(acc, As[cur], Bs[cur], wm, wn, lane);
-        if (k0 + 2 * KT < ke) stage(As[cur ^ 1], Bs[cur ^ 1], k0 + KT, k0 + 2 * KT, VecTag{});
-        else if (k0 + KT < ke) stage(As[cur ^ 1], Bs[cur ^ 1], k0 + KT, k0 + KT, ScalarTag{});
-        __syncthreads();
-        cur ^= 1;
-    }
-    // accumulator register r of tile (i, j) is row m0 + 64 wm + 32 i + acc_row(r), column n0 + 64 wn + 32 j + (lane & 31)
     if (EPI == 1) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -353,6 +434,202 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
                 if (row < g.so.M && col < g.so.N) out[(int64_t)row * g.so.ld + col] = acc[i][j][r];
             }
         }
+}
+
+// C tile -> slab.  grid (tiles_m * tiles_n, KS, A): block (m tile, n tile) x k range ks x arm.  Tile t + 1 is written to
+// the second LDS buffer while tile t is multiplied (one barrier per K tile); a piece's registers request tile t + 2 as
+// soon as they have been written out for tile t + 1.
+template <bool AMINOR, bool BMINOR, int EPI = 0>
+__global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
+    const GemmArgs g = g_in;
+    __shared__ __attribute__((aligned(16))) unsigned As[2][BT * LDB];   // two K tiles in LDS: tile t is multiplied while tile
+    __shared__ __attribute__((aligned(16))) unsigned Bs[2][BT * LDB];   // t + 1 is written and tile t + 2 is in flight
+    const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    Operand oa_h = g.a, ob_h = g.b;
+    oa_h.ptr += (int64_t)arm * g.a_arm;
+    ob_h.ptr += (int64_t)arm * g.b_arm;
+    if (oa_h.bits) oa_h.bits += (int64_t)arm * g.a_bits_arm;
+    if (ob_h.bits) ob_h.bits += (int64_t)arm * g.b_bits_arm;
+    const OperandDev oa = make_operand_dev<AMINOR>(oa_h), ob = make_operand_dev<BMINOR>(ob_h);
+    const int tiles_n = cdiv(g.N, BT);
+    int wg = blockIdx.x;
+    if (EPI == 1) {   // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x a contiguous range of tiles
+        const int nwg = gridDim.x;
+        if (nwg % 8 == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+    }
+    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * BT;
+    const int nkt = cdiv(g.K, KT);
+    const int kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KT;
+    const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
+    f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+    TileRegsT<true> ta, tb;
+    // Software pipeline at the granularity of one 16-byte piece: a piece of tile t + 1 is rounded and written to LDS
+    // and the SAME registers immediately request the piece of tile t + 2, so sixteen loads per thread are in flight
+    // all the time and every load has a whole iteration (the other fifteen pieces, the MFMAs, the barrier) to land.
+    auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
+        constexpr bool LOAD = decltype(load_tag)::value;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            // (no run-time condition around a load: hipcc then waits for every load separately)
+            quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
+            if constexpr (LOAD) quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
+            quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
+            if constexpr (LOAD) quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
+        }
+    };
+    if (kb < ke) {
+        tile_load<AMINOR>(ta, oa, m0, kb, ke);
+        tile_load<BMINOR>(tb, ob, n0, kb, ke);
+    }
+    if (kb < ke) {
+        if (kb + KT < ke) stage(As[0], Bs[0], kb, kb + KT, VecTag{});
+        else stage(As[0], Bs[0], kb, kb, ScalarTag{});
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kb; k0 < ke; k0 += KT) {
+        mfma_ktile<AMINOR, BMINOR>(acc, As[cur], Bs[cur], wm, wn, lane);
+        if (k0 + 2 * KT < ke) stage(As[cur ^ 1], Bs[cur ^ 1], k0 + KT, k0 + 2 * KT, VecTag{});
+        else if (k0 + KT < ke) stage(As[cur ^ 1], Bs[cur ^ 1], k0 + KT, k0 + KT, ScalarTag{});
+        __syncthreads();
+        cur ^= 1;
+    }
+    gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, arm);
+}
+
+// The split (NP = 3) engine: fp32 operands as three bf16 planes each, six MFMAs per pair of fragments.  With six times the
+// matrix instructions and eleven VALU instructions per pair of elements for the split, a block tile is no longer a pure
+// memory stream: the matrix phase (48 MFMAs per wave and K tile of 32) and the staging phase (split + LDS writes + the
+// next requests) are about equally long, and two independent workgroups per CU did not overlap them (measured: the sum of
+// the phases, 93 us for fc1).  So ONE workgroup of 512 threads carries TWO block tiles in lock-step ping-pong: group 0
+// (waves 0-3) multiplies its K tile t while group 1 (waves 4-7, one per SIMD beside a wave of group 0) stages its own,
+// and at every workgroup barrier the roles swap -- each SIMD always has one wave on the matrix pipe and one on the
+// VALU / LDS / memory pipes.  A group owns one LDS buffer set (3 planes x 2 operands x 10 KB = 60 KB; 120 KB per CU).
+// grid (ceil(tiles / 2), KS, A): group g of block b owns tile 2 b + g.
+// SHARE: the two tiles of a block are neighbours along m when the GEMM is one tile wide (fc1, d(d10), dW11: same n0,
+// SHARE = 2) or along n when it is one tile high (dW1: same m0, SHARE = 1) -- the narrow operand's K tile is then the
+// SAME for both groups, and what bounds these kernels is the bytes a CU takes in (about 13 B per cycle, measured with
+// in-kernel stamps: a stage phase lasts as long as its loads take to issue).  Group 0 stages the shared operand for both
+// (two LDS buffers, indexed by the K tile's parity; group 1 multiplies tile t while group 0 already stages tile t + 1), a
+// quarter less traffic per pair of tiles.  LDS: two private + two shared buffer sets of 30 KB = 120 KB.
+// SPL: the shared operand comes as slice planes (k_presplit) and is copied, not split again by every block.
+template <bool AMINOR, bool BMINOR, int EPI = 0, int SHARE = 0, bool SPL = false>
+__global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
+    typedef Eng<3> E;
+    constexpr int KTv = E::KT;
+    const GemmArgs g = g_in;
+    __shared__ __attribute__((aligned(16))) unsigned As[2][3 * E::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned Bs[2][3 * E::PLANE];
+    const int arm = blockIdx.z, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    Operand oa_h = g.a, ob_h = g.b;
+    oa_h.ptr += (int64_t)arm * g.a_arm;
+    ob_h.ptr += (int64_t)arm * g.b_arm;
+    if (oa_h.bits) oa_h.bits += (int64_t)arm * g.a_bits_arm;
+    if (ob_h.bits) ob_h.bits += (int64_t)arm * g.b_bits_arm;
+    const OperandDev oa = make_operand_dev<AMINOR>(oa_h), ob = make_operand_dev<BMINOR>(ob_h);
+    const int tiles_n = cdiv(g.N, BT), ntiles = cdiv(g.M, BT) * tiles_n;
+    int wg = 2 * blockIdx.x + grp;
+    const bool active = wg < ntiles;                 // (an odd tile count leaves the last block's second group idle)
+    if (EPI == 1) {   // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x a contiguous range of tiles
+        const int nwg = 2 * gridDim.x;
+        if (nwg == ntiles && nwg % 16 == 0) wg = 2 * ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) + grp;
+    }
+    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * BT;
+    const int nkt = cdiv(g.K, KTv);
+    const int kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KTv;
+    const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KTv);
+    const int n = ke > kb ? cdiv(ke - kb, KTv) : 0;  // K tiles of this block (the same for both groups)
+    f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+    TileRegsT<true, E::NQ> ta, tb;
+    PlaneRegs ps;
+    constexpr bool APL = SPL && SHARE == 1, BPL = SPL && SHARE == 2;
+    const PlaneDev dp = make_plane_dev(SHARE == 1 ? g.a : g.b, arm);
+    const bool do_a = SHARE != 1 || grp == 0, do_b = SHARE != 2 || grp == 0;   // which operands this group stages
+    // one piece of each operand in turn; a piece's registers request the next tile as soon as they have been written out
+    auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
+        constexpr bool LOAD = decltype(load_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if constexpr (APL) {
+                if (do_a) {
+                    plane_store<AMINOR>(Ad, ps, i);
+                    if constexpr (LOAD) plane_load<AMINOR>(ps, dp, m0, kld, i);
+                }
+            } else if (i < E::NQ) {
+                if (do_a) {
+                    quad_store<AMINOR, true, 3>(Ad, ta, oa, m0, kst, ke, i);
+                    if constexpr (LOAD) quad_load<AMINOR, true, 3>(ta, oa, m0, kld, ke, i);
+                }
+            }
+            if constexpr (BPL) {
+                if (do_b) {
+                    plane_store<BMINOR>(Bd, ps, i);
+                    if constexpr (LOAD) plane_load<BMINOR>(ps, dp, n0, kld, i);
+                }
+            } else if (i < E::NQ) {
+                if (do_b) {
+                    quad_store<BMINOR, true, 3>(Bd, tb, ob, n0, kst, ke, i);
+                    if constexpr (LOAD) quad_load<BMINOR, true, 3>(tb, ob, n0, kld, ke, i);
+                }
+            }
+        }
+    };
+    if (active && n > 0) {
+        if constexpr (APL) {
+            if (do_a) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) plane_load<AMINOR>(ps, dp, m0, kb, i);
+            }
+        } else if (do_a) tile_load<AMINOR, true, 3>(ta, oa, m0, kb, ke);
+        if constexpr (BPL) {
+            if (do_b) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) plane_load<BMINOR>(ps, dp, n0, kb, i);
+            }
+        } else if (do_b) tile_load<BMINOR, true, 3>(tb, ob, n0, kb, ke);
+    }
+#ifdef X3_STAMPS
+    long long t_st = 0, t_mf = 0, t_bar = 0, t_ld = 0, t0 = __builtin_amdgcn_s_memtime(), t_begin = t0;
+#endif
+    // phase p: group g is at step q = p - g of its own sequence stage(0), mfma(0), stage(1), mfma(1), ...
+    for (int p = 0; p <= 2 * n; ++p) {
+        const int q = p - grp;
+        if (active && q >= 0 && q < 2 * n) {
+            const int t = q >> 1, k0 = kb + t * KTv;
+            unsigned* const Ad = As[SHARE == 1 ? (t & 1) : grp];
+            unsigned* const Bd = Bs[SHARE == 2 ? (t & 1) : grp];
+            if (q & 1) {
+                mfma_ktile<AMINOR, BMINOR, 3>(acc, Ad, Bd, wm, wn, lane);
+#ifdef X3_STAMPS
+                asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][1]));
+                { const long long t1 = __builtin_amdgcn_s_memtime(); t_mf += t1 - t0; t0 = t1; }
+#endif
+            } else {
+#ifdef X3_STAMPS
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): how long the stage waits for its operands
+                { const long long t1 = __builtin_amdgcn_s_memtime(); t_ld += t1 - t0; t0 = t1; }
+#endif
+                if (k0 + KTv < ke) stage(Ad, Bd, k0, k0 + KTv, VecTag{});
+                else stage(Ad, Bd, k0, k0, ScalarTag{});
+#ifdef X3_STAMPS
+                __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS writes have been issued and accepted
+                { const long long t1 = __builtin_amdgcn_s_memtime(); t_st += t1 - t0; t0 = t1; }
+#endif
+            }
+        }
+        __syncthreads();
+#ifdef X3_STAMPS
+        { const long long t1 = __builtin_amdgcn_s_memtime(); t_bar += t1 - t0; t0 = t1; }
+#endif
+    }
+#ifdef X3_STAMPS
+    if (g.dbg && lane == 0 && wv == 0 && blockIdx.x == 3 && blockIdx.y == 2 && blockIdx.z == 0) {
+        g.dbg[grp * 8 + 0] = t_st; g.dbg[grp * 8 + 1] = t_mf; g.dbg[grp * 8 + 2] = t_bar; g.dbg[grp * 8 + 3] = n;
+        g.dbg[grp * 8 + 4] = __builtin_amdgcn_s_memtime() - t_begin;
+        g.dbg[grp * 8 + 5] = t_ld;
+    }
+#endif
+    if (active) gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, arm);
 }
 
 // fc11 forward + bias + reconstruction loss + dZ11.  The product is computed TRANSPOSED, z^T = W11 d10^T: MFMA rows are
@@ -639,8 +916,26 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers (same workspace layouts and split factors as the fp32 fast path)
 // ---------------------------------------------------------------------------------------------------------------
-static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1}; }
-static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1}; }
+static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1, nullptr, 0, 0, 0}; }
+static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1, nullptr, 0, 0, 0}; }
+
+// slice planes of a small operand (fp32x3 engine): k_presplit job + the operand's plane fields
+static inline int rup_i(int a, int b) { return cdiv(a, b) * b; }
+static SplitJob plane_job(Operand& o, const float* src, int64_t ld, int64_t src_arm, int R, int C, int Rp, int Cp, int ones_col,
+                          float* ws_planes) {
+    unsigned short* dst = reinterpret_cast<unsigned short*>(ws_planes);
+    o.pl = dst; o.pl_plane = (int64_t)Rp * Cp; o.pl_arm = 3 * o.pl_plane; o.pl_ld = Cp;
+    return SplitJob{src, ld, src_arm, R, C, Rp, Cp, ones_col, dst, o.pl_arm};
+}
+static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n) {
+    SplitJobs js{};
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) { js.j[i] = jobs[i]; most = most > (int64_t)jobs[i].Rp * (jobs[i].Cp / 8) ? most : (int64_t)jobs[i].Rp * (jobs[i].Cp / 8); }
+    const int blocks = (int)imin64(256, cdiv64(most, 256));
+    hipLaunchKernelGGL(k_presplit, dim3(blocks, n, A), dim3(256), 0, s, js);
+    HIP_LAUNCH_CHECK("k_presplit");
+    return 0;
+}
 
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs) {
     const mmvae_dims& d = c.d;
@@ -653,7 +948,13 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
     g.b_arm = c.po.per_arm;
     g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A;
     g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
-    hipLaunchKernelGGL((k_bf16_gemm<false, false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+    g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
+    if (split3_gemms(c)) {   // (fc_dim <= 124: one tile wide, the two tiles of a block share the W1 tile)
+        const SplitJob j = plane_job(g.b, params + c.po.o[0], d.D, c.po.per_arm, d.H, d.D, 128, rup_i(d.D, 32), -1, c.ws + c.lay.pl_w1);
+        if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+        hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+    } else
+        hipLaunchKernelGGL((k_bf16_gemm<false, false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
     HIP_LAUNCH_CHECK("k_bf16_gemm<fc1>");
     return 0;
 }
@@ -697,7 +998,12 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.b_arm = c.po.per_arm;
         g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A;
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
-        hipLaunchKernelGGL((k_bf16_gemm<false, true>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), NS, d.A), dim3(256), 0, c.stream, g);
+        if (split3_gemms(c)) {
+            const SplitJob j = plane_job(g.b, params + c.po.o[26], d.H, c.po.per_arm, d.D, d.H, rup_i(d.D, 128), 128, -1, c.ws + L.pl_w11);
+            if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+            hipLaunchKernelGGL((k_x3_gemm<false, true, 0, 2, true>), dim3(cdiv(cdiv(d.B, BT), 2), NS, d.A), dim3(512), 0, c.stream, g);
+        } else
+            hipLaunchKernelGGL((k_bf16_gemm<false, true>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), NS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<gd10>");
     }
     return 0;
@@ -715,8 +1021,14 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.b_arm = xs;
         if (use_mask) { g.b.bits = reinterpret_cast<const uint32_t*>(c.ws + L.xbits); g.b.wpr = cdiv(d.D, 32); g.b_bits_arm = (int64_t)d.B * g.b.wpr; }
         g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A;
+        g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
         g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
-        hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+        if (split3_gemms(c)) {   // one tile high: the two tiles of a block share the dZ1 tile
+            const SplitJob j = plane_job(g.a, c.ws + L.DZ[1], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 128), 128, -1, c.ws + L.pl_dz1);
+            if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+        } else
+            hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW1>");
     }
     if (which & 2) {   // [dW11 | db11][j][h] = sum_b dZ11[b][j] [d10 | 1][b][h]
@@ -727,8 +1039,14 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.b.ones_row = d.H;                                      // logical row H (not in memory) reads 1: the bias gradient
         g.b_arm = (int64_t)d.B * d.H;
         g.M = d.D; g.N = d.H + 1; g.K = d.B; g.KS = L.sp.ks_dw11; g.A = d.A;
+        g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
-        hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+        if (split3_gemms(c)) {   // one tile wide: the two tiles of a block share the [d10 | 1] tile
+            const SplitJob j = plane_job(g.b, c.ws + L.Dk[4], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 128), 128, d.H, c.ws + L.pl_d10);
+            if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+        } else
+            hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW11>");
     }
     return 0;
@@ -736,13 +1054,16 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
 
 // C[M][ld] = act((A[M][K] . W[N][K]^T) * scale + shift): the augmenter's layers with bf16 operands (augment.hip)
 int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw, int N,
-                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols) {
+                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3) {
     GemmArgs g{};
     g.a = kmajor(A, lda, M, Kpad);        // rows are zero-padded to Kpad = pad4(K) floats on both sides
     g.b = kmajor(W, ldw, N, Kpad);
     g.M = M; g.N = ncols; g.K = Kpad; g.KS = 1; g.A = 1;
     g.ao = AffineOut{sc, sh, C, ldc, M, N, relu ? 1 : 0, affine ? 1 : 0};
-    hipLaunchKernelGGL((k_bf16_gemm<false, false, 1>), dim3(cdiv(M, BT) * cdiv(ncols, BT), 1, 1), dim3(256), 0, s, g);
+    if (split3)
+        hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 0>), dim3(cdiv(cdiv(M, BT) * cdiv(ncols, BT), 2), 1, 1), dim3(512), 0, s, g);
+    else
+        hipLaunchKernelGGL((k_bf16_gemm<false, false, 1>), dim3(cdiv(M, BT) * cdiv(ncols, BT), 1, 1), dim3(256), 0, s, g);
     HIP_LAUNCH_CHECK("k_bf16_gemm<affine>");
     return 0;
 }

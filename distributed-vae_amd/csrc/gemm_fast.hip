@@ -1437,7 +1437,7 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
 
 int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad,
                      int which /*bit0: x_rec/loss/dZ11 kernel, bit1: d(d10) GEMM*/) {
-    if (bf16_gemms(c)) return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
+    if (bf16_gemms(c) && !split3_gemms(c)) return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int ldk = rup(d.H, 8) + 4;

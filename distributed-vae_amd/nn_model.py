@@ -239,11 +239,9 @@ class mixVAE_model(nn.Module):
         self._explicit_noise = list(noise) if isinstance(noise, (list, tuple)) else noise
 
     def _hyper(self, temp: float, eval_flag: bool) -> N.Hyper:
-        if self.gemm_dtype not in ("fp32", "bf16"):
-            raise ValueError(f"gemm_dtype must be 'fp32' or 'bf16', got {self.gemm_dtype!r}")
         return N.Hyper(self.tau, float(temp), self.beta, self.lam, self.eps, self.momentum, float(self.x_dp.p),
                        float(self.s_dp.p), int(bool(self.hard)), int(self.training), int(bool(eval_flag)),
-                       int(self.gemm_dtype == "bf16"))
+                       N.gemm_mode(self.gemm_dtype))
 
     def _next_noise(self) -> N.Noise:
         if isinstance(self._explicit_noise, list):

@@ -1,0 +1,136 @@
+"""-m gpu: the fp32 configuration's large GEMMs on the bf16 matrix pipe (``gemm_dtype = "fp32x3"``,
+``mmvae_hyper.gemm_bf16 == 2``; csrc/gemm_bf16.hip with three LDS planes per operand).
+
+An fp32 operand is split exactly into three bf16 slices (8 + 8 + 8 significand bits) and a product is formed from six
+of the nine slice products; what is dropped is <= 2^-26 of |a b|, below the fp32 rounding of the accumulation.  So the
+engine must be as close to the fp64 product OF THE FP32 OPERANDS as the fp32 matrix instruction is -- that is what is
+tested: every product is recomputed on the host in fp64 from the operands the device consumed (no rounding of the
+operands), and the split engine's distance from it is bounded by an absolute 2e-6 of the result's scale (fp32
+accumulation of up to 5000 terms) and by twice the distance of the fp32-MFMA engine on the same inputs.
+Reference arithmetic: mmidas/nn_model.py:263-287 (fc1, fc11), :542-546 (loss), autograd of both.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ABS_TOL = 2e-6
+
+
+def _run(h, B, seed, dtype):
+    from tests import gpu_util as U
+    sd = R.init_state_dict(h, seed)
+    x = R.synthetic_batch(B, h.input_dim, seed=seed + 1)
+    noise = R.draw_noise(h, B, seed=seed + 2)
+    m = U.build_model(h, sd)
+    m.train()
+    m.gemm_dtype = dtype
+    m.set_explicit_noise(U.noise_to_device(noise))
+    buf = m.fused_train_step(x.to(DEV).expand(h.n_arm, -1, -1), 1.0, None, do_adam=False).clone()
+    torch.cuda.synchronize()
+    return m, sd, x, noise, buf.cpu()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def _products(m, sd, x, noise, h, B):
+    """distance of each large product from the fp64 product of the operands the device consumed"""
+    A, D, H = h.n_arm, h.input_dim, h.fc_dim
+    eng = m._engine
+    keep = 1.0 / (1.0 - h.x_drop)
+    ns = eng.splits()[4]
+    d10 = eng.ws_view("d10", H).cpu().double()
+    dz11 = eng.ws_view("dz11", D).cpu().double()
+    dz1 = eng.ws_view("dz1", H).cpu().double()
+    r1 = eng.ws_view("r1", H).cpu().double()
+    gd10 = eng.ws_raw("gd10_slab", ns * A * B * H).view(ns, A, B, H).cpu().double().sum(0)
+    grads = {k: gv.detach().cpu().double() for (k, _), gv in zip(m.named_parameters(), m._grad_views)}
+    coef = max(A - 1, 1) / B
+    err = {}
+    for a in range(A):
+        xm = (x * noise["x_mask"][a].float()).double()
+        w1, b1 = sd[f"fc1.{a}.weight"].double(), sd[f"fc1.{a}.bias"].double()
+        w11, b11 = sd[f"fc11.{a}.weight"].double(), sd[f"fc11.{a}.bias"].double()
+        err["fc1", a] = _rel(r1[a], torch.relu(keep * (xm @ w1.t()) + b1))
+        z = d10[a] @ w11.t() + b11
+        want = coef * (torch.relu(z) - x.double()) * (z > 0)
+        sure = z.abs() > 1e-4                                  # fp32 accumulation may flip a ReLU at |z| ~ 0
+        err["fc11", a] = float(((dz11[a] - want).abs() * sure).max()) / float(want.abs().max())
+        assert float(sure.double().mean()) > 0.99
+        err["gd10", a] = _rel(gd10[a], dz11[a] @ w11)
+        err["dW1", a] = _rel(grads[f"fc1.{a}.weight"], keep * (dz1[a].t() @ xm))
+        err["dW11", a] = _rel(grads[f"fc11.{a}.weight"], dz11[a].t() @ d10[a])
+        err["db11", a] = _rel(grads[f"fc11.{a}.bias"], dz11[a].sum(0))
+    return err
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 520, 100), (3, 130, 192, 100), (2, 257, 1000, 64), (2, 1100, 2600, 100)])
+def test_split_engine_is_as_close_to_the_exact_products_as_the_fp32_matrix_instruction(shape):
+    A, B, D, H = shape
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=12, state_dim=2, lowD_dim=6, n_arm=A)
+    m, sd, x, noise, _ = _run(h, B, 21, "fp32x3")
+    assert m._hyper(1.0, False).gemm_bf16 == 2
+    e3 = _products(m, sd, x, noise, h, B)
+    m0, sd0, x0, noise0, _ = _run(h, B, 21, "fp32_mfma")
+    assert m0._hyper(1.0, False).gemm_bf16 == 0
+    e0 = _products(m0, sd0, x0, noise0, h, B)
+    print({k: ("%.1e" % e3[k], "%.1e" % e0[k]) for k in e3})
+    for k in e3:
+        assert e3[k] < max(ABS_TOL, 2.0 * e0[k]), (k, e3[k], e0[k])
+
+
+@pytest.mark.parametrize("name", G.SMALL_CASES)
+def test_split_configuration_passes_the_fp32_gates_of_the_reference_fixtures(name):
+    """The reference-generated golden cases at the fp32 tolerances of tests/test_gpu_parity.py (forward 1e-4, loss 1e-5,
+    gradients 1e-3 of the largest magnitude)."""
+    from tests import gpu_util as U
+    g = G.load(name)
+    h = G.hyper_of(g)
+    m = U.build_model(h, G.state_dict_of(g))
+    m.train()
+    m.gemm_dtype = "fp32x3"
+    x = torch.from_numpy(g["x"]).to(DEV)
+    out, lt, grads = U.run_step(m, x, G.noise_of(g))
+    for got, key in ((lt[0], "loss/total"), (lt[2], "loss/joint"), (lt[4], "loss/c_dist")):
+        assert abs(float(got) - float(g[key])) <= 1e-5 * abs(float(g[key])), key
+    assert G.rel_err(lt[1].cpu(), g["loss/rec"]) < 1e-5
+    hard = bool(g["hard"])
+    for k, v in grads.items():
+        ref = torch.from_numpy(g["grad/" + k])
+        assert G.rel_err(v, ref) < (5e-2 if hard else 1e-3), k
+
+
+def test_split_configuration_at_full_size_is_as_close_to_the_fp64_oracle_as_the_fp32_engine():
+    """A = 2, B = D = 5000: the fused step's loss vector and gradients against the oracle evaluated in fp64, split engine
+    and fp32-MFMA engine side by side (90th-percentile entry error per tensor, as tests/test_gpu_fullsize.py)."""
+    A, B, D = 2, 5000, 5000
+    h = R.Hyper(input_dim=D, n_arm=A)
+    m3, sd, x, noise, buf3 = _run(h, B, 546, "fp32x3")
+    g3 = {k: gv.detach().cpu().double() for (k, _), gv in zip(m3.named_parameters(), m3._grad_views)}
+    del m3
+    m0, _, _, _, buf0 = _run(h, B, 546, "fp32_mfma")
+    g0 = {k: gv.detach().cpu().double() for (k, _), gv in zip(m0.named_parameters(), m0._grad_views)}
+    del m0
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    noise64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in noise.items()}
+    _, lt, gref = R.grads_autograd(sd64, [x.double()] * A, h, noise64)
+    want = [float(lt[0]), float(lt[2]), float(lt[3]), float(lt[4]), float(lt[5])] + [float(v) for v in lt[1]]
+    for buf, tag in ((buf3, "fp32x3"), (buf0, "fp32_mfma")):
+        errs = [abs(a - b) / (abs(b) + 1e-30) for a, b in zip(buf[:5 + A].double().tolist(), want)]
+        print(tag, "loss vector relative errors:", ["%.1e" % e for e in errs])
+        assert max(errs) < 1e-5, (tag, errs)
+    for k in gref:
+        ref = gref[k].double()
+        scale = float(ref.abs().max()) + 1e-300
+        q3 = float(torch.quantile(((g3[k] - ref).abs() / scale).flatten()[:4_000_000], 0.9))
+        q0 = float(torch.quantile(((g0[k] - ref).abs() / scale).flatten()[:4_000_000], 0.9))
+        m3e, m0e = _rel(g3[k], ref), _rel(g0[k], ref)
+        print("%-22s p90 %.1e (fp32_mfma %.1e)   max %.1e (%.1e)" % (k, q3, q0, m3e, m0e))
+        assert q3 < max(1e-5, 3.0 * q0), k
+        assert m3e < 5e-3, k
