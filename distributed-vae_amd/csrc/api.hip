@@ -147,7 +147,7 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.small_slab = take((int64_t)L.sp.ks_small * A * N_SMALL * NP * SMALL_LD);
     L.xbits = take(A * B * cdiv(d.D, 32));
     {   // slice planes (bf16: two per float)
-        const int64_t Dk = cdiv64(D, 32) * 32, Dr = cdiv64(D, 128) * 128, Br = cdiv64(B, 128) * 128;
+        const int64_t Dk = cdiv64(D, 32) * 32, Dr = cdiv64(D, 128) * 128, Br = cdiv64(B, 256) * 256;
         L.pl_w1 = take(A * 3 * 128 * Dk / 2);
         L.pl_w11 = take(A * 3 * Dr * 128 / 2);
         L.pl_dz1 = take(A * 3 * Br * 128 / 2);

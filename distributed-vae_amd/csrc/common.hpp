@@ -67,9 +67,9 @@ struct Layout {
     // bf16 slice planes of the SMALL operands of the large GEMMs (fp32x3 engine, gemm_bf16.hip): [A][3][rows][cols] bf16,
     // zero-padded to whole tiles so that the GEMMs copy them into LDS without bounds checks or arithmetic
     int64_t pl_w1;                 // W1   [H -> 128][D -> rup 32]
-    int64_t pl_w11;                // W11  [D -> rup 128][H -> 128]
-    int64_t pl_dz1;                // dZ1  [B -> rup 128][H -> 128]
-    int64_t pl_d10;                // [d10 | 1]  [B -> rup 128][H + 1 -> 128]
+    int64_t pl_w11;                // [W11 | b11]  [D -> rup 128][H + 1 -> 128]
+    int64_t pl_dz1;                // dZ1  [B -> rup 256][H -> 128]
+    int64_t pl_d10;                // [d10 | 1]  [B -> rup 256][H + 1 -> 128]
     int64_t loss_scratch;          // small
     int64_t total;
 };

@@ -74,18 +74,24 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 // the three bf16 slices of two fp32 values (low half: a, high half: b)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // one v_cvt_pk_bf16_f32 (low half: a), round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void split3(float a, float b, unsigned (&w)[3]) {
-    w[0] = pack_bf16(a, b);
+    // eleven VALU instructions per pair: 3 conversions, 4 half -> float, 4 exact subtractions
+    w[0] = cvt_pk_bf16(a, b);
 #ifdef X3_NOSPLIT
     w[1] = w[2] = w[0];
     return;
 #endif
     a -= __uint_as_float(w[0] << 16);
     b -= __uint_as_float(w[0] & 0xFFFF0000u);
-    w[1] = pack_bf16(a, b);
+    w[1] = cvt_pk_bf16(a, b);
     a -= __uint_as_float(w[1] << 16);
     b -= __uint_as_float(w[1] & 0xFFFF0000u);
-    w[2] = pack_bf16(a, b);
+    w[2] = cvt_pk_bf16(a, b);
 }
 
 struct Operand {
@@ -299,11 +305,13 @@ struct SplitJob {
     const float* src; int64_t ld, src_arm;
     int R, C, Rp, Cp, ones_col;
     unsigned short* dst; int64_t dst_arm;
+    const float* col_src; int64_t col_arm;   // column `ones_col` reads col_src[row] instead of 1.0 (the bias column of [W11 | b11])
 };
 struct SplitJobs { SplitJob j[4]; };
 __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
     const SplitJob& J = js.j[blockIdx.y];
     const float* src = J.src + (int64_t)blockIdx.z * J.src_arm;
+    const float* col = J.col_src ? J.col_src + (int64_t)blockIdx.z * J.col_arm : nullptr;
     unsigned short* dst = J.dst + (int64_t)blockIdx.z * J.dst_arm;
     const int c8n = J.Cp >> 3;
     const int64_t n = (int64_t)J.Rp * c8n, plane = (int64_t)J.Rp * J.Cp;
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e;
-            v[e] = (r < J.R && c < J.C) ? src[(int64_t)r * J.ld + c] : ((r < J.R && c == J.ones_col) ? 1.f : 0.f);
+            v[e] = (r < J.R && c < J.C) ? src[(int64_t)r * J.ld + c] : ((r < J.R && c == J.ones_col) ? (col ? col[r] : 1.f) : 0.f);
         }
         unsigned w[4][3];
 #pragma unroll
@@ -913,6 +921,245 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
     }
 }
 
+// fc11 forward + bias + reconstruction loss + dZ11 + d(d10) of the fp32x3 configuration (the train step's dominant kernel).
+// Same mathematics and data flow as k_bf16_fc11g -- z^T = W11 d10^T on the matrix pipe with the cell on the lane, the
+// dZ11 piece in the accumulator IS the next product's operand -- with every operand as three bf16 slices and six slice
+// products per product:
+//   * [W11 | b11] and [d10 | 1] arrive as slice planes (k_presplit, once per step): the bias rides as k = fc_dim, so the
+//     accumulator already holds z + b and the epilogue loads no bias;
+//   * 512 threads = 8 waves x 32 cells; a wave keeps its cells' d10 slices in REGISTERS for the whole kernel (7 K steps x
+//     3 slices x 4 VGPRs) -- per wave private data, and as LDS images they would not leave room for anything else;
+//   * LDS holds only the W11 tile (64 genes x 128 k x 3 slices, row pitch 272 B), double-buffered and filled by
+//     LDS-DMA (global_load_lds_dwordx4: no registers, no VALU); it serves the z product as the A operand (ds_read_b128)
+//     and the d(d10) product as the B operand through transposing reads (ds_read_b64_tr_b16);
+//   * dZ11 is split into its slices in registers between the two products (eleven VALU instructions per pair).
+// grid (ceil(B / 256), gene splits NS, A); fc_dim + 1 <= 112.
+constexpr int FW_ROW = 68;                     // dwords per W11 image row: 128 bf16 + 16 B
+constexpr int FW_PLANE = 64 * FW_ROW;          // dwords per slice image of a 64-gene tile
+constexpr int FW_TILE = 3 * FW_PLANE;
+__global__ __launch_bounds__(512, 1) void k_x3_fc11g(const GemmArgs g_in) {
+    const GemmArgs g = g_in;
+    __shared__ __attribute__((aligned(16))) unsigned Wl[2][FW_TILE];
+    __shared__ float red[16];
+    const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const unsigned short* Wp = g.b.pl + (int64_t)arm * g.b.pl_arm;      // [3][Dr][128]
+    const unsigned short* Dp = g.a.pl + (int64_t)arm * g.a.pl_arm;      // [3][Br][128]
+    const int64_t wplane = g.b.pl_plane, dplane = g.a.pl_plane;
+    const int B = g.fo.B, D = g.fo.D, H = g.K;
+    const int c0 = blockIdx.x * 256;
+    const int tiles = cdiv(D, 64);
+    const int t0 = (int)(((int64_t)blockIdx.y * tiles) / g.KS), t1 = (int)(((int64_t)(blockIdx.y + 1) * tiles) / g.KS);
+    const int cell = c0 + 32 * wv + l31;
+    const float* xa = g.fo.x + (int64_t)arm * g.fo_x_arm;
+    float* dza = g.fo.dz + (int64_t)arm * g.fo_arm;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa), 0, (int)((int64_t)B * D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(dza, 0, (int)((int64_t)B * D * 4), 0x00020000);
+    const int rowoff = min(cell, B - 1) * D;          // B * D < 2^30 (fast-path condition)
+    const bool cell_ok = cell < B;
+
+    // LDS-DMA of W11 tile t into buffer `buf`: 3 slices x 64 rows x 17 sixteen-byte pieces (the 17th is the row's pad and
+    // re-reads piece 0) = 51 wave instructions of 1 KB, seven per wave (the last wave repeats instruction 50).
+    auto dma = [&](int t, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int ii = min(wv + 8 * j, 50);
+            const int pl = ii / 17, chunk = ii - 17 * pl;
+            const int pc = chunk * 64 + lane, row = pc / 17, c = pc - 17 * row;
+            // (32-bit element offsets: the planes of an arm are a few MB; 64-bit per-lane addresses for seven pieces spilled)
+            const unsigned off = (unsigned)pl * (unsigned)wplane + (unsigned)(t * 64 + row) * 128u + (c < 16 ? 8u * c : 0u);
+            const unsigned short* src = Wp + off;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(&Wl[buf][pl * FW_PLANE + chunk * 256]), 16, 0, 0);
+        }
+    };
+    if (t0 < t1) dma(t0, 0);
+    // this wave's d10 slices: lane = cell, K step s holds k = 16 s + 8 hh .. + 7
+    bf16x8 dfr[7][3];
+    {
+        const int cr = min(cell, (int)(dplane / 128) - 1);
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                dfr[s][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Dp + (int64_t)pl * dplane + (int64_t)cr * 128 + 16 * s + 8 * hh));
+    }
+    f32x16 gd[4] = {zero16(), zero16(), zero16(), zero16()};   // d(d10)[cell = 32 wv + row][h = 32 nt + (lane & 31)]
+    float seq[4] = {0.f, 0.f, 0.f, 0.f};
+    int mism = 0;                       // wave-uniform: mismatches of the whole wave
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    // transposing-read address of this lane inside a (4 genes x 16 h) block: row (lane & 15) >> 2, columns 4 (lane & 3) ..
+    const int tr_off = ((lane & 15) >> 2) * (2 * FW_ROW) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    float4 xin[4];
+    auto request_x = [&](int j0g) __attribute__((always_inline)) {      // x of the 32-gene piece that starts at gene j0g
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int gene = j0g + 8 * q + 4 * hh;                      // D % 4 == 0: a float4 exists entirely or not at all
+            xin[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (cell_ok && gene < D) ? (rowoff + gene) * 4 : -16, 0, 0));
+        }
+    };
+    if (t0 < t1) request_x(t0 * 64);
+#ifdef X3_STAMPS
+    long long tz = 0, te = 0, td = 0, tw = 0, tx = 0, tp = __builtin_amdgcn_s_memtime(), tbeg = tp;
+#define X3_ST(var) { const long long t1_ = __builtin_amdgcn_s_memtime(); var += t1_ - tp; tp = t1_; }
+#else
+#define X3_ST(var)
+#endif
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        // the tile's DMA was issued one tile ago, in front of sixteen younger vector-memory instructions (2 x (4 stores +
+        // 4 loads)); vector-memory instructions retire in order, so "at most eight outstanding" leaves only the last
+        // piece's stores and the x prefetch in flight and guarantees the DMA has landed
+        if (t == t0) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0F78);                // vmcnt(8)
+        __syncthreads();
+        X3_ST(tw)
+        if (t + 1 < t1) dma(t + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned* Wt = Wl[buf];
+        const unsigned short* Wt16 = reinterpret_cast<const unsigned short*>(Wt);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int j0g = t * 64 + 32 * gi;
+            // ---- z^T piece: 32 genes x this wave's 32 cells (bias included: k = H)
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Wt + pl * FW_PLANE + (32 * gi + l31) * FW_ROW + 8 * s + 4 * hh));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], dfr[s][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], dfr[s][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], dfr[s][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][0], acc, 0, 0, 0);
+            }
+#ifdef X3_STAMPS
+            asm volatile("" :: "v"(acc));
+            X3_ST(tz)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            X3_ST(tx)
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- epilogue: acc[4 q + e] is gene j0g + 8 q + 4 hh + e of cell `cell`.  Cells and genes that do not exist
+            // have z = 0 (zero rows of the slice planes) and read x = 0 (buffer range), so they need no masks: error, dZ11
+            // and mismatch come out as zero by themselves.  Eight VALU instructions per element; the mismatch count is
+            // kept on the scalar unit (lane-mask population counts), outside the VALU's dependency chains.
+            unsigned au[2][3][4];          // dZ11 slices: K step c (sixteen genes in register order), slice, four dwords
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gene = j0g + 8 * q + 4 * hh;
+                const float xv[4] = {xin[q].x, xin[q].y, xin[q].z, xin[q].w};
+                float dz[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a_ = acc[4 * q + e];
+                    // max(z, 0) as ONE instruction: a signed-integer maximum of the bit pattern (fmaxf also canonicalises its
+                    // input -- a second v_max_f32 per element)
+                    const float xr = __int_as_float(max(__float_as_int(a_), 0));
+                    const float er = xr - xv[e];
+                    seq[q] = __builtin_fmaf(er, er, seq[q]);
+                    const float d_ = g.fo.coef * er;
+                    dz[e] = a_ > 0.f ? d_ : 0.f;
+                    mism += __builtin_popcountll(__builtin_amdgcn_ballot_w64(xr > 0.1f) ^ __builtin_amdgcn_ballot_w64(xv[e] > 0.1f));
+                }
+                // (always issued -- the counted wait above relies on it; what must not be written gets an offset beyond the
+                // buffer's range, which the hardware drops)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, make_float4(dz[0], dz[1], dz[2], dz[3])), rz,
+                                                       (cell_ok && gene < D) ? (cell * D + gene) * 4 : -16, 0, 0);
+                unsigned w0[3], w1[3];
+                split3(dz[0], dz[1], w0);
+                split3(dz[2], dz[3], w1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) { au[q >> 1][pl][2 * (q & 1)] = w0[pl]; au[q >> 1][pl][2 * (q & 1) + 1] = w1[pl]; }
+            }
+            asm volatile("" : "+s"(mism));
+            // x of the next piece (its registers are free now; the loads land under the MFMAs below and the next z product)
+            {
+                const int nxt = gi == 0 ? j0g + 32 : (t + 1) * 64;
+                request_x(nxt);
+            }
+            __builtin_amdgcn_s_setprio(0);
+#ifdef X3_STAMPS
+            asm volatile("" :: "v"(au[0][0][0]), "v"(au[1][2][3]));
+            X3_ST(te)
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- d(d10) += dZ11 piece (registers) x W11 rows 32 gi .. + 31 (LDS, transposed): two K steps of sixteen genes
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    u32x4v u;
+                    u[0] = au[c][pl][0]; u[1] = au[c][pl][1]; u[2] = au[c][pl][2]; u[3] = au[c][pl][3];
+                    af[pl] = __builtin_bit_cast(bf16x8, u);
+                }
+                const int grow = 32 * gi + 16 * c + 4 * hh;            // first of this lane's two gene groups (second: + 8)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    bf16x8 w[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned short* a = Wt16 + pl * (2 * FW_PLANE) + grow * (2 * FW_ROW) + 32 * nt + tr_off;
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * (2 * FW_ROW)));
+                        s16x8 r;
+                        r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
+                        r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
+                        w[pl] = __builtin_bit_cast(bf16x8, r);
+                    }
+                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], w[0], gd[nt], 0, 0, 0);
+                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], w[2], gd[nt], 0, 0, 0);
+                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], w[1], gd[nt], 0, 0, 0);
+                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], w[0], gd[nt], 0, 0, 0);
+                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], w[1], gd[nt], 0, 0, 0);
+                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], w[0], gd[nt], 0, 0, 0);
+                }
+            }
+#ifdef X3_STAMPS
+            asm volatile("" :: "v"(gd[0]), "v"(gd[3]));
+            X3_ST(td)
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#ifdef X3_STAMPS
+    if (g.dbg && lane == 0 && (wv == 0 || wv == 4) && blockIdx.x == 3 && blockIdx.y == 2 && blockIdx.z == 0) {
+        long long* o = g.dbg + (wv >> 2) * 8;
+        o[0] = tz; o[1] = te; o[2] = td; o[3] = 2 * (t1 - t0); o[4] = __builtin_amdgcn_s_memtime() - tbeg; o[5] = tw; o[6] = tx;
+    }
+#endif
+    // ---- d(d10) partial of this gene range: slab [NS][A][B][H]; gd[nt][r]: cell row acc_row(r), h = 32 nt + (lane & 31)
+    {
+        float* out = g.so.out + (int64_t)blockIdx.y * g.so.ks_stride + (int64_t)arm * g.so.arm_stride;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int h = 32 * nt + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = c0 + 32 * wv + acc_row(r, lane);
+                if (row < B && h < H) out[(int64_t)row * H + h] = gd[nt][r];
+            }
+        }
+    }
+    const float se = wave_sum((seq[0] + seq[1]) + (seq[2] + seq[3]));
+    if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = (float)mism; }
+    __syncthreads();
+    if (tid == 0) {
+        float* p = g.fo.part + ((int64_t)arm * g.n11 + (int64_t)blockIdx.x * g.KS + blockIdx.y) * 2;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { a0 += red[2 * w]; a1 += red[2 * w + 1]; }
+        p[0] = a0;
+        p[1] = a1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers (same workspace layouts and split factors as the fp32 fast path)
 // ---------------------------------------------------------------------------------------------------------------
@@ -925,7 +1172,7 @@ static SplitJob plane_job(Operand& o, const float* src, int64_t ld, int64_t src_
                           float* ws_planes) {
     unsigned short* dst = reinterpret_cast<unsigned short*>(ws_planes);
     o.pl = dst; o.pl_plane = (int64_t)Rp * Cp; o.pl_arm = 3 * o.pl_plane; o.pl_ld = Cp;
-    return SplitJob{src, ld, src_arm, R, C, Rp, Cp, ones_col, dst, o.pl_arm};
+    return SplitJob{src, ld, src_arm, R, C, Rp, Cp, ones_col, dst, o.pl_arm, nullptr, 0};
 }
 static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n) {
     SplitJobs js{};
@@ -966,6 +1213,32 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
     // forward for gradients without x_rec (the train step, mmvae_forward(need_grad) for backward): one fused kernel, and
     // the call for d(d10) (which & 2) has nothing left to do; with x_rec wanted (or MMVAE_TUNE_FC11_ZG_OFF) two kernels
     const bool fused = need_grad && !x_rec && !c.tune(MMVAE_TUNE_FC11_ZG_OFF);
+    if (split3_gemms(c)) {
+        // fp32x3: only the fused train-step kernel exists in this engine (fc_dim + 1 <= 112, 256 cells per block fit the
+        // loss-partial slots); everything else runs the fp32 matrix-instruction kernels (the caller falls through)
+        if (!(which & 1)) return 0;
+        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
+        GemmArgs g{};
+        g.a = kmajor(c.ws + L.Dk[4], d.H, d.B, d.H);
+        g.b = kmajor(params + c.po.o[26], d.H, d.D, d.H);
+        SplitJob jobs[2];
+        jobs[0] = plane_job(g.b, params + c.po.o[26], d.H, c.po.per_arm, d.D, d.H, rup_i(d.D, 128), 128, d.H, c.ws + L.pl_w11);
+        jobs[0].col_src = params + c.po.o[27];      // the bias as column k = fc_dim
+        jobs[0].col_arm = c.po.per_arm;
+        jobs[1] = plane_job(g.a, c.ws + L.Dk[4], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 256), 128, d.H, c.ws + L.pl_d10);
+        if (int rc = launch_presplit(c.stream, d.A, jobs, 2)) return rc;
+        g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.A = d.A; g.n11 = L.n11;
+        g.fo = Fc11Out{params + c.po.o[27], x, c.ws + L.DZ11, nullptr, c.ws + L.fc11_part,
+                       (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D};
+        g.fo_arm = (int64_t)d.B * d.D;
+        g.fo_x_arm = xs;
+        g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
+        g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
+        hipLaunchKernelGGL(k_x3_fc11g, dim3(cdiv(d.B, 256), NS, d.A), dim3(512), 0, c.stream, g);
+        HIP_LAUNCH_CHECK("k_x3_fc11g");
+        return 0;
+    }
     if (which & 1) {
         hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
@@ -1042,7 +1315,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
         if (split3_gemms(c)) {   // one tile wide: the two tiles of a block share the [d10 | 1] tile
-            const SplitJob j = plane_job(g.b, c.ws + L.Dk[4], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 128), 128, d.H, c.ws + L.pl_d10);
+            const SplitJob j = plane_job(g.b, c.ws + L.Dk[4], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 256), 128, d.H, c.ws + L.pl_d10);
             if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
             hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
         } else

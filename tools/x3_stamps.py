@@ -21,6 +21,12 @@ for it in range(3):
     eng.debug_stage(int(sys.argv[1]) if len(sys.argv) > 1 else 14, hyper, noise, m._flat, x, 0, m._flat_grad)
     torch.cuda.synchronize()
     v = dbg.cpu().numpy()
+    if len(sys.argv) > 1 and sys.argv[1] == "1":   # fc11 stamps: waves 0 and 4 of one block
+        for grp in (0, 1):
+            tz, te, td, n, tot, tw, tx = [int(q) for q in v[grp * 8: grp * 8 + 7]]
+            n = max(n, 1)
+            print(f"wave {4 * grp}: pieces {n}  per 32-gene piece: z {tz / n:.0f}  x wait {tx / n:.0f}  epilogue {te / n:.0f}  d(d10) {td / n:.0f}  tile sync {tw / n:.0f} | total {tot} cycles")
+        continue
     for grp in (0, 1):
         st, mf, bar, n, tot, ld = [int(t) for t in v[grp * 8: grp * 8 + 6]]
         n = max(n, 1)
