@@ -408,14 +408,15 @@ def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tenso
 
 # ---------------------------------------------------------------------------------------------------------------
 # operand type of the large GEMMs (mmvae_hyper.gemm_bf16 / mmvae_augment's gemm_bf16 argument)
-#   "fp32"       fp32 results; the library's fastest fp32-grade engine (see FP32_ENGINE below)
+#   "fp32"       fp32 results; the library's fastest fp32-grade engine ("fp32x3", see FP32_ENGINE below; shapes the split
+#                engine does not take -- fc_dim > 111, D % 4 != 0 -- run the fp32 matrix instruction by themselves)
 #   "fp32_mfma"  fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: an exact fmaf chain)
 #   "fp32x3"     fp32 operands split exactly into three bf16 slices, six slice products per product on the bf16 matrix
 #                pipe, fp32 accumulation: truncation <= 2^-26 per product, below the fp32 rounding of the accumulation
 #   "bf16"       operands rounded to bf16 (BASELINE.json's bf16 configuration)
 # MMVAE_FP32_ENGINE=fp32_mfma|fp32x3 picks what "fp32" means (A/B timing, and running the parity suite on either).
 # ---------------------------------------------------------------------------------------------------------------
-FP32_ENGINE = os.environ.get("MMVAE_FP32_ENGINE", "fp32_mfma")
+FP32_ENGINE = os.environ.get("MMVAE_FP32_ENGINE", "fp32x3")
 _GEMM_MODES = {"fp32_mfma": 0, "bf16": 1, "fp32x3": 2}
 
 

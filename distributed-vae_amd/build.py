@@ -24,6 +24,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", 
 # per-source extra flags.  gemm_bf16.hip: hipcc's SLP vectoriser packs the fp32 subtractions of the operand split into
 # v_pk_add_f32, which issues very slowly beside a partner wave's MFMAs (stage phase 3100 -> 1780 cycles without it)
 EXTRA = {"gemm_bf16.hip": ["-fno-slp-vectorize"]}
+# gemm_bf16.hip is compiled WITHOUT -amdgpu-mfma-vgpr-form: its accumulators are touched by MFMAs only (and once by the
+# epilogue), so they can live in the accumulator half of the register file and leave the 256 architectural VGPRs to
+# operand fragments in flight
+DROP = {"gemm_bf16.hip": ["-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -50,7 +54,11 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o]
+            flags = list(FLAGS)
+            for f in DROP.get(src, []):
+                i = flags.index(f)
+                del flags[i - 1:i + 1]          # the option and its "-mllvm"
+            cmd = [hipcc] + flags + EXTRA.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -82,10 +82,6 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // one v_c
 __device__ __forceinline__ void split3(float a, float b, unsigned (&w)[3]) {
     // eleven VALU instructions per pair: 3 conversions, 4 half -> float, 4 exact subtractions
     w[0] = cvt_pk_bf16(a, b);
-#ifdef X3_NOSPLIT
-    w[1] = w[2] = w[0];
-    return;
-#endif
     a -= __uint_as_float(w[0] << 16);
     b -= __uint_as_float(w[0] & 0xFFFF0000u);
     w[1] = cvt_pk_bf16(a, b);
@@ -171,9 +167,6 @@ __device__ __forceinline__ void quad_load(TileRegsT<BITS, Eng<NP>::NQ>& t, const
         off = kc * o.ld + (row < o.ld ? row : 0);
         woff = kc * o.wpr + (min(row, o.rows - 1) >> 5);
     }
-#ifdef X3_NOLOAD
-    if (NP == 3 && k0 > 64) return;
-#endif
     t.v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 4, 0, 0));
     if constexpr (BITS) t.wd[q] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
 }
@@ -228,9 +221,6 @@ __device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileR
         unsigned w0[3], w1[3];
         split3(x[0], x[1], w0);
         split3(x[2], x[3], w1);
-#ifdef X3_NOLDSW
-        if (k0 > 64) { if (w0[0] + w0[1] + w0[2] + w1[0] + w1[1] + w1[2] == 0x12345u) T[idx] = 1; return; }
-#endif
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(&T[pl * PLANE + idx]) = make_uint2(w0[pl], w1[pl]);
     }
@@ -927,27 +917,34 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
 // products per product:
 //   * [W11 | b11] and [d10 | 1] arrive as slice planes (k_presplit, once per step): the bias rides as k = fc_dim, so the
 //     accumulator already holds z + b and the epilogue loads no bias;
-//   * 512 threads = 8 waves x 32 cells; a wave keeps its cells' d10 slices in REGISTERS for the whole kernel (7 K steps x
-//     3 slices x 4 VGPRs) -- per wave private data, and as LDS images they would not leave room for anything else;
-//   * LDS holds only the W11 tile (64 genes x 128 k x 3 slices, row pitch 272 B), double-buffered and filled by
-//     LDS-DMA (global_load_lds_dwordx4: no registers, no VALU); it serves the z product as the A operand (ds_read_b128)
-//     and the d(d10) product as the B operand through transposing reads (ds_read_b64_tr_b16);
-//   * dZ11 is split into its slices in registers between the two products (eleven VALU instructions per pair).
-// grid (ceil(B / 256), gene splits NS, A); fc_dim + 1 <= 112.
-constexpr int FW_ROW = 68;                     // dwords per W11 image row: 128 bf16 + 16 B
+//   * ONE WAVE PER SIMD (256 threads = 4 waves x 32 cells, up to 512 VGPRs each).  Two waves per SIMD at 256 registers
+//     were measured first: a wave's VALU instructions hardly issue while its partner runs MFMAs (epilogue 1 860 cycles
+//     alone, 3 600 - 4 700 beside the partner), the two waves ran in the sum of their times, and 256 registers left the
+//     compiler no room to request LDS fragments ahead of the MFMAs that consume them.  With 512 registers the wave
+//     overlaps its own work instead: the z product of piece p + 1 (42 MFMAs, fragments requested one K step ahead) is
+//     issued through the epilogue of piece p (about six VALU instructions fit behind every MFMA);
+//   * a wave keeps its cells' d10 slices in registers for the whole kernel (7 K steps x 3 slices x 4 VGPRs);
+//   * LDS holds only W11 tiles (64 genes x 112 k x 3 slices, row pitch 240 B), three of them, filled by LDS-DMA
+//     (global_load_lds_dwordx4: no registers, no VALU) two tiles ahead; a tile serves the z product as the A operand
+//     (ds_read_b128) and the d(d10) product as the B operand through transposing reads (ds_read_b64_tr_b16);
+//   * dZ11 is split into its slices in registers between the two products (eleven VALU instructions per pair);
+//   * cells and genes that do not exist have z = 0 (zero rows of the planes) and read x = 0 (buffer range): no masks.
+// grid (ceil(B / 128), gene splits NS, A); fc_dim + 1 <= 112.
+constexpr int FW_ROW = 60;                     // dwords per W11 image row: 112 bf16 (seven K steps) + 16 B
 constexpr int FW_PLANE = 64 * FW_ROW;          // dwords per slice image of a 64-gene tile
 constexpr int FW_TILE = 3 * FW_PLANE;
-__global__ __launch_bounds__(512, 1) void k_x3_fc11g(const GemmArgs g_in) {
+__global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     const GemmArgs g = g_in;
-    __shared__ __attribute__((aligned(16))) unsigned Wl[2][FW_TILE];
-    __shared__ float red[16];
+    __shared__ __attribute__((aligned(16))) unsigned Wl[3 * FW_TILE + 64];   // three tiles (+ slack: the transposing reads of the
+                                                                              // last h tile run past a row's 112 columns)
+    __shared__ float red[8];
     const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const unsigned short* Wp = g.b.pl + (int64_t)arm * g.b.pl_arm;      // [3][Dr][128]
     const unsigned short* Dp = g.a.pl + (int64_t)arm * g.a.pl_arm;      // [3][Br][128]
     const int64_t wplane = g.b.pl_plane, dplane = g.a.pl_plane;
     const int B = g.fo.B, D = g.fo.D, H = g.K;
-    const int c0 = blockIdx.x * 256;
+    const int c0 = blockIdx.x * 128;
     const int tiles = cdiv(D, 64);
     const int t0 = (int)(((int64_t)blockIdx.y * tiles) / g.KS), t1 = (int)(((int64_t)(blockIdx.y + 1) * tiles) / g.KS);
     const int cell = c0 + 32 * wv + l31;
@@ -958,22 +955,28 @@ __global__ __launch_bounds__(512, 1) void k_x3_fc11g(const GemmArgs g_in) {
     const int rowoff = min(cell, B - 1) * D;          // B * D < 2^30 (fast-path condition)
     const bool cell_ok = cell < B;
 
-    // LDS-DMA of W11 tile t into buffer `buf`: 3 slices x 64 rows x 17 sixteen-byte pieces (the 17th is the row's pad and
-    // re-reads piece 0) = 51 wave instructions of 1 KB, seven per wave (the last wave repeats instruction 50).
-    auto dma = [&](int t, int buf) __attribute__((always_inline)) {
+    // LDS-DMA of W11 tile t into buffer (t - t0) % 3: 3 slices x 64 rows x 15 sixteen-byte pieces (the 15th is the row's pad
+    // and re-reads piece 0) = 45 wave instructions of 1 KB, twelve per wave (the last three slots repeat instruction 44).
+    auto dma = [&](int t) __attribute__((always_inline)) {
+        const int buf = (t - t0) % 3;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int ii = min(wv + 8 * j, 50);
-            const int pl = ii / 17, chunk = ii - 17 * pl;
-            const int pc = chunk * 64 + lane, row = pc / 17, c = pc - 17 * row;
-            // (32-bit element offsets: the planes of an arm are a few MB; 64-bit per-lane addresses for seven pieces spilled)
-            const unsigned off = (unsigned)pl * (unsigned)wplane + (unsigned)(t * 64 + row) * 128u + (c < 16 ? 8u * c : 0u);
+        for (int j = 0; j < 12; ++j) {
+            const int ii = min(wv + 4 * j, 44);
+            const int pl = ii / 15, chunk = ii - 15 * pl;
+            const int pc = chunk * 64 + lane, row = pc / 15, c = pc - 15 * row;
+            // (32-bit element offsets: the planes of an arm are a few MB)
+            const unsigned off = (unsigned)pl * (unsigned)wplane + (unsigned)(t * 64 + row) * 128u + (c < 14 ? 8u * c : 0u);
             const unsigned short* src = Wp + off;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(&Wl[buf][pl * FW_PLANE + chunk * 256]), 16, 0, 0);
+            // (inline assembly, not __builtin_amdgcn_global_load_lds: hipcc's wait-count pass treats the builtin as a store to
+            // "some" LDS and puts s_waitcnt vmcnt(0) in front of the next LDS read -- which, with the x prefetch just issued,
+            // stalled every tile for a full memory round trip.  The waits for the DMA are the counted ones in the loop.)
+            const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&Wl[buf * FW_TILE + pl * FW_PLANE + chunk * 256]);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src) : "memory");
         }
     };
-    if (t0 < t1) dma(t0, 0);
+    if (t0 < t1) dma(t0);
+    if (t0 + 1 < t1) dma(t0 + 1);
     // this wave's d10 slices: lane = cell, K step s holds k = 16 s + 8 hh .. + 7
     bf16x8 dfr[7][3];
     {
@@ -991,147 +994,219 @@ __global__ __launch_bounds__(512, 1) void k_x3_fc11g(const GemmArgs g_in) {
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     // transposing-read address of this lane inside a (4 genes x 16 h) block: row (lane & 15) >> 2, columns 4 (lane & 3) ..
     const int tr_off = ((lane & 15) >> 2) * (2 * FW_ROW) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    float4 xin[4];
-    auto request_x = [&](int j0g) __attribute__((always_inline)) {      // x of the 32-gene piece that starts at gene j0g
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int gene = j0g + 8 * q + 4 * hh;                      // D % 4 == 0: a float4 exists entirely or not at all
-            xin[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (cell_ok && gene < D) ? (rowoff + gene) * 4 : -16, 0, 0));
-        }
+    const int npieces = 2 * (t1 - t0);
+    // piece p: genes [64 t0 + 32 p, + 32), rows 32 (p & 1) of tile t0 + p / 2 in LDS buffer (p / 2) % 3
+    auto w_rows = [&](int p) __attribute__((always_inline)) { return Wl + ((p >> 1) % 3) * FW_TILE + 32 * (p & 1) * FW_ROW; };
+    auto a_frag = [&](const unsigned* Wr, int s, int pl) __attribute__((always_inline)) {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Wr + pl * FW_PLANE + l31 * FW_ROW + 8 * s + 4 * hh));
     };
-    if (t0 < t1) request_x(t0 * 64);
+    auto request_x = [&](float4 (&X)[4], int j0g, int q) __attribute__((always_inline)) {   // x of gene group q of the piece at j0g
+        const int gene = j0g + 8 * q + 4 * hh;                      // D % 4 == 0: a float4 exists entirely or not at all
+        int off = (cell_ok && gene < D) ? (rowoff + gene) * 4 : -16;
+        asm("" : "+v"(off));       // (a plain select: hipcc otherwise branches around two copies of the load, and a branch
+                                   // ends the region in which MFMAs and VALU instructions can be interleaved)
+        X[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    };
+    // six slice products of one K step
+    // (one accumulation chain: dependent MFMAs of this shape issue back to back, tools/micro/x3_issue_bench.hip)
+    auto mfma6 = [&](f32x16& acc, const bf16x8 (&a)[3], int s) __attribute__((always_inline)) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], dfr[s][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], dfr[s][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], dfr[s][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][0], acc, 0, 0, 0);
+    };
+    // ------------------------------------------------------------------------------------------------------------
+    // One piece = stage 1 (the z product of the NEXT piece, 42 MFMAs in seven regions of one K step, with this piece's
+    // epilogue cut into eight chunks of VALU work behind them) + stage 2 (this piece's d(d10) product, 48 MFMAs in four
+    // regions).  Every LDS fragment is requested TWO regions before the MFMAs that consume it (a ds_read costs 64+ cycles
+    // when it is waited for at once -- tools/micro/x3_issue_bench.hip -- and hipcc sinks reads towards their uses, so the
+    // regions are fenced with sched_barrier and the requests placed by hand); the rings of fragments carry over from
+    // piece to piece.  Accumulators live in the accumulator half of the register file (this file is compiled without
+    // -amdgpu-mfma-vgpr-form), which leaves the architectural VGPRs to the fragments in flight.
+    // ------------------------------------------------------------------------------------------------------------
+    bf16x8 an[3][3];          // A fragments (W11 slices) of the z product: ring over K steps
+    bf16x8 wq[2][2][3];       // transposed W11 fragments of the d(d10) product: ring over regions; [h tile of the pair][slice]
+    auto z_frags = [&](const unsigned* Wr, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) an[s % 3][pl] = a_frag(Wr, s, pl);
+    };
+    auto d_frags = [&](const unsigned short* Wt16, int r) __attribute__((always_inline)) {   // region r: K step r >> 1, h tiles 2 (r & 1) ..
+        const int grow = 16 * (r >> 1) + 4 * hh;            // first of this lane's two gene groups (second: + 8)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const unsigned short* ap = Wt16 + pl * (2 * FW_PLANE) + grow * (2 * FW_ROW) + 32 * (2 * (r & 1) + j) + tr_off;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)ap);
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(ap + 8 * (2 * FW_ROW)));
+                s16x8 rr;
+                rr[0] = v0[0]; rr[1] = v0[1]; rr[2] = v0[2]; rr[3] = v0[3];
+                rr[4] = v1[0]; rr[5] = v1[1]; rr[6] = v1[2]; rr[7] = v1[3];
+                wq[r & 1][j][pl] = __builtin_bit_cast(bf16x8, rr);
+            }
+    };
+    float4 xa_[4], xb_[4];
+    f32x16 acc_a = zero16(), acc_b = zero16();
+    if (npieces > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) request_x(xa_, t0 * 64, q);
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): both first tiles and x
+        // (hipcc's wait-count pass does not see that wait: without a use of the registers HERE it keeps "d10 / x may still
+        // be in flight" alive around the loop's back edge and waits for vmcnt(0) -- i.e. for the x prefetch issued a moment
+        // earlier -- in front of the first MFMA of every tile)
+#pragma unroll
+        for (int s7 = 0; s7 < 7; ++s7)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(dfr[s7][pl]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(xa_[q].x), "+v"(xa_[q].y), "+v"(xa_[q].z), "+v"(xa_[q].w));
+        __syncthreads();
+        if (t0 + 2 < t1) dma(t0 + 2);
+        // z of piece 0
+        const unsigned* Wr = w_rows(0);
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[pl] = a_frag(Wr, s, pl);
+            mfma6(acc_a, a, s);
+        }
+        const unsigned* W1 = w_rows(npieces > 1 ? 1 : 0);
+        z_frags(W1, 0);
+        z_frags(W1, 1);
+    }
 #ifdef X3_STAMPS
-    long long tz = 0, te = 0, td = 0, tw = 0, tx = 0, tp = __builtin_amdgcn_s_memtime(), tbeg = tp;
+    long long t_s1 = 0, t_dma = 0, t_s2 = 0, tw = 0, tp = __builtin_amdgcn_s_memtime(), tbeg = tp;
 #define X3_ST(var) { const long long t1_ = __builtin_amdgcn_s_memtime(); var += t1_ - tp; tp = t1_; }
 #else
 #define X3_ST(var)
 #endif
-    for (int t = t0; t < t1; ++t) {
-        const int buf = (t - t0) & 1;
-        // the tile's DMA was issued one tile ago, in front of sixteen younger vector-memory instructions (2 x (4 stores +
-        // 4 loads)); vector-memory instructions retire in order, so "at most eight outstanding" leaves only the last
-        // piece's stores and the x prefetch in flight and guarantees the DMA has landed
-        if (t == t0) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(0x0F78);                // vmcnt(8)
-        __syncthreads();
-        X3_ST(tw)
-        if (t + 1 < t1) dma(t + 1, buf ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned* Wt = Wl[buf];
-        const unsigned short* Wt16 = reinterpret_cast<const unsigned short*>(Wt);
+    // piece p: epilogue reads `acc` / `xin`, the z product of piece p + 1 goes to `accn`, its x to `xnx`
+    auto piece = [&](int p, f32x16& acc, f32x16& accn, float4 (&xin)[4], float4 (&xnx)[4], int dma_tile) __attribute__((always_inline)) {
+        const int j0g = t0 * 64 + 32 * p;
+        const unsigned* Wn = w_rows(p + 1 < npieces ? p + 1 : p);
+        const unsigned short* Wt16 = reinterpret_cast<const unsigned short*>(w_rows(p));
+        accn = zero16();
+        unsigned au[2][3][4];          // dZ11 slices: K step c (sixteen genes in register order), slice, four dwords
+        float dzq[4];
+        // x of the next piece first: requested in front of this piece's stores, the wait for it (vector-memory instructions
+        // retire in order) then does not include them
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int j0g = t * 64 + 32 * gi;
-            // ---- z^T piece: 32 genes x this wave's 32 cells (bias included: k = H)
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int s = 0; s < 7; ++s) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    a[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Wt + pl * FW_PLANE + (32 * gi + l31) * FW_ROW + 8 * s + 4 * hh));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], dfr[s][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], dfr[s][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], dfr[s][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], dfr[s][0], acc, 0, 0, 0);
-            }
-#ifdef X3_STAMPS
-            asm volatile("" :: "v"(acc));
-            X3_ST(tz)
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            X3_ST(tx)
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- epilogue: acc[4 q + e] is gene j0g + 8 q + 4 hh + e of cell `cell`.  Cells and genes that do not exist
-            // have z = 0 (zero rows of the slice planes) and read x = 0 (buffer range), so they need no masks: error, dZ11
-            // and mismatch come out as zero by themselves.  Eight VALU instructions per element; the mismatch count is
-            // kept on the scalar unit (lane-mask population counts), outside the VALU's dependency chains.
-            unsigned au[2][3][4];          // dZ11 slices: K step c (sixteen genes in register order), slice, four dwords
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 4; ++q) request_x(xnx, j0g + 32, q);
+        // chunk 2 q: loss terms, dZ11 and its store for gene group q (acc[4 q + e] is gene j0g + 8 q + 4 hh + e of cell
+        // `cell`); chunk 2 q + 1: its slices.  Eight VALU instructions per element; the mismatch count is kept on the scalar
+        // unit (lane-mask population counts), outside the VALU's dependency chains.
+        auto chunk = [&](int ch) __attribute__((always_inline)) {
+            const int q = ch >> 1;
+            if ((ch & 1) == 0) {
                 const int gene = j0g + 8 * q + 4 * hh;
                 const float xv[4] = {xin[q].x, xin[q].y, xin[q].z, xin[q].w};
-                float dz[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a_ = acc[4 * q + e];
-                    // max(z, 0) as ONE instruction: a signed-integer maximum of the bit pattern (fmaxf also canonicalises its
-                    // input -- a second v_max_f32 per element)
+                    // max(z, 0) as ONE instruction: a signed-integer maximum of the bit pattern (fmaxf also canonicalises
+                    // its input -- a second v_max_f32 per element)
                     const float xr = __int_as_float(max(__float_as_int(a_), 0));
                     const float er = xr - xv[e];
                     seq[q] = __builtin_fmaf(er, er, seq[q]);
                     const float d_ = g.fo.coef * er;
-                    dz[e] = a_ > 0.f ? d_ : 0.f;
+                    dzq[e] = a_ > 0.f ? d_ : 0.f;
                     mism += __builtin_popcountll(__builtin_amdgcn_ballot_w64(xr > 0.1f) ^ __builtin_amdgcn_ballot_w64(xv[e] > 0.1f));
                 }
-                // (always issued -- the counted wait above relies on it; what must not be written gets an offset beyond the
-                // buffer's range, which the hardware drops)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, make_float4(dz[0], dz[1], dz[2], dz[3])), rz,
-                                                       (cell_ok && gene < D) ? (cell * D + gene) * 4 : -16, 0, 0);
+                // (always issued -- the counted wait at the end of a tile relies on it; what must not be written gets an offset
+                // beyond the buffer's range, which the hardware drops)
+                int soff = (cell_ok && gene < D) ? (cell * D + gene) * 4 : -16;
+                asm("" : "+v"(soff));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, make_float4(dzq[0], dzq[1], dzq[2], dzq[3])), rz, soff, 0, 0);
+            } else {
                 unsigned w0[3], w1[3];
-                split3(dz[0], dz[1], w0);
-                split3(dz[2], dz[3], w1);
+                split3(dzq[0], dzq[1], w0);
+                split3(dzq[2], dzq[3], w1);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) { au[q >> 1][pl][2 * (q & 1)] = w0[pl]; au[q >> 1][pl][2 * (q & 1) + 1] = w1[pl]; }
             }
-            asm volatile("" : "+s"(mism));
-            // x of the next piece (its registers are free now; the loads land under the MFMAs below and the next z product)
-            {
-                const int nxt = gi == 0 ? j0g + 32 : (t + 1) * 64;
-                request_x(nxt);
-            }
-            __builtin_amdgcn_s_setprio(0);
-#ifdef X3_STAMPS
-            asm volatile("" :: "v"(au[0][0][0]), "v"(au[1][2][3]));
-            X3_ST(te)
-#endif
+        };
+        // ---- stage 1
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
             __builtin_amdgcn_sched_barrier(0);
-            // ---- d(d10) += dZ11 piece (registers) x W11 rows 32 gi .. + 31 (LDS, transposed): two K steps of sixteen genes
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                bf16x8 af[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    u32x4v u;
-                    u[0] = au[c][pl][0]; u[1] = au[c][pl][1]; u[2] = au[c][pl][2]; u[3] = au[c][pl][3];
-                    af[pl] = __builtin_bit_cast(bf16x8, u);
-                }
-                const int grow = 32 * gi + 16 * c + 4 * hh;            // first of this lane's two gene groups (second: + 8)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    bf16x8 w[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned short* a = Wt16 + pl * (2 * FW_PLANE) + grow * (2 * FW_ROW) + 32 * nt + tr_off;
-                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
-                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 8 * (2 * FW_ROW)));
-                        s16x8 r;
-                        r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
-                        r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
-                        w[pl] = __builtin_bit_cast(bf16x8, r);
-                    }
-                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], w[0], gd[nt], 0, 0, 0);
-                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], w[2], gd[nt], 0, 0, 0);
-                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], w[1], gd[nt], 0, 0, 0);
-                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], w[0], gd[nt], 0, 0, 0);
-                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], w[1], gd[nt], 0, 0, 0);
-                    gd[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], w[0], gd[nt], 0, 0, 0);
-                }
-            }
-#ifdef X3_STAMPS
-            asm volatile("" :: "v"(gd[0]), "v"(gd[3]));
-            X3_ST(td)
-#endif
-            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < 7) z_frags(Wn, s + 2);
+            if (s == 5) d_frags(Wt16, 0);           // (the first region of stage 2: its slot of the ring is free)
+            mfma6(accn, an[s % 3], s);
+            chunk(s);
+            if (s == 6) chunk(7);
         }
+        asm volatile("" : "+s"(mism));
+        // the DMA of a later tile goes here, behind the last use of this piece's x: hipcc does not count the assembly's
+        // instructions, so a wait it places for a register loaded BEFORE them also waits for them
+#ifdef X3_STAMPS
+        asm volatile("" :: "v"(accn), "v"(au[0][0][0]), "v"(au[1][2][3]));
+        X3_ST(t_s1)
+#endif
+        if (dma_tile >= 0) dma(dma_tile);
+#ifdef X3_STAMPS
+        X3_ST(t_dma)
+#endif
+        // ---- stage 2: d(d10) += dZ11 piece (registers) x W11 rows of piece p (LDS, transposed)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (r + 1 < 4) d_frags(Wt16, r + 1);    // the other slot of the ring (region r - 1 is done with it)
+            if (r >= 2) {
+                // the first two K steps of the next piece's z product (piece p + 2: its tile has landed -- it is the tile of
+                // piece p + 1 or the one the barrier at the end of the previous tile waited for)
+                const unsigned* W2 = w_rows(p + 2 < npieces ? p + 2 : p);
+                z_frags(W2, r - 2);
+            }
+            const int c = r >> 1;
+            bf16x8 af[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                u32x4v u;
+                u[0] = au[c][pl][0]; u[1] = au[c][pl][1]; u[2] = au[c][pl][2]; u[3] = au[c][pl][3];
+                af[pl] = __builtin_bit_cast(bf16x8, u);
+            }
+            // product-major: consecutive MFMAs go to the two h tiles of the region (independent accumulators)
+            const int n0 = 2 * (r & 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gd[n0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], wq[r & 1][j][0], gd[n0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gd[n0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wq[r & 1][j][2], gd[n0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gd[n0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], wq[r & 1][j][1], gd[n0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gd[n0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], wq[r & 1][j][0], gd[n0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gd[n0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wq[r & 1][j][1], gd[n0 + j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) gd[n0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], wq[r & 1][j][0], gd[n0 + j], 0, 0, 0);
+        }
+#ifdef X3_STAMPS
+        asm volatile("" :: "v"(gd[0]), "v"(gd[3]));
+        X3_ST(t_s2)
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t = t0; t < t1; ++t) {
+        const int p = 2 * (t - t0);
+        // the first piece of tile t also requests tile t + 2 (into the buffer of tile t - 1, which every wave left at the
+        // barrier below; tiles t0 .. t0 + 2 were requested by the prologue)
+        piece(p, acc_a, acc_b, xa_, xb_, (t > t0 && t + 2 < t1) ? t + 2 : -1);
+        piece(p + 1, acc_b, acc_a, xb_, xa_, -1);
+        // ---- end of a tile (two pieces): tile t + 2 is needed next (the z product runs one piece ahead).  It was requested
+        // in front of eight younger vector-memory instructions (the second piece's 4 loads + 4 stores); vector-memory
+        // instructions retire in order, so "at most four outstanding" (those stores) guarantees this wave's share of it has
+        // landed, and the barrier that of the others.  The barrier also lets tile t's buffer be overwritten.
+        __builtin_amdgcn_s_waitcnt(0x0F74);                // vmcnt(4)
+        __syncthreads();
+        X3_ST(tw)
     }
 #ifdef X3_STAMPS
-    if (g.dbg && lane == 0 && (wv == 0 || wv == 4) && blockIdx.x == 3 && blockIdx.y == 2 && blockIdx.z == 0) {
-        long long* o = g.dbg + (wv >> 2) * 8;
-        o[0] = tz; o[1] = te; o[2] = td; o[3] = 2 * (t1 - t0); o[4] = __builtin_amdgcn_s_memtime() - tbeg; o[5] = tw; o[6] = tx;
+    if (g.dbg && lane == 0 && (wv == 0 || wv == 3) && blockIdx.x == 3 && blockIdx.y == 2 && blockIdx.z == 0) {
+        long long* o = g.dbg + (wv ? 1 : 0) * 8;
+        o[0] = t_s1; o[1] = t_dma; o[2] = t_s2; o[3] = npieces; o[4] = __builtin_amdgcn_s_memtime() - tbeg; o[5] = tw; o[6] = 0;
     }
 #endif
     // ---- d(d10) partial of this gene range: slab [NS][A][B][H]; gd[nt][r]: cell row acc_row(r), h = 32 nt + (lane & 31)
@@ -1151,12 +1226,9 @@ __global__ __launch_bounds__(512, 1) void k_x3_fc11g(const GemmArgs g_in) {
     if (lane == 0) { red[wv * 2] = se; red[wv * 2 + 1] = (float)mism; }
     __syncthreads();
     if (tid == 0) {
-        float* p = g.fo.part + ((int64_t)arm * g.n11 + (int64_t)blockIdx.x * g.KS + blockIdx.y) * 2;
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { a0 += red[2 * w]; a1 += red[2 * w + 1]; }
-        p[0] = a0;
-        p[1] = a1;
+        float* pp = g.fo.part + ((int64_t)arm * g.n11 + (int64_t)blockIdx.x * g.KS + blockIdx.y) * 2;
+        pp[0] = (red[0] + red[2]) + (red[4] + red[6]);
+        pp[1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
 }
 
@@ -1214,7 +1286,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
     // the call for d(d10) (which & 2) has nothing left to do; with x_rec wanted (or MMVAE_TUNE_FC11_ZG_OFF) two kernels
     const bool fused = need_grad && !x_rec && !c.tune(MMVAE_TUNE_FC11_ZG_OFF);
     if (split3_gemms(c)) {
-        // fp32x3: only the fused train-step kernel exists in this engine (fc_dim + 1 <= 112, 256 cells per block fit the
+        // fp32x3: only the fused train-step kernel exists in this engine (fc_dim + 1 <= 112, 128 cells per block fit the
         // loss-partial slots); everything else runs the fp32 matrix-instruction kernels (the caller falls through)
         if (!(which & 1)) return 0;
         hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
@@ -1235,7 +1307,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.fo_x_arm = xs;
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
         g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
-        hipLaunchKernelGGL(k_x3_fc11g, dim3(cdiv(d.B, 256), NS, d.A), dim3(512), 0, c.stream, g);
+        hipLaunchKernelGGL(k_x3_fc11g, dim3(cdiv(d.B, 128), NS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_x3_fc11g");
         return 0;
     }

@@ -1440,7 +1440,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
     // fp32x3: the fused train-step form (forward for gradients, no x_rec, fc_dim + 1 <= 112) has its own kernel; the other
     // forms of fc11 (x_rec wanted, forward only) run the fp32 matrix-instruction kernels below
     if (split3_gemms(c) && need_grad && !x_rec && c.d.H + 1 <= 112 && !c.tune(MMVAE_TUNE_FC11_ZG_OFF) &&
-        (int64_t)cdiv(c.d.B, 256) * c.lay.sp.ks_gd10 <= c.lay.n11)
+        (int64_t)cdiv(c.d.B, 128) * c.lay.sp.ks_gd10 <= c.lay.n11)
         return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
     if (bf16_gemms(c) && !split3_gemms(c)) return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
     const mmvae_dims& d = c.d;

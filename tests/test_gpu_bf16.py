@@ -132,7 +132,7 @@ def test_bf16_configuration_at_full_size_against_the_oracle():
     print("bf16 vs fp32 oracle, worst gradient cosine over the parameter tensors: %.5f" % worst)
     assert worst > 0.9
     # and the fp32 configuration of the same model object is untouched by the switch
-    m.gemm_dtype = "fp32"
+    m.gemm_dtype = "fp32_mfma"
     assert m._hyper(1.0, False).gemm_bf16 == 0
 
 

@@ -7,7 +7,7 @@ N=$1; S=$2; F=$3
 C=distributed-vae_amd/csrc
 python distributed-vae_amd/build.py > /tmp/mmvae_build.log 2>&1 || { tail -30 /tmp/mmvae_build.log; exit 1; }
 mkdir -p ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize $F -c $C/$S -o ab/$N.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc -fno-slp-vectorize $F -c $C/$S -o ab/$N.o
 OBJS=$(ls $C/_obj/*.o | grep -v "/${S%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/lib$N.so $OBJS ab/$N.o
 echo ab/lib$N.so

@@ -25,7 +25,7 @@ for it in range(3):
         for grp in (0, 1):
             tz, te, td, n, tot, tw, tx = [int(q) for q in v[grp * 8: grp * 8 + 7]]
             n = max(n, 1)
-            print(f"wave {4 * grp}: pieces {n}  per 32-gene piece: z {tz / n:.0f}  x wait {tx / n:.0f}  epilogue {te / n:.0f}  d(d10) {td / n:.0f}  tile sync {tw / n:.0f} | total {tot} cycles")
+            print(f"wave {3 * grp}: pieces {n}  per 32-gene piece: stage 1 (z of next + epilogue) {tz / n:.0f}  DMA issue {te / n:.0f}  stage 2 (d(d10)) {td / n:.0f}  tile sync {tw / n:.0f} | total {tot} cycles")
         continue
     for grp in (0, 1):
         st, mf, bar, n, tot, ld = [int(t) for t in v[grp * 8: grp * 8 + 6]]
