@@ -425,4 +425,7 @@ def gemm_mode(dtype: str) -> int:
         dtype = FP32_ENGINE
     if dtype not in _GEMM_MODES:
         raise ValueError(f"gemm_dtype must be 'fp32', 'fp32_mfma', 'fp32x3' or 'bf16', got {dtype!r}")
-    return _GEMM_MODES[dtype]
+    mode = _GEMM_MODES[dtype]
+    if mode == 2:   # diagnostics: MMVAE_X3_OFF=<mask> keeps single products on the fp32 matrix instruction (1 fc1, 2 fc11, 4 dW1, 8 dW11)
+        mode |= (int(os.environ.get("MMVAE_X3_OFF", "0")) & 0xF) << 8
+    return mode

@@ -582,8 +582,10 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit
 // bf16-operand variants of the five D x H GEMMs (gemm_bf16.hip; mmvae_hyper.gemm_bf16), same outputs / layouts
 // gemm_bf16 == 2: fp32 operands split exactly into three bf16 slices each (six slice products per product: fp32-grade
 // results on the bf16 matrix pipe); the same tile engine with three LDS planes per operand
-inline bool bf16_gemms(const Ctx& c) { return c.h.gemm_bf16 != 0 && c.d.H <= 124; }
-inline bool split3_gemms(const Ctx& c) { return c.h.gemm_bf16 == 2 && c.d.H <= 124; }
+// bits 8.. of gemm_bf16 (diagnostics): products that stay on the fp32 matrix instruction although gemm_bf16 & 0xFF == 2
+// (1 fc1, 2 fc11 + d(d10), 4 dW1, 8 dW11)
+inline bool split3_gemms(const Ctx& c, int op = 0) { return (c.h.gemm_bf16 & 0xFF) == 2 && c.d.H <= 124 && !((c.h.gemm_bf16 >> 8) & op); }
+inline bool bf16_gemms(const Ctx& c, int op = 0) { return ((c.h.gemm_bf16 & 0xFF) == 1 || split3_gemms(c, op)) && c.d.H <= 124; }
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);
 int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);

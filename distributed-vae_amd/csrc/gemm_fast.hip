@@ -1406,7 +1406,7 @@ int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
 }
 
 int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64_t xs) {
-    if (bf16_gemms(c)) return launch_fc1_fwd_bf16(c, params, x, xs);
+    if (bf16_gemms(c, 1)) return launch_fc1_fwd_bf16(c, params, x, xs);
     const mmvae_dims& d = c.d;
     const bool use_mask = c.h.training && c.h.x_drop > 0.f;
     const int KS = c.lay.sp.ks_fc1;
@@ -1439,10 +1439,10 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
                      int which /*bit0: x_rec/loss/dZ11 kernel, bit1: d(d10) GEMM*/) {
     // fp32x3: the fused train-step form (forward for gradients, no x_rec, fc_dim + 1 <= 112) has its own kernel; the other
     // forms of fc11 (x_rec wanted, forward only) run the fp32 matrix-instruction kernels below
-    if (split3_gemms(c) && need_grad && !x_rec && c.d.H + 1 <= 112 && !c.tune(MMVAE_TUNE_FC11_ZG_OFF) &&
+    if (split3_gemms(c, 2) && need_grad && !x_rec && c.d.H + 1 <= 112 && !c.tune(MMVAE_TUNE_FC11_ZG_OFF) &&
         (int64_t)cdiv(c.d.B, 128) * c.lay.sp.ks_gd10 <= c.lay.n11)
         return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
-    if (bf16_gemms(c) && !split3_gemms(c)) return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
+    if ((c.h.gemm_bf16 & 0xFF) == 1 && bf16_gemms(c)) return launch_fc11_bf16(c, params, x, xs, x_rec, need_grad, which);
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     const int ldk = rup(d.H, 8) + 4;
@@ -1529,6 +1529,14 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
 }
 
 int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
+    if ((c.h.gemm_bf16 & 0xFF) == 2 && ((c.h.gemm_bf16 >> 8) & 12)) {     // diagnostics: one of the two on the fp32 matrix instruction
+        int rc = 0;
+        Ctx c0 = c;
+        c0.h.gemm_bf16 = 0;
+        if (which & 1) rc = split3_gemms(c, 4) ? launch_dw_big_bf16(c, x, xs, 1) : launch_dw_big_fast(c0, x, xs, 1);
+        if (!rc && (which & 2)) rc = split3_gemms(c, 8) ? launch_dw_big_bf16(c, x, xs, 2) : launch_dw_big_fast(c0, x, xs, 2);
+        return rc;
+    }
     if (bf16_gemms(c)) return launch_dw_big_bf16(c, x, xs, which);
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
