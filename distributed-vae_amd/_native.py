@@ -81,6 +81,7 @@ TUNE_ENV = {
     "MMVAE_FC11_NSZ": (10, int), "MMVAE_GD10_V2": (11, int), "MMVAE_DW1_V2": (12, int), "MMVAE_DW11_V2": (13, int),
     "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_ABLATE_B": (16, int),
 }
+TUNE_ENGINE = 17    # MMVAE_TUNE_ENGINE: the GEMM engine the caller runs (the layout's split factors are chosen for it)
 
 
 class Exec(C.Structure):
@@ -90,9 +91,11 @@ class Exec(C.Structure):
                 ("early_recorded", C.c_int32), ("split", C.c_int32 * 6), ("tune", C.c_int32 * N_TUNE)]
 
 
-def exec_from_env() -> Exec:
-    """An Exec with the split factors (MMVAE_SPLIT<i>) and experiment switches the environment asks for."""
+def exec_from_env(engine: int = 0) -> Exec:
+    """An Exec with the split factors (MMVAE_SPLIT<i>) and experiment switches the environment asks for; ``engine`` is the
+    GEMM engine the caller is going to run (gemm_mode(...) & 0xFF)."""
     ex = Exec()
+    ex.tune[TUNE_ENGINE] = engine & 0xFF
     for w in range(6):
         v = os.environ.get(f"MMVAE_SPLIT{w}")
         if v:
@@ -229,15 +232,16 @@ class Engine:
     (dims, device) and issues the C-ABI calls on torch's current stream OF THAT DEVICE.  Nothing is shared between
     engines except the process-wide side stream of a device (see ``shared_stream``): each engine has its own events."""
 
-    def __init__(self, A, B, D, H, L, Cc, S, device, ex: Optional[Exec] = None):
+    def __init__(self, A, B, D, H, L, Cc, S, device, ex: Optional[Exec] = None, gemm_engine: int = 0):
         self.dims = Dims(A, B, D, H, L, Cc, S)
+        self.gemm_engine = gemm_engine & 0xFF      # which engine the layout's split factors are chosen for
         check(lib().mmvae_check_dims(C.byref(self.dims)), "mmvae_check_dims")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise NativeError("the HIP engine needs a GPU device (no CPU fallback)")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.ex = ex if ex is not None else exec_from_env()
+        self.ex = ex if ex is not None else exec_from_env(self.gemm_engine)
         self.side = None
         self.early_event = None
         self._events = []

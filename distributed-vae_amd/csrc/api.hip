@@ -75,6 +75,17 @@ Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex) {
         s.ks_gd10 = best;
     }
     s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, fastdims && d.H == 100 ? 64 : 32)));   // fc_dim 100: also k_fc11_zg's gene split
+    // fp32x3 engine (gemm_bf16.hip): its kernels run ONE 512- or 256-thread workgroup per CU -- a pair of 128-row tiles
+    // (fc1, dW1, dW11) or 128 cells (the fused fc11 kernel) -- so the splits fill 256 slots, not 512.  dW11 runs beside the
+    // latency-bound backward chain, which needs CUs of its own: half the chip (measured at A = 2: 873 us per step with the
+    // splits above, 836 with these).
+    if (ex && ex->tune[MMVAE_TUNE_ENGINE] == 2 && fastdims && d.H + 1 <= 112) {
+        const int pairs_b = cdiv(nb128, 2), pairs_d = cdiv(cdiv(d.D, 128), 2);
+        if (g_split[0] <= 0) s.ks_fc1 = min(fit(pairs_b * d.A, CUS, 16), max(1, cdiv(d.D, 32)));
+        if (g_split[4] <= 0) s.ks_gd10 = min(fit(nb128 * d.A, CUS, 16), max(1, cdiv(d.D, 64)));
+        if (g_split[2] <= 0) s.ks_dw = min(fit(pairs_d * d.A, CUS, 16), max(1, cdiv(d.B, 32)));
+        if (g_split[5] <= 0) s.ks_dw11 = min(fit(pairs_d * d.A, CUS / 2, 16), max(1, cdiv(d.B, 32)));
+    }
     return s;
 }
 
@@ -249,6 +260,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     const bool fast = fast_path_ok(c, params, x, xs);
     if (fast) {
         if ((rc = launch_make_xbits(c, nz))) return rc;
+        if ((rc = launch_x3_planes(c, params, 1))) return rc;          // fp32x3: slice planes of W1 and [W11 | b11]
         if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
         if ((rc = launch_fc1_epi(c, params))) return rc;
     } else if ((rc = launch_fc1_fwd(c, nz, params, x, xs))) {
@@ -273,6 +285,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         *couple_done = true;
     }
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
+    if (fast && need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;   // fp32x3: slice planes of [d10 | 1] (fc11, dW11)
     if (fast && fc11_split_path(c, params, x, xs) && couple_done && *couple_done && loss_out) {
         if ((rc = launch_fc11_fast(c, params, x, xs, x_rec, need_grad, 1))) return rc;
         if ((rc = fork_to_side(c, EV_FC11))) return rc;
@@ -348,6 +361,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         if ((rc = record_on_side(c, EV_JOIN))) return rc;
     }
     if (fast) {
+        if ((rc = launch_x3_planes(c, params, 4))) return rc;            // fp32x3: slice planes of dZ1 (dW1)
         if ((rc = launch_dw_big_fast(c, x, xs, forked ? 1 : 3))) return rc;
     } else if ((rc = launch_dw_big(c, nz, x, xs))) {
         return rc;

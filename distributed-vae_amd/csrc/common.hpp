@@ -586,6 +586,7 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit
 // (1 fc1, 2 fc11 + d(d10), 4 dW1, 8 dW11)
 inline bool split3_gemms(const Ctx& c, int op = 0) { return (c.h.gemm_bf16 & 0xFF) == 2 && c.d.H <= 124 && !((c.h.gemm_bf16 >> 8) & op); }
 inline bool bf16_gemms(const Ctx& c, int op = 0) { return ((c.h.gemm_bf16 & 0xFF) == 1 || split3_gemms(c, op)) && c.d.H <= 124; }
+int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11], bit1 [d10|1], bit2 dZ1*/);
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);
 int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);

@@ -303,15 +303,24 @@ __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
     const float* src = J.src + (int64_t)blockIdx.z * J.src_arm;
     const float* col = J.col_src ? J.col_src + (int64_t)blockIdx.z * J.col_arm : nullptr;
     unsigned short* dst = J.dst + (int64_t)blockIdx.z * J.dst_arm;
-    const int c8n = J.Cp >> 3;
-    const int64_t n = (int64_t)J.Rp * c8n, plane = (int64_t)J.Rp * J.Cp;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / c8n), c0 = (int)(i % c8n) * 8;
+    const int c8n = J.Cp >> 3;                      // eight-column pieces per row
+    const int64_t plane = (int64_t)J.Rp * J.Cp;
+    const bool vec = (J.ld & 3) == 0 && (J.C & 3) == 0;
+    // a thread keeps its piece column and walks the rows (row pitch of the walk: 256 / c8n rows when c8n <= 256)
+    const int n = J.Rp * c8n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int r = i / c8n, c0 = (i - r * c8n) * 8;
         float v[8];
+        if (r < J.R && vec && c0 + 8 <= J.C) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)r * J.ld + c0);
+            const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)r * J.ld + c0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c0 + e;
-            v[e] = (r < J.R && c < J.C) ? src[(int64_t)r * J.ld + c] : ((r < J.R && c == J.ones_col) ? (col ? col[r] : 1.f) : 0.f);
+            for (int e = 0; e < 8; ++e) {
+                const int c = c0 + e;
+                v[e] = (r < J.R && c < J.C) ? src[(int64_t)r * J.ld + c] : ((r < J.R && c == J.ones_col) ? (col ? col[r] : 1.f) : 0.f);
+            }
         }
         unsigned w[4][3];
 #pragma unroll
@@ -366,29 +375,41 @@ struct GemmArgs {
 // small ones first)
 template <bool AMINOR, bool BMINOR, int NP = 1>
 __device__ __forceinline__ void mfma_ktile(f32x16 (&acc)[2][2], const unsigned* As, const unsigned* Bs, int wm, int wn, int lane) {
-    constexpr int LDBv = Eng<NP>::LDB, PLANE = Eng<NP>::PLANE;
-#pragma unroll
-    for (int s = 0; s < Eng<NP>::KT / 16; ++s) {
-        bf16x8 a[2][NP], b[2][NP];
+    constexpr int LDBv = Eng<NP>::LDB, PLANE = Eng<NP>::PLANE, NS = Eng<NP>::KT / 16;
+    // NP = 3: the K tile has two K steps; the fragments of the second are requested before the MFMAs of the first (a
+    // ds_read that is waited for at once costs 64+ cycles -- tools/micro/x3_issue_bench.hip -- and hipcc sinks reads
+    // towards their uses: the fence keeps them where they are)
+    bf16x8 a[NP == 3 ? 2 : 1][2][NP], b[NP == 3 ? 2 : 1][2][NP];
+    auto frags = [&](int s, int w) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            a[0][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64, s, lane);
-            a[1][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64 + 32, s, lane);
-            b[0][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64, s, lane);
-            b[1][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64 + 32, s, lane);
+            a[w][0][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64, s, lane);
+            a[w][1][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64 + 32, s, lane);
+            b[w][0][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64, s, lane);
+            b[w][1][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64 + 32, s, lane);
         }
+    };
+    if constexpr (NP == 3) {
+        frags(0, 0);
+        frags(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int w = NP == 3 ? s : 0;
+        if constexpr (NP != 3) frags(s, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if constexpr (NP == 3) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[w][i][2], b[w][j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[w][i][0], b[w][j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[w][i][1], b[w][j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[w][i][1], b[w][j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[w][i][0], b[w][j][1], acc[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[w][i][0], b[w][j][0], acc[i][j], 0, 0, 0);
             }
     }
 }
@@ -1238,22 +1259,55 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
 static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1, nullptr, 0, 0, 0}; }
 static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1, nullptr, 0, 0, 0}; }
 
-// slice planes of a small operand (fp32x3 engine): k_presplit job + the operand's plane fields
+// Slice planes of the four small operands (fp32x3 engine).  They are written by launch_x3_planes at fixed points of the
+// step -- W1 and [W11 | b11] at the start of the forward pass, [d10 | 1] behind the decoder chain, dZ1 behind the encoder's
+// backward chain -- and read by the GEMM launchers below, which only fill in the operand's plane fields.
 static inline int rup_i(int a, int b) { return cdiv(a, b) * b; }
-static SplitJob plane_job(Operand& o, const float* src, int64_t ld, int64_t src_arm, int R, int C, int Rp, int Cp, int ones_col,
-                          float* ws_planes) {
-    unsigned short* dst = reinterpret_cast<unsigned short*>(ws_planes);
-    o.pl = dst; o.pl_plane = (int64_t)Rp * Cp; o.pl_arm = 3 * o.pl_plane; o.pl_ld = Cp;
-    return SplitJob{src, ld, src_arm, R, C, Rp, Cp, ones_col, dst, o.pl_arm, nullptr, 0};
+enum { PL_W1 = 0, PL_W11 = 1, PL_D10 = 2, PL_DZ1 = 3 };
+struct PlaneGeom { int R, C, Rp, Cp, ones_col; int64_t ws_off; };
+static PlaneGeom plane_geom(const Ctx& c, int kind) {
+    const mmvae_dims& d = c.d;
+    switch (kind) {
+        case PL_W1:  return PlaneGeom{d.H, d.D, 128, rup_i(d.D, 32), -1, c.lay.pl_w1};                 // W1 [H][D]
+        case PL_W11: return PlaneGeom{d.D, d.H, rup_i(d.D, 128), 128, d.H, c.lay.pl_w11};              // [W11 | b11] [D][H + 1]
+        case PL_D10: return PlaneGeom{d.B, d.H, rup_i(d.B, 256), 128, d.H, c.lay.pl_d10};              // [d10 | 1] [B][H + 1]
+        default:     return PlaneGeom{d.B, d.H, rup_i(d.B, 256), 128, -1, c.lay.pl_dz1};               // dZ1 [B][H]
+    }
+}
+static void use_planes(const Ctx& c, Operand& o, int kind) {
+    const PlaneGeom g = plane_geom(c, kind);
+    o.pl = reinterpret_cast<const unsigned short*>(c.ws + g.ws_off);
+    o.pl_plane = (int64_t)g.Rp * g.Cp; o.pl_arm = 3 * o.pl_plane; o.pl_ld = g.Cp;
+}
+static SplitJob plane_job(const Ctx& c, int kind, const float* src, int64_t ld, int64_t src_arm, const float* col_src = nullptr, int64_t col_arm = 0) {
+    const PlaneGeom g = plane_geom(c, kind);
+    return SplitJob{src, ld, src_arm, g.R, g.C, g.Rp, g.Cp, g.ones_col, reinterpret_cast<unsigned short*>(c.ws + g.ws_off),
+                    3 * (int64_t)g.Rp * g.Cp, col_src, col_arm};
 }
 static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n) {
     SplitJobs js{};
     int64_t most = 0;
     for (int i = 0; i < n; ++i) { js.j[i] = jobs[i]; most = most > (int64_t)jobs[i].Rp * (jobs[i].Cp / 8) ? most : (int64_t)jobs[i].Rp * (jobs[i].Cp / 8); }
-    const int blocks = (int)imin64(256, cdiv64(most, 256));
+    const int blocks = (int)imin64(1024, cdiv64(most, 256));
     hipLaunchKernelGGL(k_presplit, dim3(blocks, n, A), dim3(256), 0, s, js);
     HIP_LAUNCH_CHECK("k_presplit");
     return 0;
+}
+
+// fp32x3: write the slice planes of the small operands (bit 0: W1 and [W11 | b11], from the parameters; bit 1: [d10 | 1];
+// bit 2: dZ1) -- one small launch each time, ahead of the GEMMs that copy them into LDS.  No-op for the other engines.
+int launch_x3_planes(const Ctx& c, const float* params, int which) {
+    if (!split3_gemms(c)) return 0;
+    const mmvae_dims& d = c.d;
+    SplitJob jobs[4];
+    int n = 0;
+    if (which & 1) {
+        jobs[n++] = plane_job(c, PL_W1, params + c.po.o[0], d.D, c.po.per_arm);
+        jobs[n++] = plane_job(c, PL_W11, params + c.po.o[26], d.H, c.po.per_arm, params + c.po.o[27], c.po.per_arm);   // bias: column fc_dim
+    }
+    if (which & 2) jobs[n++] = plane_job(c, PL_D10, c.ws + c.lay.Dk[4], d.H, (int64_t)d.B * d.H);
+    if (which & 4) jobs[n++] = plane_job(c, PL_DZ1, c.ws + c.lay.DZ[1], d.H, (int64_t)d.B * d.H);
+    return n ? launch_presplit(c.stream, d.A, jobs, n) : 0;
 }
 
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs) {
@@ -1269,8 +1323,7 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
     g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
     g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
     if (split3_gemms(c)) {   // (fc_dim <= 124: one tile wide, the two tiles of a block share the W1 tile)
-        const SplitJob j = plane_job(g.b, params + c.po.o[0], d.D, c.po.per_arm, d.H, d.D, 128, rup_i(d.D, 32), -1, c.ws + c.lay.pl_w1);
-        if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+        use_planes(c, g.b, PL_W1);
         hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
     } else
         hipLaunchKernelGGL((k_bf16_gemm<false, false>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
@@ -1294,12 +1347,8 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         GemmArgs g{};
         g.a = kmajor(c.ws + L.Dk[4], d.H, d.B, d.H);
         g.b = kmajor(params + c.po.o[26], d.H, d.D, d.H);
-        SplitJob jobs[2];
-        jobs[0] = plane_job(g.b, params + c.po.o[26], d.H, c.po.per_arm, d.D, d.H, rup_i(d.D, 128), 128, d.H, c.ws + L.pl_w11);
-        jobs[0].col_src = params + c.po.o[27];      // the bias as column k = fc_dim
-        jobs[0].col_arm = c.po.per_arm;
-        jobs[1] = plane_job(g.a, c.ws + L.Dk[4], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 256), 128, d.H, c.ws + L.pl_d10);
-        if (int rc = launch_presplit(c.stream, d.A, jobs, 2)) return rc;
+        use_planes(c, g.b, PL_W11);
+        use_planes(c, g.a, PL_D10);
         g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.A = d.A; g.n11 = L.n11;
         g.fo = Fc11Out{params + c.po.o[27], x, c.ws + L.DZ11, nullptr, c.ws + L.fc11_part,
                        (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D};
@@ -1344,8 +1393,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.M = d.B; g.N = d.H; g.K = d.D; g.KS = NS; g.A = d.A;
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
         if (split3_gemms(c)) {
-            const SplitJob j = plane_job(g.b, params + c.po.o[26], d.H, c.po.per_arm, d.D, d.H, rup_i(d.D, 128), 128, -1, c.ws + L.pl_w11);
-            if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+            use_planes(c, g.b, PL_W11);      // (its bias column is row fc_dim of the transposed operand: beyond N, never stored)
             hipLaunchKernelGGL((k_x3_gemm<false, true, 0, 2, true>), dim3(cdiv(cdiv(d.B, BT), 2), NS, d.A), dim3(512), 0, c.stream, g);
         } else
             hipLaunchKernelGGL((k_bf16_gemm<false, true>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), NS, d.A), dim3(256), 0, c.stream, g);
@@ -1369,8 +1417,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
         g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
         if (split3_gemms(c)) {   // one tile high: the two tiles of a block share the dZ1 tile
-            const SplitJob j = plane_job(g.a, c.ws + L.DZ[1], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 128), 128, -1, c.ws + L.pl_dz1);
-            if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+            use_planes(c, g.a, PL_DZ1);
             hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
         } else
             hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
@@ -1387,8 +1434,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
         if (split3_gemms(c)) {   // one tile wide: the two tiles of a block share the [d10 | 1] tile
-            const SplitJob j = plane_job(g.b, c.ws + L.Dk[4], d.H, (int64_t)d.B * d.H, d.B, d.H, rup_i(d.B, 256), 128, d.H, c.ws + L.pl_d10);
-            if (int rc = launch_presplit(c.stream, d.A, &j, 1)) return rc;
+            use_planes(c, g.b, PL_D10);
             hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
         } else
             hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);

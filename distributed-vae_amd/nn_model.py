@@ -197,14 +197,17 @@ class mixVAE_model(nn.Module):
     def _ensure(self, B: int) -> N.Engine:
         if not self._is_packed():
             self._pack()
-        if self._engine is None or self._engine.dims.B != B or self._engine.device != self._flat.device:
+        mode = N.gemm_mode(self.gemm_dtype) & 0xFF
+        if (self._engine is None or self._engine.dims.B != B or self._engine.device != self._flat.device
+                or self._engine.gemm_engine != mode):
             # a trainer alternates between a few batch sizes (training batch, evaluation chunks, their ragged tails):
-            # keep the last few engines (workspace + events each) instead of reallocating 0.5 GB per switch
-            key = (B, str(self._flat.device), id(self._exec))
+            # keep the last few engines (workspace + events each) instead of reallocating 0.5 GB per switch.  The GEMM
+            # engine is part of the key: the workspace's split factors are chosen for its workgroup shapes.
+            key = (B, str(self._flat.device), id(self._exec), mode)
             eng = self._engines.pop(key, None)
             if eng is None:
                 d = self._dims(B)
-                eng = N.Engine(d.A, d.B, d.D, d.H, d.L, d.C, d.S, self._flat.device, self._exec)
+                eng = N.Engine(d.A, d.B, d.D, d.H, d.L, d.C, d.S, self._flat.device, self._exec, gemm_engine=mode)
             self._engines[key] = eng
             while len(self._engines) > 3:
                 self._engines.pop(next(iter(self._engines)))

@@ -129,6 +129,9 @@ enum {
     MMVAE_TUNE_ABLATE_L,           /* latent kernels: ablations                                       */
     MMVAE_TUNE_LAT_FULLWAVE,       /* latent kernels: one wave per cell instead of the half-wave layout */
     MMVAE_TUNE_ABLATE_B,           /* bf16 GEMM engine: 1 no MFMAs, 2 no global loads, 4 no LDS stores (results wrong)  */
+    MMVAE_TUNE_ENGINE,             /* not an experiment: the GEMM engine the caller is going to run (mmvae_hyper.gemm_bf16
+                                      & 0xFF; 0 = not stated).  The split factors of the workspace layout are chosen for the
+                                      workgroup shapes of that engine; any engine runs correctly on any layout */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {
