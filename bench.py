@@ -15,9 +15,11 @@ N>1 is plain data parallelism: each rank trains on its own shard of cells, ONE R
 (average) of the flat gradient buffer per step, Adam on every rank ("weak" scaling: per-GPU batch fixed).
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  "roofline":     dominant kernel (k_fc11_fused: x_rec GEMM + loss + dZ11 + d(d10) GEMM), algorithmic
-                  FLOPs per launch / its average duration measured with HIP events on the launch stream,
-                  against the fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
+  "roofline":     dominant kernel (fc11 forward + loss + dZ11 + d(d10) in one launch: k_x3_fc11g under the default fp32x3
+                  engine, k_fc11_zg under --gemm-dtype fp32_mfma), ALGORITHMIC fp32 FLOPs per launch / its average
+                  duration measured with HIP events on the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s,
+                  MI355X_MICROARCH.md); under fp32x3 also "executed": the bf16 MFMAs actually issued (six slice products
+                  per product on padded tiles) against the bf16 matrix peak;
   "cpu_baseline": the oracle (oracle/restatement.py, kind "port": the reference's arithmetic restated,
                   pinned to the reference by tests/) timed on this box's host cores on the same workload.
 """
@@ -40,6 +42,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense (same guide)
 
 
 def flops_per_cell_arm(D, H, L, C, S):
@@ -230,9 +233,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-operand configuration measured beside the headline")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
-    ap.add_argument("--gemm-dtype", choices=["fp32", "bf16"], default="fp32",
-                    help="operand type of the five D x H GEMMs: fp32 (the headline / parity configuration) or bf16 "
-                         "(BASELINE.json configs[2]: bf16 operands, fp32 accumulation, everything else fp32)")
+    ap.add_argument("--gemm-dtype", choices=["fp32", "fp32x3", "fp32_mfma", "bf16"], default="fp32",
+                    help="operand type of the five D x H GEMMs: fp32 (the headline / parity configuration; the library's "
+                         "fp32 engine, i.e. fp32x3: every fp32 operand as three exact bf16 slices, six slice products per "
+                         "product on the bf16 matrix pipe, fp32 accumulation), fp32_mfma (the fp32 matrix instruction), or "
+                         "bf16 (BASELINE.json configs[2]: operands ROUNDED to bf16, fp32 accumulation, everything else fp32)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N > 1 path on a box with fewer GPUs: every rank uses cuda:0 and the collectives "
                          "go through gloo (RCCL refuses two ranks on one device); the line is marked as a rehearsal")
@@ -373,16 +378,17 @@ def main():
         "scaling": "weak",
         **({"rehearsal": "ranks share one GPU, gloo collectives: NOT a multi-GPU measurement"} if args.share_gpu else {}),
         "vs_baseline": None,
-        "dtype": "f32" if args.gemm_dtype == "fp32" else "bf16 operands in the five D x H GEMMs, f32 accumulation and everything else",
+        "dtype": "f32" if args.gemm_dtype != "bf16" else "bf16 operands in the five D x H GEMMs, f32 accumulation and everything else",
         "data": "synthetic",
         "config": {"workload": f"cpl_mixVAE A={A} arms, synthetic-10x-v1 {args.cells} cells x {D} genes per GPU, "
                                f"batch {B}/GPU, fp32, H=100 L=10 C=92 S=2, x_drop=0.5, Adam lr=1e-3",
                    "global_batch": world * B, "parallelism": f"dp{world}", "noise": "in-kernel Philox4x32-10",
+                   "gemm_engine": engine_name(N, args.gemm_dtype),
                    "flop_per_cell": fl_cell, "bytes_per_cell": by_cell, "last_loss": loss_last},
     }
     if rccl_ranks is not None:
         out["rccl_ranks"] = rccl_ranks
-    if args.gemm_dtype == "fp32" and not args.no_bf16:
+    if args.gemm_dtype != "bf16" and not args.no_bf16:
         # BASELINE.json configs[2] beside the headline: the same step with bf16 operands in the five D x H GEMMs
         try:
             out["bf16_config"] = bf16_config(args, model_args, batches, nb, A, B, D, H, L, C, S, P_count(N, A, B, D, H, L, C, S),
@@ -605,6 +611,18 @@ def augmenter_forward(args, batches, A, B, D, with_cpu):
     return out
 
 
+def engine_name(N, gemm_dtype):
+    """The GEMM engine behind a gemm_dtype, with what it does to an fp32 product (for the JSON line)."""
+    mode = N.gemm_mode(gemm_dtype) & 0xFF
+    return {0: "fp32_mfma: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)",
+            1: "bf16: operands rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulation",
+            2: "fp32x3: each fp32 operand split exactly into three bf16 slices, six slice products per product on "
+               "v_mfma_f32_32x32x16_bf16, fp32 accumulation (dropped terms <= 2^-26 per product)"}[mode]
+
+
+# kernel names of the fp32x3 engine for the same debug stages (gemm_bf16.hip)
+STAGES_X3 = {14: "k_x3_gemm<fc1>", 1: "k_x3_fc11g", 12: "k_x3_gemm<dW1>", 13: "k_x3_gemm<dW11>"}
+
 STAGES = {
     # debug-stage id: (kernel, algorithmic FLOPs per launch, algorithmic HBM bytes per launch, on the critical path?)
     # as functions of (A,B,D,H).  dW11 runs on a side stream beside the latency-bound backward chain (with fewer,
@@ -627,6 +645,7 @@ def measure_stages(model, x, A, B, D, H):
 
     eng = model._engine
     hyper = model._hyper(1.0, False)
+    x3 = (hyper.gemm_bf16 & 0xFF) == 2 and H + 1 <= 112
     noise = N.make_noise(None, 99, 1)
     eng.forward(hyper, noise, model._flat, model._bn_flat, None, x, 0, None, True)
     eng.loss(hyper)
@@ -636,6 +655,8 @@ def measure_stages(model, x, A, B, D, H):
     for sid, (names, fl, by, crit) in STAGES.items():
         # fc_dim 100 runs the 96 + 4 column kernels (v3), any other width the 128-wide tiles (v2)
         name = names.split("|")[0 if (H == 100 or "|" not in names) else 1]
+        if x3:
+            name = STAGES_X3[sid]
         for _ in range(3):
             eng.debug_stage(sid, hyper, noise, model._flat, x, 0)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -654,6 +675,17 @@ def measure_stages(model, x, A, B, D, H):
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
            "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
            "traffic_source": src, "avg_launch_ms": res[dom]["avg_launch_ms"], "stages": res}
+    if x3:
+        # `achieved` / `frac` stay ALGORITHMIC fp32 FLOPs against the fp32 matrix peak (the contract's pricing).  What the
+        # kernel executes is six bf16 MFMAs per pair of fragments on padded tiles (k_x3_fc11g: 90 v_mfma_f32_32x32x16_bf16
+        # per wave and piece of 32 cells x 32 genes); against the bf16 matrix peak:
+        ex_fl = A * (4 * ((B + 127) // 128)) * (2 * ((D + 63) // 64)) * 90 * 32768.0 if dom == "k_x3_fc11g" else None
+        out["engine"] = "fp32x3 (fp32 operands as three exact bf16 slices, six slice products per product)"
+        if ex_fl:
+            t_s = res[dom]["avg_launch_ms"] * 1e-3
+            out["executed"] = {"mfma_tflops": ex_fl / t_s / 1e12, "peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS,
+                               "frac_of_bf16_mfma_peak": ex_fl / t_s / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                               "executed_over_algorithmic_flops": ex_fl / STAGES[1][1](A, B, D, H)}
     busy = pmc_mfma_busy(dom, A, B, D, H)
     if busy is not None:
         out["mfma_busy"] = busy
@@ -700,7 +732,7 @@ def pmc_traffic(kernel, A, B, D, H):
     `--pmc WRITE_SIZE` runs of this bench command, summarised by tools/pmc_summary.py).  FETCH_SIZE (KB) is doubled as
     the gfx950 guide prescribes for 16-byte-per-lane loads -- which is how k_fc11_zg and k_fc1_fwd_v3 read x and the
     weights -- and WRITE_SIZE (KB) is taken as is.  Other kernels: null (their load widths are uncalibrated)."""
-    if kernel not in ("k_fc11_zg", "k_fc1_fwd_v3"):
+    if kernel not in ("k_fc11_zg", "k_fc1_fwd_v3", "k_x3_fc11g"):
         return None, None
     rows, src = _pmc_rows("hbm", A, B, D, H)
     for r in rows or []:

@@ -64,6 +64,13 @@ struct Eng {
     static constexpr int NQ = KT / 8;            // 16-byte pieces per thread per operand and K tile
     static constexpr int LDB = KT / 2 + 4;       // KMAJOR image row stride in dwords (36 / 20: conflict-free ds_read_b128)
     static constexpr int PLANE = BT * LDB;       // dwords of one plane's image (the KMINOR image, KT x LDK bf16, fits in it)
+    // KMINOR image [k][row]: k-row pitch in bf16.  A transposing read (ds_read_b64_tr_b16) takes, per 16 lanes, 4 k rows x
+    // 16 row-columns (8 bytes per lane), 32 lanes per LDS cycle: with a pitch of 68 dwords (136 bf16) k rows q and q + 1
+    // land 4 banks apart and collide with the neighbouring lanes' 8-byte reads (PMC: SQ_LDS_BANK_CONFLICT = 31 % of the
+    // busy cycles of dW1 / dW11); 80 dwords (160 bf16) puts them 16 banks apart -- the four k rows of both 16-lane
+    // groups tile the 64 banks exactly -- and 32 x 160 bf16 is exactly one plane.  The one-plane engine (K tile 64)
+    // has no room for that pitch and keeps 136.
+    static constexpr int LDK = NP == 1 ? 136 : 160;
     static constexpr int NBUF = NP == 1 ? 2 : 1;
 };
 
@@ -194,7 +201,7 @@ __device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileR
         for (int e = 0; e < 4; ++e) x[e] = __uint_as_float(__float_as_uint(vv[e]) & (unsigned)__builtin_amdgcn_sbfe(nib, e, 1));
         idx = (rr + 32 * p) * LDBv + (kq + 8 * h) * 2;
     } else {
-        // natural layout [k][row] (rows contiguous, LDK bf16 per k): one 8-byte store per (k, four rows); the MFMA
+        // natural layout [k][row] (rows contiguous, Eng<NP>::LDK bf16 per k): one 8-byte store per (k, four rows); the MFMA
         // fragments come out of it through the transposing LDS read (ds_read_b64_tr_b16, see frag8)
         const int r4 = (tid & 31) * 4, kp = tid >> 5;
         const int kl = 2 * (kp + 8 * p) + h, k = k0 + kl;
@@ -210,7 +217,7 @@ __device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileR
             for (int e = 0; e < 4; ++e)
                 if (kok && r0 + r4 + e == o.ones_row) x[e] = 1.f;
         }
-        idx = (kl * LDK + r4) >> 1;     // LDK and r4 are multiples of 4 bf16
+        idx = (kl * Eng<NP>::LDK + r4) >> 1;     // LDK and r4 are multiples of 4 bf16
     }
     if constexpr (NP == 1) {
         uint2 w;
@@ -243,17 +250,17 @@ __device__ __forceinline__ void tile_store(unsigned* __restrict__ T, const TileR
 // group of 16 lanes the hardware reads a 4 (k) x 16 (rows) block and hands lane i of the group column i, i.e. four
 // consecutive k of row i; lane 4 q + p supplies the address of block row q, columns 4 p .. 4 p + 3.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-template <bool MINOR, int LDBv = LDB>
+template <bool MINOR, int LDBv = LDB, int LDKv = LDK>
 __device__ __forceinline__ bf16x8 frag8(const unsigned* T, int rb, int s, int lane) {
     if (!MINOR) {
         return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(T + (rb + (lane & 31)) * LDBv + 4 * (lane >> 5) + 8 * s));
     } else {
         const unsigned short* Tk = reinterpret_cast<const unsigned short*>(T);
         const int grp = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-        const unsigned short* a = Tk + (16 * s + 8 * (grp >> 1) + q) * LDK + rb + 16 * (grp & 1) + 4 * p;
+        const unsigned short* a = Tk + (16 * s + 8 * (grp >> 1) + q) * LDKv + rb + 16 * (grp & 1) + 4 * p;
         typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * LDK));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * LDKv));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 r;
         r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
@@ -285,7 +292,7 @@ __device__ __forceinline__ void plane_store(unsigned* __restrict__ T, const Plan
     const int tid = threadIdx.x & 255, pl = j >> 1, id = tid + 256 * (j & 1);
     int idx;   // dwords
     if (!KMINOR) idx = pl * Eng<3>::PLANE + (id >> 2) * Eng<3>::LDB + 4 * (id & 3);
-    else idx = pl * Eng<3>::PLANE + (((id >> 4) * LDK + 8 * (id & 15)) >> 1);
+    else idx = pl * Eng<3>::PLANE + (((id >> 4) * Eng<3>::LDK + 8 * (id & 15)) >> 1);
     *reinterpret_cast<u32x4v*>(&T[idx]) = t.v[j];
 }
 
@@ -383,10 +390,10 @@ __device__ __forceinline__ void mfma_ktile(f32x16 (&acc)[2][2], const unsigned* 
     auto frags = [&](int s, int w) __attribute__((always_inline)) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-            a[w][0][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64, s, lane);
-            a[w][1][pl] = frag8<AMINOR, LDBv>(As + pl * PLANE, wm * 64 + 32, s, lane);
-            b[w][0][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64, s, lane);
-            b[w][1][pl] = frag8<BMINOR, LDBv>(Bs + pl * PLANE, wn * 64 + 32, s, lane);
+            a[w][0][pl] = frag8<AMINOR, LDBv, Eng<NP>::LDK>(As + pl * PLANE, wm * 64, s, lane);
+            a[w][1][pl] = frag8<AMINOR, LDBv, Eng<NP>::LDK>(As + pl * PLANE, wm * 64 + 32, s, lane);
+            b[w][0][pl] = frag8<BMINOR, LDBv, Eng<NP>::LDK>(Bs + pl * PLANE, wn * 64, s, lane);
+            b[w][1][pl] = frag8<BMINOR, LDBv, Eng<NP>::LDK>(Bs + pl * PLANE, wn * 64 + 32, s, lane);
         }
     };
     if constexpr (NP == 3) {
@@ -945,19 +952,25 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
 //     overlaps its own work instead: the z product of piece p + 1 (42 MFMAs, fragments requested one K step ahead) is
 //     issued through the epilogue of piece p (about six VALU instructions fit behind every MFMA);
 //   * a wave keeps its cells' d10 slices in registers for the whole kernel (7 K steps x 3 slices x 4 VGPRs);
-//   * LDS holds only W11 tiles (64 genes x 112 k x 3 slices, row pitch 240 B), three of them, filled by LDS-DMA
+//   * LDS holds only W11 tiles (64 genes x 128 k x 3 slices, XOR-swizzled, 48 KB), three of them, filled by LDS-DMA
 //     (global_load_lds_dwordx4: no registers, no VALU) two tiles ahead; a tile serves the z product as the A operand
 //     (ds_read_b128) and the d(d10) product as the B operand through transposing reads (ds_read_b64_tr_b16);
 //   * dZ11 is split into its slices in registers between the two products (eleven VALU instructions per pair);
 //   * cells and genes that do not exist have z = 0 (zero rows of the planes) and read x = 0 (buffer range): no masks.
 // grid (ceil(B / 128), gene splits NS, A); fc_dim + 1 <= 112.
-constexpr int FW_ROW = 60;                     // dwords per W11 image row: 112 bf16 (seven K steps) + 16 B
+// W11 tile image in LDS: [gene][k], 128 bf16 = 16 sixteen-byte blocks per row, NO padding; block c of row r sits at block
+// c ^ fw_swz(r).  The image is read two ways -- row per lane (ds_read_b128: 16 lanes x 16 B must hit 16 different
+// 4-bank groups) and transposed (ds_read_b64_tr_b16: per LDS cycle 2 x 16 lanes = 4 rows x 2 blocks x 2 column groups) --
+// and no row pitch serves both (60 dwords: transposing reads 2-way conflicts, 19 % of the kernel's busy cycles in the PMC
+// pass; 80: row reads 4-way).  The XOR below makes both conflict-free: rows r .. r + 3 differ in bits 2-3 of the block,
+// rows r, r + 4, r + 8, r + 12 in bits 0-1.
+constexpr int FW_ROW = 64;                     // dwords per W11 image row
 constexpr int FW_PLANE = 64 * FW_ROW;          // dwords per slice image of a 64-gene tile
 constexpr int FW_TILE = 3 * FW_PLANE;
+__device__ __forceinline__ int fw_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     const GemmArgs g = g_in;
-    __shared__ __attribute__((aligned(16))) unsigned Wl[3 * FW_TILE + 64];   // three tiles (+ slack: the transposing reads of the
-                                                                              // last h tile run past a row's 112 columns)
+    __shared__ __attribute__((aligned(16))) unsigned Wl[3 * FW_TILE];        // three tiles
     __shared__ float red[8];
     const int arm = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -976,17 +989,18 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     const int rowoff = min(cell, B - 1) * D;          // B * D < 2^30 (fast-path condition)
     const bool cell_ok = cell < B;
 
-    // LDS-DMA of W11 tile t into buffer (t - t0) % 3: 3 slices x 64 rows x 15 sixteen-byte pieces (the 15th is the row's pad
-    // and re-reads piece 0) = 45 wave instructions of 1 KB, twelve per wave (the last three slots repeat instruction 44).
+    // LDS-DMA of W11 tile t into buffer (t - t0) % 3: 3 slices x 64 rows x 16 sixteen-byte blocks = 48 wave instructions of
+    // 1 KB, twelve per wave; LDS slot (row, block b) takes the plane's block b ^ fw_swz(row) (blocks 14, 15: the planes'
+    // zero padding).
     auto dma = [&](int t) __attribute__((always_inline)) {
         const int buf = (t - t0) % 3;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            const int ii = min(wv + 4 * j, 44);
-            const int pl = ii / 15, chunk = ii - 15 * pl;
-            const int pc = chunk * 64 + lane, row = pc / 15, c = pc - 15 * row;
+            const int ii = wv + 4 * j;
+            const int pl = ii >> 4, chunk = ii & 15;
+            const int row = chunk * 4 + (lane >> 4), c = (lane & 15) ^ fw_swz(row);
             // (32-bit element offsets: the planes of an arm are a few MB)
-            const unsigned off = (unsigned)pl * (unsigned)wplane + (unsigned)(t * 64 + row) * 128u + (c < 14 ? 8u * c : 0u);
+            const unsigned off = (unsigned)pl * (unsigned)wplane + (unsigned)(t * 64 + row) * 128u + 8u * c;
             const unsigned short* src = Wp + off;
             // (inline assembly, not __builtin_amdgcn_global_load_lds: hipcc's wait-count pass treats the builtin as a store to
             // "some" LDS and puts s_waitcnt vmcnt(0) in front of the next LDS read -- which, with the x prefetch just issued,
@@ -1013,13 +1027,16 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     int mism = 0;                       // wave-uniform: mismatches of the whole wave
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    // transposing-read address of this lane inside a (4 genes x 16 h) block: row (lane & 15) >> 2, columns 4 (lane & 3) ..
-    const int tr_off = ((lane & 15) >> 2) * (2 * FW_ROW) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    // transposing read: this lane supplies the address of row q = (lane & 15) >> 2 of a (4 genes x 16 h) block, columns
+    // 4 (lane & 3) .. + 3 of the 16 that start at 16 ((lane >> 4) & 1): sixteen-byte block 2 ((lane >> 4) & 1) + (lane & 3) / 2
+    // of the h tile, its half (lane & 1)
+    const int tr_q = (lane & 15) >> 2, tr_blk = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), tr_half = 4 * (lane & 1);
     const int npieces = 2 * (t1 - t0);
     // piece p: genes [64 t0 + 32 p, + 32), rows 32 (p & 1) of tile t0 + p / 2 in LDS buffer (p / 2) % 3
     auto w_rows = [&](int p) __attribute__((always_inline)) { return Wl + ((p >> 1) % 3) * FW_TILE + 32 * (p & 1) * FW_ROW; };
+    const int a_swz = fw_swz(l31);      // (a piece starts at row 0 or 32 of the tile: the row's low four bits are the lane's)
     auto a_frag = [&](const unsigned* Wr, int s, int pl) __attribute__((always_inline)) {
-        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Wr + pl * FW_PLANE + l31 * FW_ROW + 8 * s + 4 * hh));
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4v*>(Wr + pl * FW_PLANE + l31 * FW_ROW + 4 * ((2 * s + hh) ^ a_swz)));
     };
     auto request_x = [&](float4 (&X)[4], int j0g, int q) __attribute__((always_inline)) {   // x of gene group q of the piece at j0g
         const int gene = j0g + 8 * q + 4 * hh;                      // D % 4 == 0: a float4 exists entirely or not at all
@@ -1054,14 +1071,16 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
         for (int pl = 0; pl < 3; ++pl) an[s % 3][pl] = a_frag(Wr, s, pl);
     };
     auto d_frags = [&](const unsigned short* Wt16, int r) __attribute__((always_inline)) {   // region r: K step r >> 1, h tiles 2 (r & 1) ..
-        const int grow = 16 * (r >> 1) + 4 * hh;            // first of this lane's two gene groups (second: + 8)
+        const int row0 = 16 * (r >> 1) + 4 * hh + tr_q;     // this lane's row of the first gene group (second: + 8)
+        const int sw0 = fw_swz(row0), sw1 = fw_swz(row0 + 8);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                const unsigned short* ap = Wt16 + pl * (2 * FW_PLANE) + grow * (2 * FW_ROW) + 32 * (2 * (r & 1) + j) + tr_off;
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)ap);
-                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(ap + 8 * (2 * FW_ROW)));
+                const int blk = 4 * (2 * (r & 1) + j) + tr_blk;     // sixteen-byte block of the row (h tile 2 (r & 1) + j)
+                const unsigned short* base = Wt16 + pl * (2 * FW_PLANE) + tr_half;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + row0 * (2 * FW_ROW) + 8 * (blk ^ sw0)));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + (row0 + 8) * (2 * FW_ROW) + 8 * (blk ^ sw1)));
                 s16x8 rr;
                 rr[0] = v0[0]; rr[1] = v0[1]; rr[2] = v0[2]; rr[3] = v0[3];
                 rr[4] = v1[0]; rr[5] = v1[1]; rr[6] = v1[2]; rr[7] = v1[3];
@@ -1251,6 +1270,10 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
         pp[0] = (red[0] + red[2]) + (red[4] + red[6]);
         pp[1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
+    // the loss finalisation sums all n11 slots of an arm: the first block of the arm clears the ones no block writes
+    // (instead of a memset launch in front of the kernel)
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = (int)gridDim.x * g.KS * 2 + tid; i < 2 * g.n11; i += 256) g.fo.part[(int64_t)arm * g.n11 * 2 + i] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1342,8 +1365,6 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         // fp32x3: only the fused train-step kernel exists in this engine (fc_dim + 1 <= 112, 128 cells per block fit the
         // loss-partial slots); everything else runs the fp32 matrix-instruction kernels (the caller falls through)
         if (!(which & 1)) return 0;
-        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
-        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
         GemmArgs g{};
         g.a = kmajor(c.ws + L.Dk[4], d.H, d.B, d.H);
         g.b = kmajor(params + c.po.o[26], d.H, d.D, d.H);

@@ -67,10 +67,18 @@ typedef struct mmvae_hyper {
     int32_t hard;      /* straight-through one-hot sample, :486-493         */
     int32_t training;  /* module.training: batch-stat BN + dropout active   */
     int32_t eval_flag; /* forward(eval=True): no Gumbel noise, hard sample, :340-343 */
-    int32_t gemm_bf16; /* != 0: the five D x H GEMMs (fc1, fc11, d(d10), dW1, dW11) take bf16 operands (rounded to
-                          nearest even on load) with fp32 accumulation on the bf16 matrix pipe -- BASELINE.json's bf16
-                          configuration; every other computation and all parameters stay fp32.  0: fp32 operands.
-                          Needs the fast path (D % 4 == 0, fc_dim % 4 == 0, fc_dim <= 124), else ignored. */
+    int32_t gemm_bf16; /* engine of the five D x H GEMMs (fc1, fc11, d(d10), dW1, dW11); low byte:
+                          0  fp32 operands on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain);
+                          1  bf16 operands (rounded to nearest even on load), fp32 accumulation on the bf16 matrix pipe --
+                             BASELINE.json's bf16 configuration;
+                          2  "fp32x3": fp32 operands, each split EXACTLY into three bf16 slices (8 + 8 + 8 significand bits),
+                             a product formed from six of the nine slice products on the bf16 matrix pipe with fp32
+                             accumulation; what is dropped is <= 2^-26 of |a b|, below the fp32 rounding of the accumulation.
+                             fp32-grade results at 6/64 of the matrix-pipe time of engine 0 (the Python binding's "fp32").
+                          Every other computation and all parameters stay fp32 under all three.  Engines 1 and 2 need the
+                          fast path (D % 4 == 0, fc_dim % 4 == 0, fc_dim <= 124; engine 2's fused fc11 kernel fc_dim <= 111),
+                          else engine 0 runs.  Bits 8..11 (diagnostics, engine 2 only): products that stay on engine 0
+                          (1 fc1, 2 fc11 + d(d10), 4 dW1, 8 dW11). */
 } mmvae_hyper;
 
 /* Noise descriptor.  mode 0 = explicit buffers (parity tests; the reference's RNG stream cannot
@@ -309,7 +317,7 @@ int mmvae_aug_pack(const mmvae_aug_dims *d, const mmvae_aug_tensors *t, float *p
 /* x: [B,D] shared by the arms (x_arm_stride == 0, as x.expand) or [A,B,D] contiguous (x_arm_stride == B*D).
  * z0: [A,B,NZ] and eps: [A,B,Z] standard-normal draws (the reference's torch.randn / randn_like); scale: the
  * noise scale (0.1 in the trainer).  Outputs: s_out [A,B,Z] (forward out 0), x_aug [A,B,D] (forward out 1),
- * ready as the per-arm input of mmvae_train_step (x_arm_stride = B*D).  gemm_bf16 != 0: the ten large Linear layers
+ * ready as the per-arm input of mmvae_train_step (x_arm_stride = B*D).  gemm_bf16 (0 / 1 / 2 as mmvae_hyper.gemm_bf16): != 0: the ten large Linear layers
  * take bf16 operands with fp32 accumulation (BASELINE.json's bf16 configuration); the latent block, the folded
  * BatchNorm / ReLU epilogues and all stored activations stay fp32. */
 int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, int64_t x_arm_stride,

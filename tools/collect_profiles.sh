@@ -8,10 +8,13 @@ OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-eval --no-roofline --no-bf16"
-# 1. kernel stats of the fp32 train step and of the bf16 configuration
+# 1. kernel stats of the fp32 train step (default engine: fp32x3), of the same step on the fp32 matrix instruction and of
+#    the bf16 configuration
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_fp32 -- $BENCH > $OUT/kstats_fp32.json 2> $OUT/kstats_fp32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_mfma -- $BENCH --gemm-dtype fp32_mfma > $OUT/kstats_mfma.json 2> $OUT/kstats_mfma.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_bf16 -- $BENCH --gemm-dtype bf16 > $OUT/kstats_bf16.json 2> $OUT/kstats_bf16.err
 cp $(find $OUT/kstats_fp32 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
+cp $(find $OUT/kstats_mfma -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_fp32mfma_kernel_stats.csv
 cp $(find $OUT/kstats_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_bf16_kernel_stats.csv
 # 2. PMC passes (own runs, counters only): HBM traffic, matrix-pipe utilisation
 SHORT="python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval --no-roofline --no-bf16"
@@ -27,10 +30,10 @@ python3 tools/pmc_summary.py $OUT/pmcb_FETCH_SIZE $OUT/pmcb_WRITE_SIZE > $OUT/${
 python3 tools/pmc_summary.py $OUT/pmc_mfma1 $OUT/pmc_mfma2 > $OUT/${R}_pmc_mfma_summary.csv
 python3 - <<PY
 import hashlib, json
-srcs = ["distributed-vae_amd/csrc/gemm_fast.hip", "distributed-vae_amd/csrc/common.hpp"]
+srcs = ["distributed-vae_amd/csrc/gemm_fast.hip", "distributed-vae_amd/csrc/gemm_bf16.hip", "distributed-vae_amd/csrc/common.hpp"]
 json.dump({"sources_sha256": {s: hashlib.sha256(open(s, "rb").read()).hexdigest() for s in srcs},
            "command": "tools/collect_profiles.sh $R"}, open("$OUT/${R}_pmc_meta.json", "w"), indent=1)
 PY
 # drop the bulky raw traces from what travels back (keep the summaries)
-rm -rf $OUT/kstats_fp32 $OUT/kstats_bf16 $OUT/pmc_* $OUT/pmcb_*
+rm -rf $OUT/kstats_fp32 $OUT/kstats_mfma $OUT/kstats_bf16 $OUT/pmc_* $OUT/pmcb_*
 ls -la $OUT
