@@ -85,6 +85,7 @@ Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex) {
         if (g_split[4] <= 0) s.ks_gd10 = min(fit(nb128 * d.A, CUS, 16), max(1, cdiv(d.D, 64)));
         if (g_split[2] <= 0) s.ks_dw = min(fit(pairs_d * d.A, CUS, 16), max(1, cdiv(d.B, 32)));
         if (g_split[5] <= 0) s.ks_dw11 = min(fit(pairs_d * d.A, CUS / 2, 16), max(1, cdiv(d.B, 32)));
+        if (g_split[3] <= 0) s.ks_small = min(fit(cdiv(N_SMALL * d.A, 2), CUS, 32), max(1, cdiv(d.B, 32)));   // k_x3_small: a pair of products per block
     }
     return s;
 }
@@ -351,7 +352,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     // T (sum of G log c, from the loss finalisation) is first needed here
     if (wait_loss && (rc = join_from_side(c, EV_COUPLE))) return rc;
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
-    if (use_side && dw11_at >= 2 && (rc = fork_dw11())) return rc;
+    if (use_side && dw11_at == 2 && (rc = fork_dw11())) return rc;   // (3: not forked -- dW11 behind dW1 on the main stream)
     for (int layer = 5; layer >= 2; --layer)
         if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
     if ((rc = launch_bn_bwd_apply1(c))) return rc;

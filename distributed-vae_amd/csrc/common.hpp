@@ -566,6 +566,19 @@ int launch_chain_bwd_enc(const Ctx& c, int layer /*5..2*/, const float* params);
 int launch_bn_bwd_apply1(const Ctx& c);
 int launch_dw_big(const Ctx& c, const mmvae_noise* nz, const float* x, int64_t xs);
 int launch_dw_small(const Ctx& c, int which = 3 /*bit0 decoder layers, bit1 encoder side*/);
+// one product of the batched small-layer gradient GEMM: out[m][n] = sum_b P[b][m] * Q'[b][n]  (gemm_big.hip, gemm_bf16.hip)
+struct TnDesc {
+    const float* P; int64_t p_arm_stride; int ldp; int Mv;   // rows of out
+    const float* Q; int64_t q_arm_stride; int ldq; int Nv;   // cols of out (before the ones column)
+    int q_ones;            // 1: column Nv of Q is the constant 1 (bias gradient)
+    int q_xmask;           // 1: Q is x, apply dropout keep-mask (scale applied by the reducer)
+    const float* q_mean;   // != null: Q <- (Q - mean[n]) * rstd[n]   (BatchNorm-normalised input)
+    const float* q_rstd;   //          arrays are [A][Nv]
+    float* out; int64_t out_arm_stride; int64_t out_ks_stride; int ldo;   // out[ks][arm][m][n]
+};
+
+struct TnDescs { TnDesc d[N_SMALL]; };
+int launch_dw_small_x3(const Ctx& c, const TnDescs& ts, int nsel);
 struct AdamHost { float* p; float* m; float* v; int64_t step; float lr, b1, b2, eps, wd; int decoupled; };
 // slabs -> grads; with `adam` (p != null) the Adam update is fused into the same pass
 int launch_reduce_grads(const Ctx& c, float* grads, float grad_scale, const AdamHost* adam, bool dw11_fast,

@@ -131,6 +131,7 @@ struct OperandDev {
     __amdgpu_buffer_rsrc_t rs, rb;   // matrix, mask words
     int ld, rows, K, wpr, ones_row;
     bool bits;
+    float4 bn_sub, bn_mul;           // BN = true (k_x3_small): this thread's four rows read (v - bn_sub) * bn_mul
 };
 template <bool KMINOR>
 __device__ __forceinline__ OperandDev make_operand_dev(const Operand& o) {
@@ -178,7 +179,7 @@ __device__ __forceinline__ void quad_load(TileRegsT<BITS, Eng<NP>::NQ>& t, const
     if constexpr (BITS) t.wd[q] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
 }
 
-template <bool KMINOR, bool BITS = true, int NP = 1>
+template <bool KMINOR, bool BITS = true, int NP = 1, bool BN = false>
 __device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileRegsT<BITS, Eng<NP>::NQ>& t, const OperandDev& o, int r0,
                                            int k0, int kend, int q) {
     constexpr int LDBv = Eng<NP>::LDB, PLANE = Eng<NP>::PLANE;
@@ -212,6 +213,11 @@ __device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileR
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = __uint_as_float(__float_as_uint(vv[e]) & (unsigned)__builtin_amdgcn_sbfe(nib, e, 1));
+        if constexpr (BN) {     // BatchNorm-normalised input, as k_gemm_tn: (v - mean) * rstd; rows / k that do not exist stay 0
+            const float sb[4] = {o.bn_sub.x, o.bn_sub.y, o.bn_sub.z, o.bn_sub.w}, ml[4] = {o.bn_mul.x, o.bn_mul.y, o.bn_mul.z, o.bn_mul.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = ((nib >> e) & 1) ? (x[e] - sb[e]) * ml[e] : 0.f;
+        }
         if (o.ones_row >= 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -1276,6 +1282,86 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
         for (int i = (int)gridDim.x * g.KS * 2 + tid; i < 2 * g.n11; i += 256) g.fo.part[(int64_t)arm * g.n11 * 2 + i] = 0.f;
 }
 
+// The small-layer weight / bias gradients (twelve products per arm, out[m][n] = sum_b P[b][m] Q'[b][n], m <= 128,
+// n + 1 <= 128, K = batch) on the split engine: the ping-pong kernel with ONE PRODUCT PER GROUP -- the two groups of a block
+// take products 2 b and 2 b + 1 of the (product, arm) list, each with its own operands (both batch-reduced, i.e. K-minor;
+// Q optionally BatchNorm-normalised on load and extended by the ones column of the bias gradient, as k_gemm_tn does).
+// grid (ceil(ndesc * A / 2), KS).  2.4 GFLOP in all: 57 us on the fp32 matrix instruction (pipe 28 % busy).
+__global__ __launch_bounds__(512, 1) void k_x3_small(const TnDescs descs, int ndesc, int A, int B, int KS) {
+    typedef Eng<3> E;
+    constexpr int KTv = E::KT;
+    __shared__ __attribute__((aligned(16))) unsigned As[2][3 * E::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned Bs[2][3 * E::PLANE];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+    const int unit = 2 * blockIdx.x + grp;
+    const bool active = unit < ndesc * A;
+    const int di = active ? unit % ndesc : 0, arm = active ? unit / ndesc : 0;
+    const TnDesc& dr = descs.d[di];
+    const TnDesc d = {dr.P, dr.p_arm_stride, dr.ldp, dr.Mv, dr.Q, dr.q_arm_stride, dr.ldq, dr.Nv, dr.q_ones, dr.q_xmask,
+                      dr.q_mean, dr.q_rstd, dr.out, dr.out_arm_stride, dr.out_ks_stride, dr.ldo};
+    Operand oa_h{d.P + (int64_t)arm * d.p_arm_stride, d.ldp, d.Mv, B, 1, nullptr, 0, -1, nullptr, 0, 0, 0};
+    Operand ob_h{d.Q + (int64_t)arm * d.q_arm_stride, d.ldq, d.Nv, B, 1, nullptr, 0, d.q_ones ? d.Nv : -1, nullptr, 0, 0, 0};
+    OperandDev oa = make_operand_dev<true>(oa_h), ob = make_operand_dev<true>(ob_h);
+    const bool bn = d.q_mean != nullptr;
+    {
+        const int r4 = (tid & 31) * 4;
+        float sb[4] = {0.f, 0.f, 0.f, 0.f}, ml[4] = {1.f, 1.f, 1.f, 1.f};
+        if (bn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (r4 + e < d.Nv) { sb[e] = d.q_mean[(int64_t)arm * d.Nv + r4 + e]; ml[e] = d.q_rstd[(int64_t)arm * d.Nv + r4 + e]; }
+        }
+        ob.bn_sub = make_float4(sb[0], sb[1], sb[2], sb[3]);
+        ob.bn_mul = make_float4(ml[0], ml[1], ml[2], ml[3]);
+    }
+    const int nkt = cdiv(B, KTv);
+    const int kb = (int)(((int64_t)blockIdx.y * nkt) / KS) * KTv;
+    const int ke = min(B, (int)(((int64_t)(blockIdx.y + 1) * nkt) / KS) * KTv);
+    const int n = ke > kb ? cdiv(ke - kb, KTv) : 0;
+    f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+    TileRegsT<false, E::NQ> ta, tb;
+    unsigned* const Ad = As[grp];
+    unsigned* const Bd = Bs[grp];
+    auto stage = [&](int kst, int kld, auto load_tag) __attribute__((always_inline)) {
+        constexpr bool LOAD = decltype(load_tag)::value;
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i) {
+            quad_store<true, false, 3>(Ad, ta, oa, 0, kst, ke, i);
+            if constexpr (LOAD) quad_load<true, false, 3>(ta, oa, 0, kld, ke, i);
+            quad_store<true, false, 3, true>(Bd, tb, ob, 0, kst, ke, i);
+            if constexpr (LOAD) quad_load<true, false, 3>(tb, ob, 0, kld, ke, i);
+        }
+    };
+    if (active && n > 0) {
+        tile_load<true, false, 3>(ta, oa, 0, kb, ke);
+        tile_load<true, false, 3>(tb, ob, 0, kb, ke);
+    }
+    for (int p = 0; p <= 2 * n; ++p) {
+        const int q = p - grp;
+        if (active && q >= 0 && q < 2 * n) {
+            const int k0 = kb + (q >> 1) * KTv;
+            if (q & 1) mfma_ktile<true, true, 3>(acc, Ad, Bd, wm, wn, lane);
+            else if (k0 + KTv < ke) stage(k0, k0 + KTv, VecTag{});
+            else stage(k0, k0, ScalarTag{});
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    float* out = d.out + (int64_t)blockIdx.y * d.out_ks_stride + (int64_t)arm * d.out_arm_stride;
+    const int ncols = d.Nv + d.q_ones, l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 64 * wn + 32 * j + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 64 * wm + 32 * i + acc_row(r, lane);
+                if (row < d.Mv && col < ncols) out[(int64_t)row * d.ldo + col] = acc[i][j][r];
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers (same workspace layouts and split factors as the fp32 fast path)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1461,6 +1547,13 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
             hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW11>");
     }
+    return 0;
+}
+
+int launch_dw_small_x3(const Ctx& c, const TnDescs& ts, int nsel) {
+    const int KS = c.lay.sp.ks_small;
+    hipLaunchKernelGGL(k_x3_small, dim3(cdiv(nsel * c.d.A, 2), KS), dim3(512), 0, c.stream, ts, nsel, c.d.A, c.d.B, KS);
+    HIP_LAUNCH_CHECK("k_x3_small");
     return 0;
 }
 

@@ -368,17 +368,7 @@ __global__ __launch_bounds__(256) void k_fc11_fused(const float* __restrict__ d1
 // Block tile TA x TB (TA*TB = 8192 or 16384), K tile 32 batch rows, 4 waves 2 x 2.
 // grid (tiles_m * tiles_n, KS, A * ndesc).  Operand transforms are selected per descriptor.
 // =============================================================================================
-struct TnDesc {
-    const float* P; int64_t p_arm_stride; int ldp; int Mv;   // rows of out
-    const float* Q; int64_t q_arm_stride; int ldq; int Nv;   // cols of out (before the ones column)
-    int q_ones;            // 1: column Nv of Q is the constant 1 (bias gradient)
-    int q_xmask;           // 1: Q is x, apply dropout keep-mask (scale applied by the reducer)
-    const float* q_mean;   // != null: Q <- (Q - mean[n]) * rstd[n]   (BatchNorm-normalised input)
-    const float* q_rstd;   //          arrays are [A][Nv]
-    float* out; int64_t out_arm_stride; int64_t out_ks_stride; int ldo;   // out[ks][arm][m][n]
-};
-
-struct TnDescs { TnDesc d[N_SMALL]; };
+// (TnDesc / TnDescs: common.hpp)
 
 template <int TA, int TB>
 __global__ __launch_bounds__(256) void k_gemm_tn(const TnDescs descs, int ndesc, NoiseDev nz, int B,
@@ -691,6 +681,11 @@ int launch_dw_small(const Ctx& c, int which) {
         tiles = max(tiles, cdiv(hd[i].Mv, 128) * cdiv(hd[i].Nv + 1, 128));
     }
     if (nsel == 0) return 0;
+    if (split3_gemms(c)) {      // fp32x3 engine: the same products as pairs of 128 x 128 tiles on the bf16 matrix pipe
+        bool fits = true;
+        for (int i = 0; i < nsel; ++i) fits = fits && ts.d[i].Mv <= 128 && ts.d[i].Nv + ts.d[i].q_ones <= 128 && !ts.d[i].q_xmask;
+        if (fits) return launch_dw_small_x3(c, ts, nsel);
+    }
     dim3 grid(tiles, KS, A * nsel);
     hipLaunchKernelGGL((k_gemm_tn<128, 128>), grid, dim3(256), 0, c.stream, ts, nsel, nd, B, KS, 3);
     HIP_LAUNCH_CHECK("k_gemm_tn<small>");
