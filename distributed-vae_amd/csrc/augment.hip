@@ -188,7 +188,12 @@ __global__ void k_aug_pack_affine(const float* __restrict__ bias, const float* _
 // ---------------------------------------------------------------------------------------------
 // packed layout
 // ---------------------------------------------------------------------------------------------
-struct AugLayer { int64_t w, sc, sh; int N, K, ldw; };   // offsets in floats into the packed buffer
+struct AugLayer {         // offsets in floats into the packed buffer
+    int64_t w, sc, sh;
+    int N, K, ldw;
+    int64_t pl;           // the weight's three bf16 slice planes [3][Np][Kp] (fp32x3 engine; gemm_bf16.hip), Np = N padded to
+    int Np, Kp;           // whole 128-row tiles, Kp = ldw padded to whole K tiles of 32
+};
 struct AugPacked {
     AugLayer g[10];          // fc1 fc2 fc3 fc4 fc5[:, :n]  fc7 fc8 fc9 fc10 fc11
     // latent block
@@ -214,6 +219,9 @@ static AugPacked aug_packed_layout(const mmvae_aug_dims& d) {
         g.w = take((int64_t)g.N * g.ldw);
         g.sc = take(g.N);
         g.sh = take(g.N);
+        g.Np = (g.N + 127) / 128 * 128;
+        g.Kp = (g.ldw + 31) / 32 * 32;
+        g.pl = take((int64_t)3 * g.Np * g.Kp / 2);     // bf16: two per float
     }
     p.noise_w = take((int64_t)NZ * NZ); p.z_sc = take(NZ); p.z_sh = take(NZ);
     p.w5b = take((int64_t)N5 * NZ); p.sc5 = take(N5); p.sh5 = take(N5);
@@ -379,7 +387,8 @@ static int aug_gemm(hipStream_t s, int force_tile, bool relu, bool affine, const
     const float* sh = pk + g.sh;
     if (force_tile == 99 || force_tile == 98)   // bf16 operands (mmvae_augment's gemm_bf16 = 1) or fp32 operands split into
         // three bf16 slices (gemm_bf16 = 2): the shared tile engine of gemm_bf16.hip, fp32 epilogue
-        return launch_bf16_affine(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.ldw, sc, sh, C, ldc, ncols, force_tile == 98);
+        return launch_bf16_affine(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.ldw, sc, sh, C, ldc, ncols, force_tile == 98,
+                                  reinterpret_cast<const unsigned short*>(pk + g.pl), g.Np, g.Kp);
     // the largest tile that still leaves two workgroups per CU (256 CUs); MMVAE_AUG_TILE=<BM><BN> code forces one
     const int force = force_tile;   // 11 12 21 22 (1 = 64, 2 = 128), 0 = automatic
     auto count = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(ncols, bn); };
@@ -449,6 +458,9 @@ int mmvae_aug_pack(const mmvae_aug_dims* d, const mmvae_aug_tensors* t, float* p
         const int mi = mod_of_g[i];
         const int src_ld = (mi == 4) ? d->N3 + d->NZ : g.K;
         packw(t->w[mi], src_ld, 0, g.N, g.K, g.w, g.ldw);
+        // slice planes of the packed (zero-padded) weight for the fp32x3 engine
+        if (int rc = launch_presplit_one(s, packed + g.w, g.ldw, g.N, g.ldw, g.Np, g.Kp, reinterpret_cast<unsigned short*>(packed + g.pl)))
+            return rc;
         if (mi == 4) continue;                                  // fc5's affine is applied in the latent kernel
         if (mi == 10) packa(t->b[10], nullptr, nullptr, nullptr, nullptr, 0.f, g.N, g.sc, g.sh);
         else packa(t->b[mi], t->bn_mean[mi], t->bn_var[mi], nullptr, nullptr, eps, g.N, g.sc, g.sh);

@@ -604,7 +604,10 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
 int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);
 int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);
 int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw, int N,
-                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3 = 0);
+                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3 = 0,
+                       const unsigned short* w_planes = nullptr, int Np = 0, int Kp = 0);
+// fp32 [R][C] (row pitch ld) -> three bf16 slice planes [3][Rp][Cp], zero-padded (fp32x3 engine)
+int launch_presplit_one(hipStream_t s, const float* src, int64_t ld, int R, int C, int Rp, int Cp, unsigned short* dst);
 // evaluation labels / consensus (consensus.hip)
 int launch_classify(const float* cc, int64_t n_cells, int C, int32_t* labels, hipStream_t s);
 int launch_confmat(const int32_t* labels, int A, int64_t n, int C, int64_t* counts, hipStream_t s);

@@ -559,14 +559,19 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     if (oa_h.bits) oa_h.bits += (int64_t)arm * g.a_bits_arm;
     if (ob_h.bits) ob_h.bits += (int64_t)arm * g.b_bits_arm;
     const OperandDev oa = make_operand_dev<AMINOR>(oa_h), ob = make_operand_dev<BMINOR>(ob_h);
-    const int tiles_n = cdiv(g.N, BT), ntiles = cdiv(g.M, BT) * tiles_n;
-    int wg = 2 * blockIdx.x + grp;
-    const bool active = wg < ntiles;                 // (an odd tile count leaves the last block's second group idle)
-    if (EPI == 1) {   // XCD-aware tile order: workgroup i runs on XCD i % 8; give XCD x a contiguous range of tiles
-        const int nwg = 2 * gridDim.x;
-        if (nwg == ntiles && nwg % 16 == 0) wg = 2 * ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) + grp;
-    }
-    const int m0 = (wg / tiles_n) * BT, n0 = (wg % tiles_n) * BT;
+    // The two tiles of a block: neighbours along m for the same n tile when they share the B operand (SHARE = 2), along n
+    // for the same m tile when they share A (SHARE = 1), consecutive tiles of the (m, n) list otherwise.  An odd count
+    // leaves the last block's second group idle.  EPI = 1 (the augmenter's layers): XCD-aware block order -- workgroup i
+    // runs on XCD i % 8; give XCD x a contiguous range of blocks (neighbouring n tiles read the same activation rows).
+    const int tiles_m = cdiv(g.M, BT), tiles_n = cdiv(g.N, BT);
+    int bi = blockIdx.x;
+    if (EPI == 1 && (gridDim.x & 7) == 0) bi = (bi & 7) * (gridDim.x >> 3) + (bi >> 3);
+    int tm, tn;
+    if (SHARE == 2) { tn = bi % tiles_n; tm = 2 * (bi / tiles_n) + grp; }
+    else if (SHARE == 1) { tm = bi % tiles_m; tn = 2 * (bi / tiles_m) + grp; }
+    else { const int wg = 2 * bi + grp; tm = wg / tiles_n; tn = wg % tiles_n; }
+    const bool active = tm < tiles_m && tn < tiles_n;
+    const int m0 = tm * BT, n0 = tn * BT;
     const int nkt = cdiv(g.K, KTv);
     const int kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KTv;
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KTv);
@@ -1558,14 +1563,25 @@ int launch_dw_small_x3(const Ctx& c, const TnDescs& ts, int nsel) {
 }
 
 // C[M][ld] = act((A[M][K] . W[N][K]^T) * scale + shift): the augmenter's layers with bf16 operands (augment.hip)
+int launch_presplit_one(hipStream_t s, const float* src, int64_t ld, int R, int C, int Rp, int Cp, unsigned short* dst) {
+    const SplitJob j{src, ld, 0, R, C, Rp, Cp, -1, dst, 0, nullptr, 0};
+    return launch_presplit(s, 1, &j, 1);
+}
+
 int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw, int N,
-                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3) {
+                       int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3,
+                       const unsigned short* w_planes, int Np, int Kp) {
     GemmArgs g{};
     g.a = kmajor(A, lda, M, Kpad);        // rows are zero-padded to Kpad = pad4(K) floats on both sides
     g.b = kmajor(W, ldw, N, Kpad);
     g.M = M; g.N = ncols; g.K = Kpad; g.KS = 1; g.A = 1;
     g.ao = AffineOut{sc, sh, C, ldc, M, N, relu ? 1 : 0, affine ? 1 : 0};
-    if (split3)
+    if (split3 && w_planes && Np >= cdiv(ncols, BT) * BT) {
+        // fp32x3 with the weight's slice planes (written at pack time): the two tiles of a block are m neighbours of one
+        // n tile and share its weight tile, copied from the planes; the activations are split on their way into LDS
+        g.b.pl = w_planes; g.b.pl_plane = (int64_t)Np * Kp; g.b.pl_arm = 0; g.b.pl_ld = Kp;
+        hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 2, true>), dim3(cdiv(cdiv(M, BT), 2) * cdiv(ncols, BT), 1, 1), dim3(512), 0, s, g);
+    } else if (split3)
         hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 0>), dim3(cdiv(cdiv(M, BT) * cdiv(ncols, BT), 2), 1, 1), dim3(512), 0, s, g);
     else
         hipLaunchKernelGGL((k_bf16_gemm<false, false, 1>), dim3(cdiv(M, BT) * cdiv(ncols, BT), 1, 1), dim3(256), 0, s, g);
