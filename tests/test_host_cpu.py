@@ -199,3 +199,36 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True,
                        timeout=300, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode != 0 and "refusing" in r.stderr and r.stdout.strip() == ""
+
+
+def test_gemm_engine_names_map_to_the_abi_values(monkeypatch):
+    """mmvae_hyper.gemm_bf16: 0 fp32 matrix instruction, 1 bf16 operands, 2 fp32x3 (include/mmvae.h); "fp32" is the
+    library's fp32 engine (fp32x3 unless MMVAE_FP32_ENGINE says otherwise); the diagnostic mask rides in bits 8.."""
+    from distributed_vae_amd import _native as N
+    assert N.gemm_mode("fp32_mfma") == 0 and N.gemm_mode("bf16") == 1 and N.gemm_mode("fp32x3") == 2
+    monkeypatch.setattr(N, "FP32_ENGINE", "fp32x3")
+    assert N.gemm_mode("fp32") == 2
+    monkeypatch.setattr(N, "FP32_ENGINE", "fp32_mfma")
+    assert N.gemm_mode("fp32") == 0
+    monkeypatch.setenv("MMVAE_X3_OFF", "5")
+    assert N.gemm_mode("fp32x3") == 2 | (5 << 8) and N.gemm_mode("bf16") == 1
+    with pytest.raises(ValueError):
+        N.gemm_mode("fp16")
+    ex = N.exec_from_env(2)
+    assert ex.tune[N.TUNE_ENGINE] == 2
+
+
+def test_split_factors_follow_the_engine_hint():
+    """mmvae_exec.tune[MMVAE_TUNE_ENGINE] = 2: the layout's split factors are chosen for the fp32x3 engine's one-workgroup-
+    per-CU kernels (A = 2, B = D = 5000: fc1 6, small layers 20, fc11 gene split 3, dW1 6, dW11 3)."""
+    from distributed_vae_amd import _native as N
+    d = N.Dims(2, 5000, 5000, 100, 10, 92, 2)
+    got = {}
+    for eng in (0, 2):
+        ex = N.Exec()
+        ex.tune[N.TUNE_ENGINE] = eng
+        sp = (C.c_int32 * 6)()
+        N.check(N.lib().mmvae_splits(C.byref(d), C.byref(ex), C.byref(sp)), "mmvae_splits")
+        got[eng] = list(sp)
+    assert got[0] == [6, 6, 12, 32, 6, 5], got
+    assert got[2] == [6, 6, 6, 20, 3, 3], got
