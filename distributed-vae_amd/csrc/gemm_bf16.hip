@@ -1179,15 +1179,18 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
                 for (int pl = 0; pl < 3; ++pl) { au[q >> 1][pl][2 * (q & 1)] = w0[pl]; au[q >> 1][pl][2 * (q & 1) + 1] = w1[pl]; }
             }
         };
-        // ---- stage 1
+        // (this piece's x was requested a piece ago: one wait for all of it here, in front of the DMA's assembly -- see below)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(xin[q].x), "+v"(xin[q].y), "+v"(xin[q].z), "+v"(xin[q].w));
+        // ---- stage 1: seven regions of six MFMAs; chunks 0 .. 4 of the epilogue behind them (the other three go behind the
+        // first MFMAs of stage 2, which has no other VALU work: 42 MFMAs + 5 chunks against 48 MFMAs + 3 chunks)
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < 7) z_frags(Wn, s + 2);
             if (s == 5) d_frags(Wt16, 0);           // (the first region of stage 2: its slot of the ring is free)
             mfma6(accn, an[s % 3], s);
-            chunk(s);
-            if (s == 6) chunk(7);
+            if (s < 5) chunk(s);
         }
         asm volatile("" : "+s"(mism));
         // the DMA of a later tile goes here, behind the last use of this piece's x: hipcc does not count the assembly's
@@ -1211,6 +1214,8 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
                 const unsigned* W2 = w_rows(p + 2 < npieces ? p + 2 : p);
                 z_frags(W2, r - 2);
             }
+            if (r == 0) { chunk(5); chunk(6); }       // (gene groups 2 and 3 feed K step 1 = regions 2 and 3)
+            if (r == 1) chunk(7);
             const int c = r >> 1;
             bf16x8 af[3];
 #pragma unroll
