@@ -77,14 +77,20 @@ Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex) {
     s.ks_gd10 = min(s.ks_gd10, max(1, cdiv(d.D, fastdims && d.H == 100 ? 64 : 32)));   // fc_dim 100: also k_fc11_zg's gene split
     // fp32x3 engine (gemm_bf16.hip): its kernels run ONE 512- or 256-thread workgroup per CU -- a pair of 128-row tiles
     // (fc1, dW1, dW11) or 128 cells (the fused fc11 kernel) -- so the splits fill 256 slots, not 512.  dW11 runs beside the
-    // latency-bound backward chain, which needs CUs of its own: half the chip (measured at A = 2: 873 us per step with the
-    // splits above, 836 with these).
+    // latency-bound backward chain, which needs CUs of its own (measured at A = 2: 873 us per step with the splits above,
+    // 836 with these).
     if (ex && ex->tune[MMVAE_TUNE_ENGINE] == 2 && fastdims && d.H + 1 <= 112) {
         const int pairs_b = cdiv(nb128, 2), pairs_d = cdiv(cdiv(d.D, 128), 2);
         if (g_split[0] <= 0) s.ks_fc1 = min(fit(pairs_b * d.A, CUS, 16), max(1, cdiv(d.D, 32)));
         if (g_split[4] <= 0) s.ks_gd10 = min(fit(nb128 * d.A, CUS, 16), max(1, cdiv(d.D, 64)));
         if (g_split[2] <= 0) s.ks_dw = min(fit(pairs_d * d.A, CUS, 16), max(1, cdiv(d.B, 32)));
-        if (g_split[5] <= 0) s.ks_dw11 = min(fit(pairs_d * d.A, CUS / 2, 16), max(1, cdiv(d.B, 32)));
+        // (dW11: at most three eighths of the CUs -- its 120 KB of LDS leave a CU no room for a chain workgroup, and the
+        // backward chain's 79 A workgroups should still find a CU each in ONE round: A = 2, 3 batch splits 768 us, 2: 757)
+        // (workgroup count nearest to 96: measured best at A = 2 (2 splits), A = 3 (2) and A = 5 (1))
+        if (g_split[5] <= 0) {
+            const int nwg = max(1, pairs_d * d.A);
+            s.ks_dw11 = min(max(1, (3 * CUS / 8 + nwg / 2) / nwg), max(1, cdiv(d.B, 32)));
+        }
         if (g_split[3] <= 0) s.ks_small = min(fit(cdiv(N_SMALL * d.A, 2), CUS, 32), max(1, cdiv(d.B, 32)));   // k_x3_small: a pair of products per block
     }
     return s;
