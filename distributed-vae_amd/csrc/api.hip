@@ -93,6 +93,15 @@ Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex) {
         }
         if (g_split[3] <= 0) s.ks_small = min(fit(cdiv(N_SMALL * d.A, 2), CUS, 32), max(1, cdiv(d.B, 32)));   // k_x3_small: a pair of products per block
     }
+    // the bf16 configuration runs its small-layer gradient products on k_x3_small too
+    if (ex && ex->tune[MMVAE_TUNE_ENGINE] == 1 && fastdims && d.H <= 124) {
+        if (g_split[3] <= 0) s.ks_small = min(fit(cdiv(N_SMALL * d.A, 2), CUS, 32), max(1, cdiv(d.B, 32)));
+        // dW11 beside the backward chain: about 160 of its two-per-CU workgroups (A = 2: 5 splits 701 us per step, 3: 688, 2: 680)
+        if (g_split[5] <= 0) {
+            const int nwg = max(1, cdiv(d.D, 128) * d.A);
+            s.ks_dw11 = min(max(1, (5 * CUS / 8 + nwg / 2) / nwg), max(1, cdiv(d.B, 32)));
+        }
+    }
     return s;
 }
 

@@ -681,7 +681,8 @@ int launch_dw_small(const Ctx& c, int which) {
         tiles = max(tiles, cdiv(hd[i].Mv, 128) * cdiv(hd[i].Nv + 1, 128));
     }
     if (nsel == 0) return 0;
-    if (split3_gemms(c)) {      // fp32x3 engine: the same products as pairs of 128 x 128 tiles on the bf16 matrix pipe
+    if (bf16_gemms(c)) {        // fp32x3 engine -- and the bf16 configuration, whose small layers stay fp32-grade: the same
+                                // products as pairs of 128 x 128 tiles of exact slice products on the bf16 matrix pipe
         bool fits = true;
         for (int i = 0; i < nsel; ++i) fits = fits && ts.d[i].Mv <= 128 && ts.d[i].Nv + ts.d[i].q_ones <= 128 && !ts.d[i].q_xmask;
         if (fits) return launch_dw_small_x3(c, ts, nsel);
