@@ -42,6 +42,59 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(long long* out, float* sink, 
     sink[blockIdx.x * blockDim.x + threadIdx.x] = s + sc + lv[0] + lv[1] + lv[2] + lv[3];
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
+// Two waves per SIMD with DIFFERENT roles: waves 0-3 issue MFMAs back to back, waves 4-7 a stream of `KIND` instructions
+// (0: independent v_add_f32, 1: one dependent v_add_f32 chain, 2: v_cvt_pk_bf16_f32 + shift + subtract (the operand split),
+// 3: ds_write_b64).  Reports the cycles per instruction the second group achieves beside the first.
+template <int KIND>
+__global__ __launch_bounds__(512, 1) void k_roles(long long* out, float* sink, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned L[8192];
+    const int grp = threadIdx.x >> 8;
+    f32x16 acc; for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(1.0f + threadIdx.x * 0.001f + e); b[e] = (__bf16)(0.5f + e * 0.25f); }
+    float v[8];
+    for (int e = 0; e < 8; ++e) v[e] = threadIdx.x + e * 0.37f;
+    unsigned w = threadIdx.x;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    if (grp == 0) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    } else {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int m = 0; m < 64; ++m) {
+                if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[m % 8]) : "v"(v[(m + 3) % 8]));
+                else if (KIND == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[0]) : "v"(v[1]));
+                else if (KIND == 2) {
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(v[m % 4]), "v"(v[4 + m % 4]));
+                    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(w) : "v"(w));
+                    asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[m % 4]) : "v"(w));
+                } else {
+                    asm volatile("ds_write_b64 %0, %1" :: "v"((unsigned)((threadIdx.x & 255) * 8 + (m & 7) * 2048)), "v"((unsigned long long)w) : "memory");
+                }
+            }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    for (int e = 0; e < 8; ++e) s += v[e];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = s + w + L[threadIdx.x];
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) out[1 + grp] = t1 - t0;
+}
+template <int KIND>
+void run_roles(const char* name, long long* d_out, float* sink) {
+    const int iters = 200;
+    hipLaunchKernelGGL((k_roles<KIND>), dim3(256), dim3(512), 0, 0, d_out, sink, iters);
+    hipLaunchKernelGGL((k_roles<KIND>), dim3(256), dim3(512), 0, 0, d_out, sink, iters);
+    hipDeviceSynchronize();
+    long long t[3]; hipMemcpy(t, d_out, 24, hipMemcpyDeviceToHost);
+    const int per_iter = KIND == 2 ? 64 * 3 : 64;
+    printf("%-52s MFMA wave: %5.1f ticks/MFMA   other wave: %5.1f ticks/instruction\n", name, (double)t[1] / (iters * 16.0),
+           (double)t[2] / (iters * (double)per_iter));
+}
+
 template <int CHAINS, int VALU, int SALU, int LDSR, int WAVES>
 void run(const char* name, long long* d_out, float* sink) {
     const int iters = 200;
@@ -70,5 +123,9 @@ int main() {
     run<1, 0, 0, 0, 8>("2 waves/SIMD, 1 chain", d_out, sink);
     run<1, 6, 0, 0, 8>("2 waves/SIMD, 1 chain + 6 VALU", d_out, sink);
     run<1, 12, 0, 0, 8>("2 waves/SIMD, 1 chain + 12 VALU", d_out, sink);
+    run_roles<0>("roles: MFMA wave + independent v_add_f32 wave", d_out, sink);
+    run_roles<1>("roles: MFMA wave + dependent v_add_f32 chain", d_out, sink);
+    run_roles<2>("roles: MFMA wave + cvt_pk / shift / sub (split)", d_out, sink);
+    run_roles<3>("roles: MFMA wave + ds_write_b64", d_out, sink);
     return 0;
 }
