@@ -1,5 +1,11 @@
-// bf16-operand variants of the five D x H GEMMs of the train step (BASELINE.json configs[2]: "bf16, DP over 8 GPUs";
-// mmvae_hyper.gemm_bf16 != 0).  Operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way
+// The five D x H GEMMs of the train step on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), in two precisions:
+//
+//   * mmvae_hyper.gemm_bf16 == 1 -- BASELINE.json configs[2] ("bf16, DP over 8 GPUs"): operands ROUNDED to bf16;
+//   * mmvae_hyper.gemm_bf16 == 2 -- "fp32x3", the library's fp32 engine: every fp32 operand split EXACTLY into three bf16
+//     slices, six slice products per product (see Eng<NP> below; k_presplit, k_x3_gemm, k_x3_small, k_x3_fc11g; DESIGN.md
+//     section 14).  It also serves the small-layer gradient products and the augmenter's layers.
+//
+// What follows describes the shared tile engine in its one-plane (bf16) form.  Operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way
 // into LDS, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense: 16 x the fp32 matrix rate), and
 // everything else of the step -- BatchNorm, the softmaxes, KL / coupling terms, the reconstruction-loss epilogue, the
 // slab reduction, Adam, the parameters themselves -- stays fp32 (SURVEY.md section 7 "Numerical range").  With the
