@@ -82,6 +82,7 @@ TUNE_ENV = {
     "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_ABLATE_B": (16, int),
 }
 TUNE_ENGINE = 17    # MMVAE_TUNE_ENGINE: the GEMM engine the caller runs (the layout's split factors are chosen for it)
+TUNE_MID_EVENT = 18  # MMVAE_TUNE_MID_EVENT: record ev[7] behind fc1 (see Engine.mid_event)
 
 
 class Exec(C.Structure):
@@ -266,6 +267,15 @@ class Engine:
 
     def _s(self):
         return _stream(self.device)
+
+    def mid_event(self, on: bool = True):
+        """The event the step records behind its first layer (fc1 + epilogue) once switched on: where it leaves its first
+        throughput-bound kernel and enters the latency-bound encoder chain.  A producer of the next batch on another
+        stream waits for it (``stream.wait_event``) so that its copy runs beside the chain.  None without a side stream."""
+        if self.side is None:
+            return None
+        self.ex.tune[TUNE_MID_EVENT] = 1 if on else 0
+        return self._events[7] if on else None
 
     def _x(self):
         return C.byref(self.ex)

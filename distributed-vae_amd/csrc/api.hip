@@ -279,6 +279,10 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         if ((rc = launch_x3_planes(c, params, 1))) return rc;          // fp32x3: slice planes of W1 and [W11 | b11]
         if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
         if ((rc = launch_fc1_epi(c, params))) return rc;
+        if (c.tune(MMVAE_TUNE_MID_EVENT) && c.side() && hipEventRecord(c.ev(EV_SPARE), c.stream) != hipSuccess) {
+            set_error("event record failed");
+            return MMVAE_E_LAUNCH;
+        }
     } else if ((rc = launch_fc1_fwd(c, nz, params, x, xs))) {
         return rc;
     }

@@ -542,7 +542,7 @@ struct Ctx {
     int tune(int i) const { return ex.tune[i]; }
 };
 // events of mmvae_exec.ev by role
-enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE };
+enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE /* MMVAE_TUNE_MID_EVENT: behind fc1 */ };
 
 #ifdef __HIPCC__
 NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h);

@@ -140,6 +140,11 @@ enum {
     MMVAE_TUNE_ENGINE,             /* not an experiment: the GEMM engine the caller is going to run (mmvae_hyper.gemm_bf16
                                       & 0xFF; 0 = not stated).  The split factors of the workspace layout are chosen for the
                                       workgroup shapes of that engine; any engine runs correctly on any layout */
+    MMVAE_TUNE_MID_EVENT,          /* not an experiment: != 0 and a side stream given -> mmvae_forward / mmvae_train_step record
+                                      ev[7] on the call's stream behind the first layer (fc1 + its epilogue), i.e. where the
+                                      step leaves its first throughput-bound kernel and enters the latency-bound encoder chain.
+                                      A caller that produces the NEXT batch on another stream (row gather, H2D copy) lets that
+                                      stream wait for it, so that the copy runs beside the chain instead of beside fc1 */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {
