@@ -157,6 +157,7 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.fc1_slab = take((int64_t)L.sp.ks_fc1 * A * B * NP);
     L.n11 = (L.nblk64 + 2) * (max(L.sp.ns_fc11, L.sp.ks_gd10) + 1) + cdiv(d.D, 64);
     L.fc11_part = take(A * (int64_t)L.n11 * 2 + 64);   // + diagnostic stamp counters
+    L.acc = take((int64_t)ACC_NSETS * A * ACC_SET_FLOATS);   // directly behind fc11_part: one zero fill at the start of a forward pass
     L.GD10_slab = take((int64_t)max(L.sp.ns_fc11, L.sp.ks_gd10) * A * B * H);
     L.DZ11 = take(A * B * D);
     L.couple_part = take(nb * 2);
@@ -274,8 +275,14 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
                       float* loss_out = nullptr, bool latent_only = false, int32_t* labels = nullptr) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
+    // training: the loss partial slots and the forward accumulator sets start the pass at zero (inside k_make_xbits
+    // when that runs); eval mode has no batch sums and the fc11 launchers zero their slots themselves
+    if (c.h.training) {
+        if ((rc = launch_forward_zero(c, fast, nz))) return rc;
+    } else if (fast && (rc = launch_make_xbits(c, nz))) {
+        return rc;
+    }
     if (fast) {
-        if ((rc = launch_make_xbits(c, nz))) return rc;
         if ((rc = launch_x3_planes(c, params, 1))) return rc;          // fp32x3: slice planes of W1 and [W11 | b11]
         if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
         if ((rc = launch_fc1_epi(c, params))) return rc;

@@ -49,6 +49,9 @@ struct ChainFwdArgs {
     int bn_idx;
     float bn_eps, bn_momentum;
     int64_t stats_part_off;             // [A][gridDim.x][2][N_last] or -1
+    // accumulator sets (common.hpp acc_add; [A] sets each) that replace the two partial arrays: the input's batch sums
+    // to read, the output's to add to; -1 = the partial arrays
+    int64_t acc_in_off, acc_out_off;
     int B, ld, wrows;
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
@@ -147,16 +150,45 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     };
     if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 
+    // ---- requested before anything waits: the first layer's weights and the workgroup's input rows (with the batch sums
+    //      below: one memory round trip in front of the first GEMM instead of three)
+    float4 wq[WQ_N];
+    bool wq_valid = false;
+    {
+        const FwdLayer L0 = a.L[0];
+        wq_valid = w_split_ok(P + L0.w_off, L0.K, rup(L0.N, 32), rup(L0.K, 8));
+        if (wq_valid) w_load(wq, P + L0.w_off, L0.N, L0.K);
+    }
+    const float* X = ws + a.x_off + (int64_t)arm * B * a.K0;
+    const int xc4n = rup(a.K0, 8) >> 2;
+    const bool x_early = (a.K0 & 3) == 0 && xc4n <= 32;   // one pass of 16-byte loads covers the tile
+    float4 xq[4];
+    if (x_early) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xq[j] = ldg4_t<true>(X, a.K0, b0 + (tid >> 3), ((tid & 7) + 8 * j) * 4, B, a.K0);
+    }
     // ---- statistics of the input's BatchNorm: recombined from the producer's partials (training) or
     //      the running buffers' values left in the workspace (eval); zero beyond K0
     if (a.bn_mean_off >= 0) {
         const int K0 = a.K0;
         float mean = 0.f, rstd = 0.f;
         if (a.bn_part_off >= 0) {
-            float m2;
+            float m2 = 0.f;
             unsigned long long st[5] = {0, 0, 0, 0, 0};
-            stats_from_partials<CH_NT>(ws + a.bn_part_off + (int64_t)arm * a.part_n * 2 * K0, a.part_n, B, a.part_rows, K0,
-                                       Ws, mean, m2, stamps ? st : nullptr);
+            if (a.acc_in_off >= 0) {
+                if (stamps) { st[0] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+                if (tid < K0)
+                    acc_mean_m2(reinterpret_cast<const long long*>(ws + a.acc_in_off) + (int64_t)arm * ACC_SET_I64, tid, B, mean, m2);
+                if (stamps) {
+                    asm volatile("" :: "v"(mean), "v"(m2));
+                    st[1] = st[2] = st[3] = st[0];
+                    st[4] = __builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_s_waitcnt(0xC07F);
+                }
+            } else {
+                stats_from_partials<CH_NT>(ws + a.bn_part_off + (int64_t)arm * a.part_n * 2 * K0, a.part_n, B, a.part_rows, K0,
+                                           Ws, mean, m2, stamps ? st : nullptr);
+            }
             if (stamps && lane == 0) {
                 unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);
                 for (int i = 0; i < 4; ++i) atomicAdd(dbg + 8 + i, st[i + 1] - st[i]);
@@ -182,9 +214,8 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     }
     // ---- input tile (optionally BatchNorm-normalised), zero padded to a multiple of 8 columns
     {
-        const float* X = ws + a.x_off + (int64_t)arm * B * a.K0;
         const bool bn = a.bn_mean_off >= 0;
-        const int c4n = rup(a.K0, 8) >> 2;
+        const int c4n = xc4n;
         const bool vec = (a.K0 & 3) == 0;    // workspace regions are 256-B aligned, widths multiples of 4
         const int part = tid & 7, row = tid >> 3;      // 128 rows x 8 sixteen-byte parts
         auto stage_x = [&](auto tag) __attribute__((always_inline)) {
@@ -192,7 +223,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
             for (int cb = 0; cb < c4n; cb += 32) {
                 float4 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ldg4_t<V>(X, a.K0, b0 + row, (cb + part + 8 * j) * 4, B, a.K0);
+                for (int j = 0; j < 4; ++j) v[j] = (V && x_early) ? xq[j] : ldg4_t<V>(X, a.K0, b0 + row, (cb + part + 8 * j) * 4, B, a.K0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = cb + part + 8 * j;
@@ -215,8 +246,6 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         else stage_x(ScalarTag{});
     }
     stamp(0);
-    float4 wq[WQ_N];
-    bool wq_valid = false;
     for (int l = 0; l < a.nlayers; ++l) {
         const FwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
@@ -295,9 +324,13 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
                         n = nn;
                     }
                 }
-                float* p = ws + a.stats_part_off + (((int64_t)arm * gridDim.x + blk) * 2) * N;
-                p[col] = mu;
-                p[N + col] = M2;
+                if (a.acc_out_off >= 0) {
+                    acc_add_stats(reinterpret_cast<long long*>(ws + a.acc_out_off) + (int64_t)arm * ACC_SET_I64, col, n, mu, M2);
+                } else {
+                    float* p = ws + a.stats_part_off + (((int64_t)arm * gridDim.x + blk) * 2) * N;
+                    p[col] = mu;
+                    p[N + col] = M2;
+                }
             }
         }
         stamp(4);
@@ -330,6 +363,10 @@ struct ChainBwdArgs {
     int64_t gout_off;       // [A,B,Klast]
     int64_t part_off;       // [A][gridDim.x][2][Klast] or -1: sums of gout and gout*xhat_prev
     int64_t rprev_off, rprev_mean_off, rprev_rstd_off;   // the BN input that produced the chain input
+    // accumulator sets that replace bnb_part (read) and part (added to); -1 = the partial arrays.  zero_off / zero_n4:
+    // float4s this launch zeroes first (the first launch of a backward pass: all backward accumulator sets)
+    int64_t acc_in_off, acc_out_off, zero_off;
+    int zero_n4;
     int B, ld, wrows;
     int64_t per_arm;
 };
@@ -347,7 +384,17 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
     const int nvalid = min(CHAIN_ROWS, B - b0);
     const float* P = params + (int64_t)arm * a.per_arm;
 
-    if (a.bnb_part_off >= 0) {
+    if (a.zero_n4 > 0) grid_zero(ws + a.zero_off, a.zero_n4);
+    if (a.bnb_part_off >= 0 && a.acc_in_off >= 0) {
+        const int N = a.L[0].N;
+        if (tid < 128) {
+            double s1 = 0.0, s2 = 0.0;
+            if (tid < N) acc_get(reinterpret_cast<const long long*>(ws + a.acc_in_off) + (int64_t)arm * ACC_SET_I64, tid, s1, s2);
+            sums_s[tid] = (float)s1;
+            sums_s[128 + tid] = (float)s2;
+        }
+        lds_barrier();
+    } else if (a.bnb_part_off >= 0) {
         const int N = a.L[0].N;
         const float r = sums_from_partials<CH_NT>(ws + a.bnb_part_off + (int64_t)arm * a.bnb_n * 2 * N, a.bnb_n, 2 * N,
                                                   reinterpret_cast<double*>(Ws));
@@ -539,38 +586,78 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < CH_RT; ++k) { t1 += Ws[(k * 2 + 0) * 256 + tid]; t2 += Ws[(k * 2 + 1) * 256 + tid]; }
-                float* p = ws + a.part_off + (((int64_t)arm * gridDim.x + blk) * 2) * K;
-                p[tid] = t1;
-                p[K + tid] = t2;
+                if (a.acc_out_off >= 0) {
+                    acc_add_sums(reinterpret_cast<long long*>(ws + a.acc_out_off) + (int64_t)arm * ACC_SET_I64, tid, t1, t2);
+                } else {
+                    float* p = ws + a.part_off + (((int64_t)arm * gridDim.x + blk) * 2) * K;
+                    p[tid] = t1;
+                    p[K + tid] = t2;
+                }
             }
         }
         lds_barrier();
     }
 }
 
-// DZ1 = BNbackward(G1) .* relu'(R1).  grid (ceil(B/32), A): every row block recombines the batch sums
-// (part: [A][npart][2][W] from fc2's backward) and applies them to its 32 rows.
+// DZ1 = BNbackward(G1) .* relu'(R1).  grid (ceil(B/32), A): every row block reads the batch sums (accumulator set, or
+// part: [A][npart][2][W] from fc2's backward, recombined here) and applies them to its 32 rows.
+// planes != null (fp32x3 engine, W even): the kernel also writes the three bf16 slice planes of dZ1 that the dW1 GEMM
+// stages ([A][3][Rp][128], zero outside [B][W]; grid ceil(Rp/32) row blocks) -- a k_presplit launch less per step.
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ R,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      const float* __restrict__ part, int npart, float* __restrict__ DZ,
-                                                      int B, int W) {
+                                                      const float* __restrict__ part, int npart,
+                                                      const long long* __restrict__ acc, float* __restrict__ DZ,
+                                                      int B, int W, unsigned short* __restrict__ planes, int Rp) {
     __shared__ __attribute__((aligned(16))) double scratch[1024];
     __shared__ float sums_s[2][128], mu_s[128], rs_s[128];
     const int arm = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
-    const float r = sums_from_partials<256>(part + (int64_t)arm * npart * 2 * W, npart, 2 * W, scratch);
-    if (tid < 2 * W) sums_s[tid < W ? 0 : 1][tid < W ? tid : tid - W] = r;
+    if (acc) {
+        if (tid < W) {
+            double s1, s2;
+            acc_get(acc + (int64_t)arm * ACC_SET_I64, tid, s1, s2);
+            sums_s[0][tid] = (float)s1;
+            sums_s[1][tid] = (float)s2;
+        }
+    } else {
+        const float r = sums_from_partials<256>(part + (int64_t)arm * npart * 2 * W, npart, 2 * W, scratch);
+        if (tid < 2 * W) sums_s[tid < W ? 0 : 1][tid < W ? tid : tid - W] = r;
+    }
     if (tid < W) { mu_s[tid] = mean[arm * W + tid]; rs_s[tid] = rstd[arm * W + tid]; }
     lds_barrier();
     const float invB = 1.f / (float)B;
-    const int nvalid = min(32, B - blk * 32);
+    const int nvalid = max(0, min(32, B - blk * 32));
     const int64_t base = ((int64_t)arm * B + (int64_t)blk * 32) * W;
-    for (int i = tid; i < nvalid * W; i += 256) {
-        const int col = i % W;
-        const float rv = R[base + i];
+    auto dz_of = [&](float gv, float rv, int col) {
         const float rs = rs_s[col];
         const float xh = (rv - mu_s[col]) * rs;
-        const float g = rs * (G[base + i] - sums_s[0][col] * invB - xh * (sums_s[1][col] * invB));
-        DZ[base + i] = rv > 0.f ? g : 0.f;
+        const float g = rs * (gv - sums_s[0][col] * invB - xh * (sums_s[1][col] * invB));
+        return rv > 0.f ? g : 0.f;
+    };
+    if (!planes) {
+        for (int i = tid; i < nvalid * W; i += 256) DZ[base + i] = dz_of(G[base + i], R[base + i], i % W);
+        return;
+    }
+    const int64_t plane = (int64_t)Rp * 128;
+    unsigned short* pl = planes + (int64_t)arm * 3 * plane;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {               // 32 rows x 64 column pairs
+        const int i = tid + 256 * it, r = i >> 6, c = (i & 63) * 2, row = blk * 32 + r;
+        const bool ok = r < nvalid && c < W;
+        const int64_t o = base + (int64_t)(ok ? r : 0) * W + (ok ? c : 0);
+        float2 d = make_float2(0.f, 0.f);
+        if (nvalid > 0) {
+            const float2 gv = *reinterpret_cast<const float2*>(G + o), rv = *reinterpret_cast<const float2*>(R + o);
+            if (ok) {
+                d = make_float2(dz_of(gv.x, rv.x, c), dz_of(gv.y, rv.y, c + 1));
+                *reinterpret_cast<float2*>(DZ + o) = d;
+            }
+        }
+        if (row < Rp) {
+            unsigned w[3];
+            split3(d.x, d.y, w);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(pl + p * plane + (int64_t)row * 128 + c) = w[p];
+        }
     }
 }
 
@@ -614,6 +701,9 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     a.bn_eps = c.h.eps;
     a.bn_momentum = c.h.bn_momentum;
     a.stats_part_off = L.bn_part[i];
+    const bool acc = c.h.training && c.use_acc();
+    a.acc_in_off = acc ? acc_set_off(L, d.A, i - 1) : -1;
+    a.acc_out_off = acc ? acc_set_off(L, d.A, i) : -1;
     a.B = d.B;
     a.ld = fwd_ld(max(d.H, N));
     a.wrows = max(rup(N, 32), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch (statistics prologue / epilogue)
@@ -645,6 +735,7 @@ int launch_chain_fwd_enc_eval(const Ctx& c, const float* params) {
     a.bn_rstd_off = L.bn_rstd[0];
     a.bn_part_off = -1;
     a.stats_part_off = -1;
+    a.acc_in_off = a.acc_out_off = -1;
     a.bn_eps = c.h.eps;
     a.B = d.B;
     a.ld = fwd_ld(max(d.H, d.L));
@@ -672,6 +763,7 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.K0 = d.C + d.S;
     a.bn_mean_off = a.bn_rstd_off = a.bn_part_off = -1;
     a.stats_part_off = -1;
+    a.acc_in_off = a.acc_out_off = -1;
     a.B = d.B;
     a.ld = fwd_ld(max(max(d.H, d.L), d.C + d.S));
     a.wrows = rup(max(d.H, d.L), 32);
@@ -702,6 +794,11 @@ int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {
     a.gout_off = L.GZIN;
     a.part_off = -1;
     a.rprev_off = a.rprev_mean_off = a.rprev_rstd_off = -1;
+    a.acc_in_off = a.acc_out_off = -1;
+    // the first launch of every backward pass: it zeroes the backward accumulator sets (the latent backward behind it is
+    // their first producer)
+    a.zero_off = acc_set_off(L, d.A, 5);
+    a.zero_n4 = c.use_acc() ? (int)(c.bwd_zero_floats() / 4) : 0;
     a.B = d.B;
     a.ld = bwd_ld(max(max(d.H, d.L), d.C + d.S));
     a.wrows = max(rup(max(d.H, d.L), 8), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch of the epilogue's sums
@@ -734,6 +831,10 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.rprev_off = L.R[i - 1];
     a.rprev_mean_off = L.bn_mean[i - 1];
     a.rprev_rstd_off = L.bn_rstd[i - 1];
+    a.acc_in_off = c.use_acc() ? acc_set_off(L, d.A, 5 + layer - 1) : -1;
+    a.acc_out_off = c.use_acc() ? acc_set_off(L, d.A, 5 + layer - 2) : -1;
+    a.zero_off = 0;
+    a.zero_n4 = 0;
     a.B = d.B;
     a.ld = bwd_ld(max(d.H, N));
     a.wrows = max(rup(N, 8), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch (batch-sum prologue / epilogue)
@@ -747,8 +848,13 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
 int launch_bn_bwd_apply1(const Ctx& c) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(L.nblk32, d.A), dim3(256), 0, c.stream, c.ws + L.G[1], c.ws + L.R[0],
-                       c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_part[1], L.nblkc, c.ws + L.DZ[1], d.B, d.H);
+    // fp32x3 engine: this launch also writes the slice planes of dZ1 (launch_x3_planes(.., 4) then has nothing to do)
+    const bool planes = bn_apply_writes_planes(c);
+    const int Rp = rup(d.B, 256);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(planes ? Rp / 32 : L.nblk32, d.A), dim3(256), 0, c.stream, c.ws + L.G[1],
+                       c.ws + L.R[0], c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_part[1], L.nblkc,
+                       c.use_acc() ? reinterpret_cast<const long long*>(c.ws + acc_set_off(L, d.A, 5)) : nullptr,
+                       c.ws + L.DZ[1], d.B, d.H, planes ? reinterpret_cast<unsigned short*>(c.ws + L.pl_dz1) : nullptr, Rp);
     HIP_LAUNCH_CHECK("k_bn_bwd_apply");
     return 0;
 }

@@ -70,9 +70,20 @@ struct Layout {
     int64_t pl_w11;                // [W11 | b11]  [D -> rup 128][H + 1 -> 128]
     int64_t pl_dz1;                // dZ1  [B -> rup 256][H -> 128]
     int64_t pl_d10;                // [d10 | 1]  [B -> rup 256][H + 1 -> 128]
+    // exact batch sums (fixed-point accumulators, see acc_add below): [ACC_NSETS][A] sets of ACC_SET_FLOATS floats;
+    // set k < 5: (sum, sum of squares) of BatchNorm k's input, set 5 + (l - 1): (sum G, sum G * xhat) of layer l's
+    // BatchNorm backward, l = 1..5.  Sets 0..4 are zeroed by the first kernel of a forward pass, 5..9 by the first
+    // kernel of a backward pass.
+    int64_t acc;
     int64_t loss_scratch;          // small
     int64_t total;
 };
+// accumulator set geometry (device side below)
+constexpr int ACC_W = 128;                             // columns per set
+constexpr int ACC_SET_I64 = 6 * ACC_W + 8;             // [6][ACC_W] slots + tail block, [0]: addends outside the window (-> NaN)
+constexpr int ACC_SET_FLOATS = 2 * ACC_SET_I64;
+constexpr int ACC_NSETS = 10;
+inline int64_t acc_set_off(const Layout& L, int A, int set) { return L.acc + (int64_t)set * A * ACC_SET_FLOATS; }
 
 Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex);
 Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex);
@@ -279,7 +290,10 @@ __device__ __forceinline__ int wave_min_i(int v) {
 constexpr int PART_MAXG = 16;
 constexpr int PART_BATCH = 16;
 // rows per workgroup of the small-layer chain kernels (chain.hip) = rows per statistics partial they emit
-constexpr int CHAIN_ROWS = 64;
+#ifndef MMVAE_CHAIN_ROWS
+#define MMVAE_CHAIN_ROWS 64
+#endif
+constexpr int CHAIN_ROWS = MMVAE_CHAIN_ROWS;
 // cells per workgroup of the latent-block kernels (16 waves, one cell per wave at a time).  These kernels are
 // VALU-bound, so what counts is cells per CU: 48 gives 105 workgroups per arm at B = 5000 -- one per CU, three cells
 // per wave -- where 32 gave 314 workgroups on 256 CUs, i.e. 58 CUs with two (four cells per wave slot).
@@ -435,6 +449,94 @@ __device__ __forceinline__ float sums_from_partials(const float* __restrict__ pa
     return sums_from_partials_t<false, NT>(part, nblk, n, scratch);
 }
 
+// ---- fp32x3 engine (gemm_bf16.hip): the three bf16 slices of two fp32 values (low half: a, high half: b) ------------
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // one v_cvt_pk_bf16_f32 (low half: a), round to nearest even
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split3(float a, float b, unsigned (&w)[3]) {
+    // eleven VALU instructions per pair: 3 conversions, 4 half -> float, 4 exact subtractions
+    w[0] = cvt_pk_bf16(a, b);
+    a -= __uint_as_float(w[0] << 16);
+    b -= __uint_as_float(w[0] & 0xFFFF0000u);
+    w[1] = cvt_pk_bf16(a, b);
+    a -= __uint_as_float(w[1] << 16);
+    b -= __uint_as_float(w[1] & 0xFFFF0000u);
+    w[2] = cvt_pk_bf16(a, b);
+}
+
+// ---- exact batch sums through fixed-point atomic accumulators ----------------------------------
+// The alternative to the partial arrays above (production; MMVAE_TUNE_BN_PARTIALS switches back): a producing
+// workgroup ADDS its block sums to one accumulator per column instead of storing them, so a consumer reads W numbers
+// instead of W x (number of producing workgroups).  Floating-point atomics would make the result depend on the arrival
+// order; these are integer adds, which commute: a block sum v (a double) is written as the 142-bit fixed-point number
+// round-toward-zero(|v| * 2^84) = h * 2^80 + m * 2^40 + l (0 <= m, l < 2^40, h < 2^62), the three pieces get the sign of v
+// and are added to three 64-bit slots with device-scope no-return atomics (2^23 addends of either sign fit without a
+// carry between the slots).  Window: |v| and the batch sum below 2^58 = 2.9e17 -- squares of activations up to 7e6 at
+// B = 5000 --, resolution 2^-84 = 5e-26: the variance of a nearly dead unit (BatchNorm eps 1e-8 and below) and gradient
+// sums of 1e-20 are still resolved.  A value outside the window (or NaN / Inf) counts in the set's flag word and every
+// consumer then returns NaN, as the reference's arithmetic would.  The result is the exact sum of the block sums --
+// bit-identical from run to run and for every consumer -- and the consumers form mean and variance from it in fp64.
+// Layout of a set: [6][ACC_W] slots (sum 1 high / middle / low, sum 2 high / middle / low; column-minor, so that the lanes
+// of one atomic instruction -- one column each -- fall into as few cache lines as possible: the L2 retires an atomic
+// request per line, and with one slot per line the same adds took 6 us per launch instead of 1), then the flag word.
+__device__ __forceinline__ void acc_add(long long* __restrict__ set, int sum, int col, double v) {
+    const double a = fabs(v);
+    if (!(a < 0x1p58)) {
+        __hip_atomic_fetch_add(set + 6 * ACC_W, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const double t = a * 0x1p84;
+    const double h = floor(t * 0x1p-80);
+    const double r = t - h * 0x1p80;             // exact: the low bits of t
+    const double m = floor(r * 0x1p-40);
+    const double l = floor(r - m * 0x1p40);
+    long long ih = (long long)h, im = (long long)m, il = (long long)l;
+    if (v < 0.0) { ih = -ih; im = -im; il = -il; }
+    long long* p = set + (3 * sum) * ACC_W + col;
+    if (ih) __hip_atomic_fetch_add(p, ih, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (im) __hip_atomic_fetch_add(p + ACC_W, im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (il) __hip_atomic_fetch_add(p + 2 * ACC_W, il, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// column `col` of a set: both sums (NaN when the set's flag word is non-zero)
+__device__ __forceinline__ void acc_get(const long long* __restrict__ set, int col, double& s1, double& s2) {
+    long long q[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q[k] = set[k * ACC_W + col];
+    const long long bad = set[6 * ACC_W];
+    s1 = ((double)q[0] * 0x1p80 + (double)q[1] * 0x1p40 + (double)q[2]) * 0x1p-84;
+    s2 = ((double)q[3] * 0x1p80 + (double)q[4] * 0x1p40 + (double)q[5]) * 0x1p-84;
+    if (bad) { s1 = __builtin_nan(""); s2 = s1; }
+}
+// (sum, sum of squares) over B rows -> (mean, M2) as stats_from_partials returns them
+__device__ __forceinline__ void acc_mean_m2(const long long* __restrict__ set, int col, int B, float& mean, float& m2) {
+    double s1, s2;
+    acc_get(set, col, s1, s2);
+    const double mu = s1 / (double)B;
+    mean = (float)mu;
+    m2 = (float)fmax(s2 - s1 * mu, 0.0);
+    if (s1 != s1) m2 = mean;
+}
+// a block's (mean, M2) over nb rows -> its contribution to (sum, sum of squares)
+__device__ __forceinline__ void acc_add_stats(long long* __restrict__ set, int col, float nb, float mean, float m2) {
+    const double n = (double)nb, mu = (double)mean;
+    acc_add(set, 0, col, n * mu);
+    acc_add(set, 1, col, (double)m2 + n * mu * mu);
+}
+__device__ __forceinline__ void acc_add_sums(long long* __restrict__ set, int col, float s1, float s2) {
+    acc_add(set, 0, col, (double)s1);
+    acc_add(set, 1, col, (double)s2);
+}
+// zero n4 float4 of p, spread over the whole grid (first kernel of a pass: the accumulator sets it is going to fill)
+__device__ __forceinline__ void grid_zero(float* __restrict__ p, int n4) {
+    const int nt = blockDim.x * blockDim.y * blockDim.z;
+    const int64_t nblk = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+    const int64_t blk = blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+    for (int64_t i = blk * nt + threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); i < n4; i += nblk * nt)
+        reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ---- Philox4x32-10 -----------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
 
@@ -540,6 +642,13 @@ struct Ctx {
     hipStream_t side() const { return reinterpret_cast<hipStream_t>(ex.side_stream); }
     hipEvent_t ev(int i) const { return reinterpret_cast<hipEvent_t>(ex.ev[i]); }
     int tune(int i) const { return ex.tune[i]; }
+    // training-mode batch sums through the fixed-point accumulators (production) or the per-workgroup partial arrays
+    bool use_acc() const { return !ex.tune[MMVAE_TUNE_BN_PARTIALS]; }
+    // set by the launcher that zeroed [fc11_part, end of the forward accumulator sets) at the start of this call's forward
+    // pass; launchers that find it unset (a stage replayed on its own) zero what they need themselves
+    mutable bool fwd_zeroed = false;
+    int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, 5) - lay.fc11_part; }
+    int64_t bwd_zero_floats() const { return (int64_t)5 * d.A * ACC_SET_FLOATS; }
 };
 // events of mmvae_exec.ev by role
 enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE /* MMVAE_TUNE_MID_EVENT: behind fc1 */ };
@@ -587,6 +696,9 @@ int launch_adam(int64_t n, float* p, const float* g, float* m, float* v, int64_t
                 float b2, float eps, float wd, int decoupled, hipStream_t s);
 bool fast_path_ok(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_make_xbits(const Ctx& c, const mmvae_noise* nz);
+// first thing of a forward pass: zero the loss partial slots and the forward accumulator sets (folded into
+// k_make_xbits when that runs, a fill otherwise)
+int launch_forward_zero(const Ctx& c, bool with_xbits, const mmvae_noise* nz);
 int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc1_epi(const Ctx& c, const float* params);
 int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad,
@@ -600,6 +712,8 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit
 inline bool split3_gemms(const Ctx& c, int op = 0) { return (c.h.gemm_bf16 & 0xFF) == 2 && c.d.H <= 124 && !((c.h.gemm_bf16 >> 8) & op); }
 inline bool bf16_gemms(const Ctx& c, int op = 0) { return ((c.h.gemm_bf16 & 0xFF) == 1 || split3_gemms(c, op)) && c.d.H <= 124; }
 int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11], bit1 [d10|1], bit2 dZ1*/);
+// the kernels that produce dZ1 / d10 write their slice planes themselves (no k_presplit launch for them)
+inline bool bn_apply_writes_planes(const Ctx& c) { return split3_gemms(c, 4) && (c.d.H & 1) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);
 int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);

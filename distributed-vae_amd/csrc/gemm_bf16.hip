@@ -86,22 +86,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     v[1] = (__bf16)b;
     return __builtin_bit_cast(unsigned, v);
 }
-// the three bf16 slices of two fp32 values (low half: a, high half: b)
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // one v_cvt_pk_bf16_f32 (low half: a), round to nearest even
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ void split3(float a, float b, unsigned (&w)[3]) {
-    // eleven VALU instructions per pair: 3 conversions, 4 half -> float, 4 exact subtractions
-    w[0] = cvt_pk_bf16(a, b);
-    a -= __uint_as_float(w[0] << 16);
-    b -= __uint_as_float(w[0] & 0xFFFF0000u);
-    w[1] = cvt_pk_bf16(a, b);
-    a -= __uint_as_float(w[1] << 16);
-    b -= __uint_as_float(w[1] & 0xFFFF0000u);
-    w[2] = cvt_pk_bf16(a, b);
-}
+// (cvt_pk_bf16 and split3 -- the three bf16 slices of two fp32 values -- live in common.hpp: the chain kernels write
+// slice planes too)
 
 struct Operand {
     const float* ptr;        // this arm's matrix
@@ -1431,7 +1417,7 @@ int launch_x3_planes(const Ctx& c, const float* params, int which) {
         jobs[n++] = plane_job(c, PL_W11, params + c.po.o[26], d.H, c.po.per_arm, params + c.po.o[27], c.po.per_arm);   // bias: column fc_dim
     }
     if (which & 2) jobs[n++] = plane_job(c, PL_D10, c.ws + c.lay.Dk[4], d.H, (int64_t)d.B * d.H);
-    if (which & 4) jobs[n++] = plane_job(c, PL_DZ1, c.ws + c.lay.DZ[1], d.H, (int64_t)d.B * d.H);
+    if ((which & 4) && !bn_apply_writes_planes(c)) jobs[n++] = plane_job(c, PL_DZ1, c.ws + c.lay.DZ[1], d.H, (int64_t)d.B * d.H);
     return n ? launch_presplit(c.stream, d.A, jobs, n) : 0;
 }
 
@@ -1484,7 +1470,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         return 0;
     }
     if (which & 1) {
-        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        hipError_t e = c.fwd_zeroed ? hipSuccess : hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
         if ((int64_t)cdiv(d.B, BT) * NS > L.n11) { set_error("fc11 bf16: loss partial slots"); return MMVAE_E_LAUNCH; }
         GemmArgs g{};

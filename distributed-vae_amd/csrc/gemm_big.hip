@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void k_fc1_fwd(const float* __restrict__ x, in
 // (t >> 5) + 8 i, i < 4.  All KS x 4 slab loads of a thread are independent float4 loads.
 __global__ __launch_bounds__(256) void k_fc1_epi(const float* __restrict__ slab, const float* __restrict__ params,
                                                  int64_t per_arm, int64_t b_off, float scale,
-                                                 float* __restrict__ R1, float* __restrict__ part, int A, int B,
-                                                 int H, int KS) {
+                                                 float* __restrict__ R1, float* __restrict__ part,
+                                                 long long* __restrict__ acc, int A, int B, int H, int KS) {
     __shared__ float sh[8][NP];
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * 32;
     const int c4 = threadIdx.x & 31, rg = threadIdx.x >> 5;
@@ -250,11 +250,23 @@ __global__ __launch_bounds__(256) void k_fc1_epi(const float* __restrict__ slab,
             const float4 u = *reinterpret_cast<const float4*>(&sh[g][c4 * 4]);
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        float* p = part + (((int64_t)arm * gridDim.x + blk) * 2) * H;
-        const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, tt[4] = {t.x, t.y, t.z, t.w};
+        if (acc) {
+            // one column per lane for the atomic adds below (consecutive lanes -> consecutive slots: few cache lines per
+            // instruction); this half wave has read sh[0..7] above, its LDS accesses stay in program order
+            *reinterpret_cast<float4*>(&sh[0][c4 * 4]) = mean;
+            *reinterpret_cast<float4*>(&sh[1][c4 * 4]) = t;
+        } else {
+            float* p = part + (((int64_t)arm * gridDim.x + blk) * 2) * H;
+            const float mm[4] = {mean.x, mean.y, mean.z, mean.w}, tt[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c4 * 4 + j < H) { p[c4 * 4 + j] = mm[j]; p[H + c4 * 4 + j] = tt[j]; }
+            for (int j = 0; j < 4; ++j)
+                if (c4 * 4 + j < H) { p[c4 * 4 + j] = mm[j]; p[H + c4 * 4 + j] = tt[j]; }
+        }
+    }
+    if (acc) {
+        __syncthreads();
+        if ((int)threadIdx.x < H)
+            acc_add_stats(acc + (int64_t)arm * ACC_SET_I64, threadIdx.x, (float)nvalid, sh[0][threadIdx.x], sh[1][threadIdx.x]);
     }
 }
 
@@ -590,8 +602,9 @@ int launch_fc1_epi(const Ctx& c, const float* params) {
     const int KS = c.lay.sp.ks_fc1;
     const float scale = (c.h.training && c.h.x_drop > 0.f) ? 1.f / (1.f - c.h.x_drop) : 1.f;
     hipLaunchKernelGGL(k_fc1_epi, dim3(c.lay.nblk32, d.A), dim3(256), 0, c.stream, c.ws + c.lay.fc1_slab, params,
-                       c.po.per_arm, c.po.o[1], scale, c.ws + c.lay.R[0], c.ws + c.lay.bn_part[0], d.A, d.B, d.H,
-                       KS);
+                       c.po.per_arm, c.po.o[1], scale, c.ws + c.lay.R[0], c.ws + c.lay.bn_part[0],
+                       c.h.training && c.use_acc() ? reinterpret_cast<long long*>(c.ws + acc_set_off(c.lay, d.A, 0)) : nullptr,
+                       d.A, d.B, d.H, KS);
     HIP_LAUNCH_CHECK("k_fc1_epi");
     return 0;
 }
@@ -604,7 +617,7 @@ int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t
     const float coef = am1 / (float)d.B;
     const int NS = c.lay.sp.ns_fc11;
     dim3 grid(c.lay.nblk64, NS, d.A);
-    hipError_t e = hipMemsetAsync(c.ws + c.lay.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * c.lay.n11, c.stream);
+    hipError_t e = c.fwd_zeroed ? hipSuccess : hipMemsetAsync(c.ws + c.lay.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * c.lay.n11, c.stream);
     if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
     hipLaunchKernelGGL(k_fc11_fused, grid, dim3(256), shm, c.stream, c.ws + c.lay.Dk[4], params, c.po.per_arm,
                        c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + c.lay.DZ11, c.ws + c.lay.GD10_slab,

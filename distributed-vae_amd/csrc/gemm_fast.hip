@@ -36,7 +36,9 @@ __device__ __forceinline__ float4 mask4(float4 v, uint32_t nib) {
 // random-bits mapping as the general kernels and mmvae_dump_noise (xmask_keep).  One thread per Philox call when a
 // call covers whole words (m <= 4 bits per element: 4 / m words), else one thread per word (m / 4 calls).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_make_xbits(NoiseDev nz, int A, int B, int D, int wpr, uint32_t* __restrict__ bits) {
+__global__ void k_make_xbits(NoiseDev nz, int A, int B, int D, int wpr, uint32_t* __restrict__ bits,
+                             float* __restrict__ zero_p, int zero_n4) {
+    grid_zero(zero_p, zero_n4);   // the step's loss partial slots and forward accumulator sets (launch_forward_zero)
     const uint32_t mlog2 = nz.x_mlog2, m = 1u << mlog2;
     const int wpt = nz.mode != 0 && m <= 4 ? (int)(4u >> mlog2) : 1;      // words per thread
     const int tpr = (wpr + wpt - 1) / wpt;                // threads per row
@@ -1391,6 +1393,17 @@ bool fc11_split_path(const Ctx& c, const float* params, const float* x, int64_t 
     return fast_path_ok(c, params, x, xs);
 }
 
+int launch_forward_zero(const Ctx& c, bool with_xbits, const mmvae_noise* nz) {
+    if (with_xbits && c.h.training && c.h.x_drop > 0.f) {
+        c.fwd_zeroed = true;   // k_make_xbits does it
+        return launch_make_xbits(c, nz);
+    }
+    hipError_t e = hipMemsetAsync(c.ws + c.lay.fc11_part, 0, sizeof(float) * (size_t)c.fwd_zero_floats(), c.stream);
+    if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
+    c.fwd_zeroed = true;
+    return 0;
+}
+
 int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
     if (!(c.h.training && c.h.x_drop > 0.f)) return 0;
     const mmvae_dims& d = c.d;
@@ -1400,7 +1413,8 @@ int launch_make_xbits(const Ctx& c, const mmvae_noise* nz) {
     const int64_t n = (int64_t)d.A * d.B * cdiv(wpr, wpt);
     const int blocks = (int)imin64(4096, cdiv64(n, 256));
     hipLaunchKernelGGL(k_make_xbits, dim3(blocks), dim3(256), 0, c.stream, nd, d.A, d.B, d.D, wpr,
-                       reinterpret_cast<uint32_t*>(c.ws + c.lay.xbits));
+                       reinterpret_cast<uint32_t*>(c.ws + c.lay.xbits), c.ws + c.lay.fc11_part,
+                       c.fwd_zeroed ? (int)(c.fwd_zero_floats() / 4) : 0);
     HIP_LAUNCH_CHECK("k_make_xbits");
     return 0;
 }
@@ -1454,7 +1468,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
     const bool use_zg = need_grad && !x_rec && d.H == 100 && !zg_off &&
                         (int64_t)cdiv(d.B, 256) * L.sp.ks_gd10 <= L.n11;
     if ((which & 1) && use_zg) {
-        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        hipError_t e = c.fwd_zeroed ? hipSuccess : hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
         const size_t shm = (size_t)(3 * 64 * ldk + 8 * 32 * ZG_LD + 16) * sizeof(float);
         static bool attr_done = false;
@@ -1471,7 +1485,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
     if (use_zg) return 0;
     if (which & 1) {
         // loss partials: the launch below fills a subset of the reserved slots
-        hipError_t e = hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
+        hipError_t e = c.fwd_zeroed ? hipSuccess : hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
         const int ntall = cdiv(d.D, 64);
         const int kgv = rup(d.H, 8) / 8;

@@ -75,6 +75,7 @@ struct LatArgs {
     // forward, training: BN5's partials [A][nblk][2][L] are recombined by every row block
     int64_t bn_part5, run_mean_off, run_var_off, run_arm_stride;
     int bn5_n;             // partials fc5's launch emitted (one per CHAIN_ROWS cells)
+    int64_t acc_bn5, acc_bnb5;   // accumulator sets ([A] each) instead of bn_part5 (read) / bnb_part5 (added to); -1 = partials
     float bn_momentum;
 };
 
@@ -162,8 +163,14 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 
     if (a.bn_part5 >= 0) {   // training: BN5 batch statistics from fc5's per-row-block partials
         float mean, m2;
-        stats_from_partials<64 * LAT_NW>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L,
-                                         sh_buf, mean, m2);
+        if (a.acc_bn5 >= 0) {
+            mean = m2 = 0.f;
+            if (threadIdx.x < L)
+                acc_mean_m2(reinterpret_cast<const long long*>(ws + a.acc_bn5) + (int64_t)arm * ACC_SET_I64, threadIdx.x, B, mean, m2);
+        } else {
+            stats_from_partials<64 * LAT_NW>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L,
+                                             sh_buf, mean, m2);
+        }
         if (threadIdx.x < L) {
             const int t = threadIdx.x;
             const float rstd = 1.0f / sqrtf(m2 / (float)B + eps);
@@ -486,7 +493,13 @@ __global__ __launch_bounds__(64 * LH_NW) void k_lat_fwd_h(const LatArgs a_in, co
 
     if (a.bn_part5 >= 0) {
         float mean, m2;
-        stats_from_partials<NT>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L, sh_buf, mean, m2);
+        if (a.acc_bn5 >= 0) {
+            mean = m2 = 0.f;
+            if (threadIdx.x < L)
+                acc_mean_m2(reinterpret_cast<const long long*>(ws + a.acc_bn5) + (int64_t)arm * ACC_SET_I64, threadIdx.x, B, mean, m2);
+        } else {
+            stats_from_partials<NT>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L, sh_buf, mean, m2);
+        }
         if (threadIdx.x < L) {
             const int t = threadIdx.x;
             const float rstd = 1.0f / sqrtf(m2 / (float)B + eps);
@@ -1083,8 +1096,12 @@ __global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, co
         float* p = ws + a.bnb_part5 + (((int64_t)arm * gridDim.x + blk) * 2) * L;
         float k0 = 0.f, k1 = 0.f;
         for (int w = 0; w < LATB_NW; ++w) { k0 += sh_s[w][0][k]; k1 += sh_s[w][1][k]; }
-        p[k] = k0;
-        p[L + k] = k1;
+        if (a.acc_bnb5 >= 0) {
+            acc_add_sums(reinterpret_cast<long long*>(ws + a.acc_bnb5) + (int64_t)arm * ACC_SET_I64, k, k0, k1);
+        } else {
+            p[k] = k0;
+            p[L + k] = k1;
+        }
     }
 }
 
@@ -1275,8 +1292,12 @@ __global__ __launch_bounds__(64 * LBH_NW) void k_lat_bwd_h(const LatArgs a_in, c
             k0 += sh_s[w][0][k] + sh_s[w][0][32 + k];      // the two halves hold different cells
             k1 += sh_s[w][1][k] + sh_s[w][1][32 + k];
         }
-        p[k] = k0;
-        p[L + k] = k1;
+        if (a.acc_bnb5 >= 0) {
+            acc_add_sums(reinterpret_cast<long long*>(ws + a.acc_bnb5) + (int64_t)arm * ACC_SET_I64, k, k0, k1);
+        } else {
+            p[k] = k0;
+            p[L + k] = k1;
+        }
     }
 }
 
@@ -1457,6 +1478,8 @@ static LatArgs make_lat_args(const Ctx& c) {
     a.am1 = (float)(d.A > 1 ? d.A - 1 : 1); a.beta = c.h.beta; a.lam = c.h.lam;
     a.bn_part5 = c.h.training ? L.bn_part[4] : -1;
     a.bn5_n = L.nblkc;
+    a.acc_bn5 = (c.h.training && c.use_acc()) ? acc_set_off(L, d.A, 4) : -1;
+    a.acc_bnb5 = c.use_acc() ? acc_set_off(L, d.A, 9) : -1;
     a.run_mean_off = c.po.bn_mean[4]; a.run_var_off = c.po.bn_var[4]; a.run_arm_stride = c.po.bn_per_arm;
     a.bn_momentum = c.h.bn_momentum;
     const int abl = c.tune(MMVAE_TUNE_ABLATE_L);

@@ -145,6 +145,10 @@ enum {
                                       step leaves its first throughput-bound kernel and enters the latency-bound encoder chain.
                                       A caller that produces the NEXT batch on another stream (row gather, H2D copy) lets that
                                       stream wait for it, so that the copy runs beside the chain instead of beside fc1 */
+    MMVAE_TUNE_BN_PARTIALS,        /* BatchNorm batch sums through per-workgroup partial arrays that every consumer recombines
+                                      (round 1's scheme) instead of the fixed-point atomic accumulators             */
+    MMVAE_TUNE_PRESPLIT_ALL,       /* fp32x3 engine: all slice planes through k_presplit launches (none written by the kernels
+                                      that produce the values)                                                       */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {
