@@ -306,20 +306,23 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     if (latent_only) return 0;   // evaluation labels need c only: no decoder, no fc11
     Ctx cs = c;
     cs.stream = c.side();
+    // The fused step on the fast path: the coupling terms AND the T sums of the latent backward (which need nothing but
+    // the coupling kernel's output) run on the side stream from here, beside the decoder chain and fc11; the loss scalars
+    // (which need fc11's partials) follow dW11 on the side stream in do_backward -- no fork between fc11 and the backward
+    // pass, and dW11 starts as soon as fc11 has finished.
+    const bool t_early = fast && couple_done && c.side() && loss_out && fc11_split_path(c, params, x, xs);
     if (couple_done && c.side()) {
         if ((rc = fork_to_side(c, EV_LAT))) return rc;
         if ((rc = launch_couple(cs))) return rc;
         *couple_done = true;
+        if (t_early) {
+            if ((rc = launch_loss_finalize(cs, loss_out, 1))) return rc;
+            if ((rc = record_on_side(c, EV_COUPLE))) return rc;
+        }
     }
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
     if (fast && need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;   // fp32x3: slice planes of [d10 | 1] (fc11, dW11)
-    if (fast && fc11_split_path(c, params, x, xs) && couple_done && *couple_done && loss_out) {
-        if ((rc = launch_fc11_fast(c, params, x, xs, x_rec, need_grad, 1))) return rc;
-        if ((rc = fork_to_side(c, EV_FC11))) return rc;
-        if ((rc = launch_loss_finalize(cs, loss_out))) return rc;
-        if ((rc = record_on_side(c, EV_COUPLE))) return rc;
-        return launch_fc11_fast(c, params, x, xs, x_rec, need_grad, 2);
-    }
+    if (t_early) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
     if (couple_done && *couple_done && (rc = record_on_side(c, EV_COUPLE))) return rc;
     if (fast) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
     return launch_fc11_fused(c, params, x, xs, x_rec, need_grad);
@@ -331,8 +334,11 @@ static int do_loss(const Ctx& c, float* loss_out) {
     return launch_loss_finalize(c, loss_out);
 }
 
+// scalars_out != null: the loss scalars are still to be computed (mmvae_train_step on the fast path; the T sums are
+// already on the side stream, EV_COUPLE) -- behind dW11 on the side stream, or at the end of the main stream
 static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params, const float* x, int64_t xs,
-                       float grad_scale, float* grads, const AdamHost* adam = nullptr, bool wait_loss = false) {
+                       float grad_scale, float* grads, const AdamHost* adam = nullptr, bool wait_loss = false,
+                       float* scalars_out = nullptr) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
     // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain.  Where it is
@@ -357,6 +363,9 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
                 return MMVAE_E_LAUNCH;
             }
             if (c.ex_out) c.ex_out->early_recorded = 1;
+        }
+        if (scalars_out) {
+            if (int r = launch_loss_finalize(cs, scalars_out, 2)) return r;
         }
         if (int r = record_on_side(c, EV_JOIN)) return r;
         forked = true;
@@ -395,6 +404,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     }
     if (!small_on_side && (rc = launch_dw_small(c))) return rc;
     if (forked && (rc = join_from_side(c, EV_JOIN))) return rc;
+    if (scalars_out && !forked && (rc = launch_loss_finalize(c, scalars_out, 2))) return rc;
     return launch_reduce_grads(c, grads, grad_scale, adam, fast, (early && forked) ? 2 : 3);
 }
 
@@ -541,9 +551,9 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
         // need no update)
         if (!exp_avg || !exp_avg_sq || step < 1) { set_error("adam state missing"); return MMVAE_E_BADARG; }
         const AdamHost ah{params, exp_avg, exp_avg_sq, step, lr, beta1, beta2, adam_eps, weight_decay, decoupled};
-        return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, &ah, loss_on_side);
+        return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, &ah, loss_on_side, loss_on_side ? loss_out : nullptr);
     }
-    return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, nullptr, loss_on_side);
+    return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, nullptr, loss_on_side, loss_on_side ? loss_out : nullptr);
 }
 
 int mmvae_eval_classify(const mmvae_dims* d, const mmvae_hyper* h, const float* params, const float* bn_running,

@@ -52,6 +52,10 @@ struct ChainFwdArgs {
     // accumulator sets (common.hpp acc_add; [A] sets each) that replace the two partial arrays: the input's batch sums
     // to read, the output's to add to; -1 = the partial arrays
     int64_t acc_in_off, acc_out_off;
+    // >= 0 (fp32x3 engine, decoder chain): the launch also writes the bf16 slice planes of [out_last | 1] that fc11 and dW11
+    // stage -- [A][3][planes_rows][128] bf16 at this workspace offset, zero outside [B][N_last + 1]
+    int64_t planes_off;
+    int planes_rows;
     int B, ld, wrows;
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
@@ -336,6 +340,26 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         stamp(4);
         lds_barrier();
         stamp(2);
+    }
+    if (a.planes_off >= 0) {
+        // slice planes of [d10 | 1]: Xs holds the last layer's output (zero beyond nvalid rows); pairs of columns, lanes
+        // along a row -> 256-byte store segments.  The last row block also writes the zero rows up to planes_rows.
+        const int N = a.L[a.nlayers - 1].N;
+        const int64_t plane = (int64_t)a.planes_rows * 128;
+        unsigned short* pl = reinterpret_cast<unsigned short*>(ws + a.planes_off) + (int64_t)arm * 3 * plane;
+        const int rows_here = blk == (int)gridDim.x - 1 ? a.planes_rows - b0 : CHAIN_ROWS;
+        for (int i = tid; i < rows_here * 64; i += CH_NT) {
+            const int r = i >> 6, c = (i & 63) * 2;
+            float v0 = 0.f, v1 = 0.f;
+            if (r < nvalid) {
+                v0 = c < N ? Xs[r * ld + c] : (c == N ? 1.f : 0.f);
+                v1 = c + 1 < N ? Xs[r * ld + c + 1] : (c + 1 == N ? 1.f : 0.f);
+            }
+            unsigned w[3];
+            split3(v0, v1, w);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(pl + p * plane + (int64_t)(b0 + r) * 128 + c) = w[p];
+        }
     }
     if (stamps && lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);
@@ -704,6 +728,7 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     const bool acc = c.h.training && c.use_acc();
     a.acc_in_off = acc ? acc_set_off(L, d.A, i - 1) : -1;
     a.acc_out_off = acc ? acc_set_off(L, d.A, i) : -1;
+    a.planes_off = -1;
     a.B = d.B;
     a.ld = fwd_ld(max(d.H, N));
     a.wrows = max(rup(N, 32), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch (statistics prologue / epilogue)
@@ -736,6 +761,7 @@ int launch_chain_fwd_enc_eval(const Ctx& c, const float* params) {
     a.bn_part_off = -1;
     a.stats_part_off = -1;
     a.acc_in_off = a.acc_out_off = -1;
+    a.planes_off = -1;
     a.bn_eps = c.h.eps;
     a.B = d.B;
     a.ld = fwd_ld(max(d.H, d.L));
@@ -764,6 +790,9 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.bn_mean_off = a.bn_rstd_off = a.bn_part_off = -1;
     a.stats_part_off = -1;
     a.acc_in_off = a.acc_out_off = -1;
+    // fp32x3 engine: the slice planes of [d10 | 1] (launch_x3_planes(.., 2) then has nothing to do)
+    a.planes_off = dec_chain_writes_planes(c) ? L.pl_d10 : -1;
+    a.planes_rows = rup(d.B, 256);
     a.B = d.B;
     a.ld = fwd_ld(max(max(d.H, d.L), d.C + d.S));
     a.wrows = rup(max(d.H, d.L), 32);

@@ -667,7 +667,7 @@ int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, flo
 int launch_chain_fwd_dec(const Ctx& c, const float* params);
 int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
 int launch_couple(const Ctx& c);
-int launch_loss_finalize(const Ctx& c, float* loss_out);
+int launch_loss_finalize(const Ctx& c, float* loss_out, int mode = 0 /*1: the T sums only, 2: the scalars only*/);
 int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab);
 bool fc11_split_path(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params);
@@ -713,6 +713,7 @@ inline bool split3_gemms(const Ctx& c, int op = 0) { return (c.h.gemm_bf16 & 0xF
 inline bool bf16_gemms(const Ctx& c, int op = 0) { return ((c.h.gemm_bf16 & 0xFF) == 1 || split3_gemms(c, op)) && c.d.H <= 124; }
 int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11], bit1 [d10|1], bit2 dZ1*/);
 // the kernels that produce dZ1 / d10 write their slice planes themselves (no k_presplit launch for them)
+inline bool dec_chain_writes_planes(const Ctx& c) { return split3_gemms(c) && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
 inline bool bn_apply_writes_planes(const Ctx& c) { return split3_gemms(c, 4) && (c.d.H & 1) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);

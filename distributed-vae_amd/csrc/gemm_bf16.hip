@@ -1416,7 +1416,7 @@ int launch_x3_planes(const Ctx& c, const float* params, int which) {
         jobs[n++] = plane_job(c, PL_W1, params + c.po.o[0], d.D, c.po.per_arm);
         jobs[n++] = plane_job(c, PL_W11, params + c.po.o[26], d.H, c.po.per_arm, params + c.po.o[27], c.po.per_arm);   // bias: column fc_dim
     }
-    if (which & 2) jobs[n++] = plane_job(c, PL_D10, c.ws + c.lay.Dk[4], d.H, (int64_t)d.B * d.H);
+    if ((which & 2) && !dec_chain_writes_planes(c)) jobs[n++] = plane_job(c, PL_D10, c.ws + c.lay.Dk[4], d.H, (int64_t)d.B * d.H);
     if ((which & 4) && !bn_apply_writes_planes(c)) jobs[n++] = plane_job(c, PL_DZ1, c.ws + c.lay.DZ[1], d.H, (int64_t)d.B * d.H);
     return n ? launch_presplit(c.stream, d.A, jobs, n) : 0;
 }

@@ -860,12 +860,15 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int A, int B, int D, int 
                                                        const float* __restrict__ lat_part, int nlat, int nblk,
                                                        const float* __restrict__ couple_part,
                                                        const float* __restrict__ T_part, float* __restrict__ T,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, int mode) {
+    // mode 0: block 0 the scalars, blocks 1.. the T sums; 1: T sums only (every block; they need the coupling kernel's
+    // output alone and the latent backward waits for them); 2: scalars only (one block; they need fc11's loss partials)
     __shared__ double sh[256];
     const int tid = threadIdx.x;
-    if (blockIdx.x > 0) {
+    const int bx = mode == 1 ? (int)blockIdx.x + 1 : (int)blockIdx.x;
+    if (bx > 0) {
         // blocks 1.. : T[a][k] = sum over row blocks of T_part[blk][a][k]  (8 block groups x 32 columns)
-        const int c = tid & 31, g = tid >> 5, i = (blockIdx.x - 1) * 32 + c, n = A * C;
+        const int c = tid & 31, g = tid >> 5, i = (bx - 1) * 32 + c, n = A * C;
         double s = 0.0;
         if (i < n)
             for (int b = g; b < nblk; b += 8) s += T_part[(int64_t)b * n + i];
@@ -1536,12 +1539,13 @@ int launch_couple(const Ctx& c) {
     return 0;
 }
 
-int launch_loss_finalize(const Ctx& c, float* loss_out) {
+int launch_loss_finalize(const Ctx& c, float* loss_out, int mode) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1 + cdiv(d.A * d.C, 32)), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C,
+    const int nT = cdiv(d.A * d.C, 32);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(mode == 0 ? 1 + nT : (mode == 1 ? nT : 1)), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C,
                        c.h.beta, c.h.lam, c.ws + L.fc11_part, L.n11, c.ws + L.lat_part, L.nblkl, L.nblk32, c.ws + L.couple_part,
-                       c.ws + L.T_part, c.ws + L.T, loss_out);
+                       c.ws + L.T_part, c.ws + L.T, loss_out, mode);
     HIP_LAUNCH_CHECK("k_loss_finalize");
     return 0;
 }
