@@ -286,7 +286,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
                 float v = 0.f;
                 if (col < N && row < nvalid) {
                     v = acc[r] + bias;
-                    if (Lr.act) v = fmaxf(v, 0.f);
+                    if (Lr.act) v = relu_keep_nan(v);
                     if (!(a.ablate & 4)) out[(int64_t)(b0 + row) * N + col] = v;
                 }
                 vals[r] = v;

@@ -449,6 +449,10 @@ __device__ __forceinline__ float sums_from_partials(const float* __restrict__ pa
     return sums_from_partials_t<false, NT>(part, nblk, n, scratch);
 }
 
+// ReLU that keeps NaN (torch.relu does; fmaxf(NaN, 0) = 0 would turn a diverged hidden layer into zeros and the loss
+// back into a finite number)
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+
 // ---- fp32x3 engine (gemm_bf16.hip): the three bf16 slices of two fp32 values (low half: a, high half: b) ------------
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // one v_cvt_pk_bf16_f32 (low half: a), round to nearest even
     unsigned r;
@@ -470,14 +474,16 @@ __device__ __forceinline__ void split3(float a, float b, unsigned (&w)[3]) {
 // The alternative to the partial arrays above (production; MMVAE_TUNE_BN_PARTIALS switches back): a producing
 // workgroup ADDS its block sums to one accumulator per column instead of storing them, so a consumer reads W numbers
 // instead of W x (number of producing workgroups).  Floating-point atomics would make the result depend on the arrival
-// order; these are integer adds, which commute: a block sum v (a double) is written as the 142-bit fixed-point number
-// round-toward-zero(|v| * 2^84) = h * 2^80 + m * 2^40 + l (0 <= m, l < 2^40, h < 2^62), the three pieces get the sign of v
-// and are added to three 64-bit slots with device-scope no-return atomics (2^23 addends of either sign fit without a
-// carry between the slots).  Window: |v| and the batch sum below 2^58 = 2.9e17 -- squares of activations up to 7e6 at
-// B = 5000 --, resolution 2^-84 = 5e-26: the variance of a nearly dead unit (BatchNorm eps 1e-8 and below) and gradient
-// sums of 1e-20 are still resolved.  A value outside the window (or NaN / Inf) counts in the set's flag word and every
-// consumer then returns NaN, as the reference's arithmetic would.  The result is the exact sum of the block sums --
-// bit-identical from run to run and for every consumer -- and the consumers form mean and variance from it in fp64.
+// order; these are integer adds, which commute: a block sum v (a double, |v| < 2^58) is written as the fixed-point number
+// round-toward-zero(|v| * 2^84) = h * 2^92 + m * 2^46 + l (0 <= m, l < 2^46, h < 2^50), the three pieces get the sign of v
+// and are added to three 64-bit slots with device-scope no-return atomics; 2^12 addends of the largest magnitude and
+// either sign fit in the high slot and 2^17 in the others without a carry between the slots (more workgroups than that
+// add to one column only for batches beyond 65 000 cells).  Window: block sums below 2^58 = 2.9e17 -- squares of
+// activations of 6e7 in every cell of a 64-cell block --, resolution 2^-84 = 5e-26: the variance of a nearly dead unit
+// (BatchNorm eps 1e-8 and below) and gradient sums of 1e-20 are still resolved.  A value outside the window (or NaN / Inf)
+// counts in the set's flag word and every consumer then returns NaN (the reference's fp32 arithmetic overflows later, at
+// squares of 3e38: a documented limit of this build).  The result is the exact sum of the block sums -- bit-identical
+// from run to run and for every consumer -- and the consumers form mean and variance from it in fp64.
 // Layout of a set: [6][ACC_W] slots (sum 1 high / middle / low, sum 2 high / middle / low; column-minor, so that the lanes
 // of one atomic instruction -- one column each -- fall into as few cache lines as possible: the L2 retires an atomic
 // request per line, and with one slot per line the same adds took 6 us per launch instead of 1), then the flag word.
@@ -488,10 +494,10 @@ __device__ __forceinline__ void acc_add(long long* __restrict__ set, int sum, in
         return;
     }
     const double t = a * 0x1p84;
-    const double h = floor(t * 0x1p-80);
-    const double r = t - h * 0x1p80;             // exact: the low bits of t
-    const double m = floor(r * 0x1p-40);
-    const double l = floor(r - m * 0x1p40);
+    const double h = floor(t * 0x1p-92);
+    const double r = t - h * 0x1p92;             // exact: the low bits of t
+    const double m = floor(r * 0x1p-46);
+    const double l = floor(r - m * 0x1p46);
     long long ih = (long long)h, im = (long long)m, il = (long long)l;
     if (v < 0.0) { ih = -ih; im = -im; il = -il; }
     long long* p = set + (3 * sum) * ACC_W + col;
@@ -505,8 +511,8 @@ __device__ __forceinline__ void acc_get(const long long* __restrict__ set, int c
 #pragma unroll
     for (int k = 0; k < 6; ++k) q[k] = set[k * ACC_W + col];
     const long long bad = set[6 * ACC_W];
-    s1 = ((double)q[0] * 0x1p80 + (double)q[1] * 0x1p40 + (double)q[2]) * 0x1p-84;
-    s2 = ((double)q[3] * 0x1p80 + (double)q[4] * 0x1p40 + (double)q[5]) * 0x1p-84;
+    s1 = ((double)q[0] * 0x1p92 + (double)q[1] * 0x1p46 + (double)q[2]) * 0x1p-84;
+    s2 = ((double)q[3] * 0x1p92 + (double)q[4] * 0x1p46 + (double)q[5]) * 0x1p-84;
     if (bad) { s1 = __builtin_nan(""); s2 = s1; }
 }
 // (sum, sum of squares) over B rows -> (mean, M2) as stats_from_partials returns them

@@ -198,10 +198,10 @@ __global__ __launch_bounds__(256) void k_fc1_epi(const float* __restrict__ slab,
             }
         }
         const bool ok = row < B;
-        z.x = ok ? fmaxf(scale * z.x + bias[0], 0.f) : 0.f;
-        z.y = ok ? fmaxf(scale * z.y + bias[1], 0.f) : 0.f;
-        z.z = ok ? fmaxf(scale * z.z + bias[2], 0.f) : 0.f;
-        z.w = ok ? fmaxf(scale * z.w + bias[3], 0.f) : 0.f;
+        z.x = ok ? relu_keep_nan(scale * z.x + bias[0]) : 0.f;
+        z.y = ok ? relu_keep_nan(scale * z.y + bias[1]) : 0.f;
+        z.z = ok ? relu_keep_nan(scale * z.z + bias[2]) : 0.f;
+        z.w = ok ? relu_keep_nan(scale * z.w + bias[3]) : 0.f;
         v[i] = z;
         if (ok) {
             float* o = R1 + ((int64_t)arm * B + row) * H + c4 * 4;
