@@ -86,10 +86,15 @@ Splits default_splits(const mmvae_dims& d, const mmvae_exec* ex) {
         if (g_split[2] <= 0) s.ks_dw = min(fit(pairs_d * d.A, CUS, 16), max(1, cdiv(d.B, 32)));
         // (dW11: at most three eighths of the CUs -- its 120 KB of LDS leave a CU no room for a chain workgroup, and the
         // backward chain's 79 A workgroups should still find a CU each in ONE round: A = 2, 3 batch splits 768 us, 2: 757)
-        // (workgroup count nearest to 96: measured best at A = 2 (2 splits), A = 3 (2) and A = 5 (1))
+        // (workgroup count nearest to 96: measured best at A = 2 (2 splits), A = 3 (2) and A = 5 (1) while the chain kernels
+        // ran their own GEMMs on the fp32 matrix instruction.  With those on the split engine too (chain.hip, X3) the chain
+        // is 40 us shorter and dW11 has to keep up: nearest to 140 -- A = 2: 4 splits 707 us per step, 3: 720, 2: 728,
+        // 5: 722; A = 3: 2 splits 931, 3: 940; A = 5: 1 split 1527, 2: 1530)
         if (g_split[5] <= 0) {
             const int nwg = max(1, pairs_d * d.A);
-            s.ks_dw11 = min(max(1, (3 * CUS / 8 + nwg / 2) / nwg), max(1, cdiv(d.B, 32)));
+            const bool chain_x3 = d.C + d.S <= 128 && d.L <= 128 && !ex->tune[MMVAE_TUNE_CHAIN_FP32];
+            const int target = chain_x3 ? 140 : 3 * CUS / 8;
+            s.ks_dw11 = min(max(1, (target + nwg / 2) / nwg), max(1, cdiv(d.B, 32)));
         }
         if (g_split[3] <= 0) s.ks_small = min(fit(cdiv(N_SMALL * d.A, 2), CUS, 32), max(1, cdiv(d.B, 32)));   // k_x3_small: a pair of products per block
     }
@@ -180,6 +185,7 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
         L.pl_w11 = take(A * 3 * Dr * 128 / 2);
         L.pl_dz1 = take(A * 3 * Br * 128 / 2);
         L.pl_d10 = take(A * 3 * Br * 128 / 2);
+        L.pl_small = take(A * (int64_t)PL_SMALL_SLOTS * 3 * 128 * 128 / 2);
     }
     L.loss_scratch = take(4096);
     L.total = off;
@@ -372,6 +378,9 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         return 0;
     };
     if (use_side && dw11_at == 0 && (rc = fork_dw11())) return rc;
+    // fp32x3 engine: a backward pass that is its own call writes the small layers' weight planes again (the fused step's
+    // forward pass has left them in place)
+    if (fast && !c.small_planes && (rc = launch_x3_planes(c, params, 8))) return rc;
     const int nslab = fc11_split_path(c, params, x, xs) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11;
     if ((rc = launch_chain_bwd_dec(c, params, nslab))) return rc;
     if (use_side && dw11_at == 1 && (rc = fork_dw11())) return rc;
@@ -602,6 +611,9 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
     if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
     if (!params || !x) { set_error("null params / x"); return MMVAE_E_BADARG; }
     if (int rc = check_noise(c, nz)) return rc;
+    // a stage is replayed on the state a complete forward / backward pass of the same engine left behind: its slice planes
+    // (fp32x3 engine) are in place
+    c.small_planes = chain_x3_ok(c) && fast_path_ok(c, params, x, x_arm_stride);
     switch (stage) {
         case 0:
             if (fast_path_ok(c, params, x, x_arm_stride)) {

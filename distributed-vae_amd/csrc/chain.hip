@@ -36,6 +36,7 @@ struct FwdLayer {
     // eval-mode encoder chain: the next layer reads BatchNorm(out) with the statistics at these workspace offsets
     // ([A,N] each; -1: the next layer reads `out` as is).  The stored `out` stays un-normalised.
     int64_t obn_mean_off = -1, obn_rstd_off = -1;
+    int pl_slot = -1;       // fp32x3 form: index of this layer's weight planes in Layout::pl_small
 };
 struct ChainFwdArgs {
     int nlayers;
@@ -56,6 +57,7 @@ struct ChainFwdArgs {
     // stage -- [A][3][planes_rows][128] bf16 at this workspace offset, zero outside [B][N_last + 1]
     int64_t planes_off;
     int planes_rows;
+    int64_t wpl_off;        // fp32x3 form (k_chain_fwd<true>): workspace offset of Layout::pl_small
     int B, ld, wrows;
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
@@ -123,6 +125,71 @@ __device__ __forceinline__ void w_store(float* Ws, int ld, const float4 (&wq)[WQ
         }
 }
 
+// ---- fp32x3 form of the chains' GEMMs (X3 = true; the fp32x3 engine of gemm_bf16.hip) ------------
+// The 64 x N x K products of a chain launch are MFMA-throughput work for the two waves of a SIMD (52 dependent
+// v_mfma_f32_32x32x2_f32 each: 3.2 us of a 13 us launch).  Here both operands live in LDS as three bf16 slice planes
+// ([row][k], row pitch `ldp` dwords = K/2 rounded up to 8, + 4: conflict-free ds_read_b128) and a product is six
+// v_mfma_f32_32x32x16_bf16 per 16 k -- 42 matrix instructions of 32 cycles instead of 52 of 64, with fp32-grade results.
+// The weights come as planes from the step's k_presplit launch (Layout::pl_small: [A][slot][3][128][128] bf16, zero
+// outside [N][K]); the activations are split where they are written to LDS (input tile, epilogue).
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+constexpr int PLS = 128 * 128;                     // bf16 elements of one global weight plane
+constexpr int WP_N = 3 * ((128 * 16) / CH_NT);     // uint4 per thread: 3 planes x 128 rows x 16 sixteen-byte slots
+__device__ __forceinline__ void wp_load(u32x4c (&wq)[WP_N], const unsigned short* __restrict__ Wg, int N, int K) {
+    const int kc_n = rup(K, 16) >> 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < WP_N / 3; ++i) {
+            const int idx = threadIdx.x + CH_NT * i, row = idx >> 4, kc = idx & 15;
+            const bool ok = row < N && kc < kc_n;
+            wq[pl * (WP_N / 3) + i] = *reinterpret_cast<const u32x4c*>(Wg + pl * PLS + (ok ? row : 0) * 128 + (ok ? kc : 0) * 8);
+        }
+}
+__device__ __forceinline__ void wp_store(unsigned* Wp, int wpl, int ldp, const u32x4c (&wq)[WP_N], int N, int K) {
+    const int kc_n = rup(K, 16) >> 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int i = 0; i < WP_N / 3; ++i) {
+            const int idx = threadIdx.x + CH_NT * i, row = idx >> 4, kc = idx & 15;
+            if (row < N && kc < kc_n) *reinterpret_cast<u32x4c*>(Wp + pl * wpl + row * ldp + kc * 4) = wq[pl * (WP_N / 3) + i];
+        }
+}
+// acc[32 x 32] += A[a_row0 + .][k] * B[b_row0 + .][k] over ksteps x 16 k, operands as three planes each (plane strides
+// xpl / wpl dwords); the fragments of step s + 1 are requested before the MFMAs of step s
+__device__ __forceinline__ void mma_nt_x3(f32x16& acc, const unsigned* Xp, int xpl, const unsigned* Wp, int wpl, int ldp,
+                                          int a_row0, int b_row0, int ksteps) {
+    const int lane = lane_id();
+    const unsigned* pa = Xp + (a_row0 + (lane & 31)) * ldp + 4 * (lane >> 5);
+    const unsigned* pb = Wp + (b_row0 + (lane & 31)) * ldp + 4 * (lane >> 5);
+    bf16x8c a[3], b[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        a[pl] = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const u32x4c*>(pa + pl * xpl));
+        b[pl] = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const u32x4c*>(pb + pl * wpl));
+    }
+    for (int st = 0; st < ksteps; ++st) {
+        const int sn = (st + 1 < ksteps) ? st + 1 : st;
+        bf16x8c an[3], bn[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            an[pl] = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const u32x4c*>(pa + pl * xpl + 8 * sn));
+            bn[pl] = __builtin_bit_cast(bf16x8c, *reinterpret_cast<const u32x4c*>(pb + pl * wpl + 8 * sn));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);   // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { a[pl] = an[pl]; b[pl] = bn[pl]; }
+    }
+}
+
+template <bool X3>
 __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
                                                    float* __restrict__ ws, float* __restrict__ bn_running,
                                                    int64_t* __restrict__ nbt) {
@@ -131,10 +198,15 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     // before each re-load, which serialises the epilogue's stores (measured: 47 % of the kernel).
     const ChainFwdArgs a = a_in;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                         // [CHAIN_ROWS][ld]
-    float* Ws = smem + CHAIN_ROWS * a.ld;     // [wrows][ld]
-    float* mean_s = Ws + a.wrows * a.ld;      // [128]
-    float* rstd_s = mean_s + 128;             // [128]
+    // fp32 form: Xs [CHAIN_ROWS][ld], Ws [wrows][ld] floats.  X3: three planes each, row pitch ld DWORDS (bf16 pairs)
+    constexpr int NPL = X3 ? 3 : 1;
+    float* Xs = smem;
+    float* Ws = smem + NPL * CHAIN_ROWS * a.ld;
+    float* mean_s = Ws + NPL * a.wrows * a.ld;      // [128]
+    float* rstd_s = mean_s + 128;                   // [128]
+    unsigned* const Xp = reinterpret_cast<unsigned*>(Xs);
+    unsigned* const Wp = reinterpret_cast<unsigned*>(Ws);
+    const int xpl = CHAIN_ROWS * a.ld, wpl = a.wrows * a.ld;     // dwords per plane (X3)
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * CHAIN_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rt = wv >> 2, ct = wv & 3;
     const int B = a.B, ld = a.ld;
@@ -156,15 +228,22 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
 
     // ---- requested before anything waits: the first layer's weights and the workgroup's input rows (with the batch sums
     //      below: one memory round trip in front of the first GEMM instead of three)
-    float4 wq[WQ_N];
+    float4 wq[X3 ? 1 : WQ_N];
+    u32x4c wq3[X3 ? WP_N : 1];
     bool wq_valid = false;
+    const unsigned short* const WPL = reinterpret_cast<const unsigned short*>(ws + (X3 ? a.wpl_off : 0)) + (int64_t)arm * PL_SMALL_SLOTS * 3 * PLS;
     {
         const FwdLayer L0 = a.L[0];
-        wq_valid = w_split_ok(P + L0.w_off, L0.K, rup(L0.N, 32), rup(L0.K, 8));
-        if (wq_valid) w_load(wq, P + L0.w_off, L0.N, L0.K);
+        if constexpr (X3) {
+            wq_valid = true;
+            wp_load(wq3, WPL + (int64_t)L0.pl_slot * 3 * PLS, L0.N, L0.K);
+        } else {
+            wq_valid = w_split_ok(P + L0.w_off, L0.K, rup(L0.N, 32), rup(L0.K, 8));
+            if (wq_valid) w_load(wq, P + L0.w_off, L0.N, L0.K);
+        }
     }
     const float* X = ws + a.x_off + (int64_t)arm * B * a.K0;
-    const int xc4n = rup(a.K0, 8) >> 2;
+    const int xc4n = rup(a.K0, X3 ? 16 : 8) >> 2;
     const bool x_early = (a.K0 & 3) == 0 && xc4n <= 32;   // one pass of 16-byte loads covers the tile
     float4 xq[4];
     if (x_early) {
@@ -242,7 +321,18 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
                         o.z = rok ? (o.z - m4.z) * r4.z : 0.f;
                         o.w = rok ? (o.w - m4.w) * r4.w : 0.f;
                     }
-                    if (c < c4n) *reinterpret_cast<float4*>(&Xs[row * ld + c * 4]) = o;
+                    if constexpr (X3) {
+                        if (c < c4n) {
+                            unsigned w0[3], w1[3];
+                            split3(o.x, o.y, w0);
+                            split3(o.z, o.w, w1);
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl)
+                                *reinterpret_cast<uint2*>(Xp + pl * xpl + row * ld + c * 2) = make_uint2(w0[pl], w1[pl]);
+                        }
+                    } else {
+                        if (c < c4n) *reinterpret_cast<float4*>(&Xs[row * ld + c * 4]) = o;
+                    }
                 }
             }
         };
@@ -253,7 +343,8 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     for (int l = 0; l < a.nlayers; ++l) {
         const FwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, KP = rup(K, 8), NPad = rup(N, 32);
-        if (wq_valid) w_store(Ws, ld, wq, N, K, NPad, KP);      // requested during the previous layer
+        if constexpr (X3) wp_store(Wp, wpl, ld, wq3, N, K);
+        else if (wq_valid) w_store(Ws, ld, wq, N, K, NPad, KP);      // requested during the previous layer
         else stage_w(Ws, ld, P + Lr.w_off, N, K, NPad, KP);
         const int col = ct * 32 + (lane & 31);
         const bool active = ct * 32 < NPad;
@@ -267,16 +358,25 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         wq_valid = false;
         if (l + 1 < a.nlayers) {   // next layer's weights travel while this layer computes
             const FwdLayer Ln = a.L[l + 1];
-            wq_valid = w_split_ok(P + Ln.w_off, Ln.K, rup(Ln.N, 32), rup(Ln.K, 8));
-            if (wq_valid) w_load(wq, P + Ln.w_off, Ln.N, Ln.K);
+            if constexpr (X3) {
+                wp_load(wq3, WPL + (int64_t)Ln.pl_slot * 3 * PLS, Ln.N, Ln.K);
+            } else {
+                wq_valid = w_split_ok(P + Ln.w_off, Ln.K, rup(Ln.N, 32), rup(Ln.K, 8));
+                if (wq_valid) w_load(wq, P + Ln.w_off, Ln.N, Ln.K);
+            }
         }
         f32x16 acc = zero16();
-        if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, rt * 32, Ws, ld, ct * 32, KP / 8);
+        if constexpr (X3) {
+            if (active && !(a.ablate & 1)) mma_nt_x3(acc, Xp, xpl, Wp, wpl, ld, rt * 32, ct * 32, rup(K, 16) >> 4);
+        } else {
+            if (active && !(a.ablate & 1)) mma_nt(acc, Xs, ld, rt * 32, Ws, ld, ct * 32, KP / 8);
+        }
         if (stamps) asm volatile("" :: "v"(acc[0]));
         stamp(3);
         lds_barrier();   // every wave has finished reading Xs / Ws
         stamp(2);
         const bool last = (l + 1 == a.nlayers);
+        const bool need_x = !last || a.planes_off >= 0;
         float vals[16];
         if (active) {
             float* out = ws + Lr.out_off + (int64_t)arm * B * N;
@@ -292,7 +392,19 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
                 vals[r] = v;
                 // next layer's input: zero beyond N (up to the next multiple of 8) and beyond nvalid
                 const float xin = obn ? ((col < N && row < nvalid) ? (v - omean) * orstd : 0.f) : v;
-                if (col < rup(N, 8)) Xs[row * ld + col] = xin;
+                if constexpr (X3) {
+                    // the even lane of a pair takes its neighbour's value (quad_perm [1,1,3,3]) and writes whole dwords: 16-bit
+                    // LDS writes of both lanes doubled the epilogue's time.  Nothing reads the tile behind a single layer.
+                    const float nbv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, xin), 0xF5, 0xF, 0xF, false));
+                    if (need_x && !(lane & 1) && col < rup(N, 16)) {
+                        unsigned w3[3];
+                        split3(xin, nbv, w3);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) Xp[pl * xpl + row * ld + (col >> 1)] = w3[pl];
+                    }
+                } else {
+                    if (col < rup(N, 8)) Xs[row * ld + col] = xin;
+                }
             }
         }
         if (last && a.stats_part_off >= 0) {
@@ -350,13 +462,25 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         const int rows_here = blk == (int)gridDim.x - 1 ? a.planes_rows - b0 : CHAIN_ROWS;
         for (int i = tid; i < rows_here * 64; i += CH_NT) {
             const int r = i >> 6, c = (i & 63) * 2;
-            float v0 = 0.f, v1 = 0.f;
-            if (r < nvalid) {
-                v0 = c < N ? Xs[r * ld + c] : (c == N ? 1.f : 0.f);
-                v1 = c + 1 < N ? Xs[r * ld + c + 1] : (c + 1 == N ? 1.f : 0.f);
+            unsigned w[3] = {0u, 0u, 0u};
+            if constexpr (X3) {
+                // Xp already holds the slices of the output (zero from N to the next multiple of 16); add the ones column
+                if (r < nvalid) {
+                    if (c < rup(N, 16)) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) w[p] = Xp[p * xpl + r * ld + (c >> 1)];
+                    }
+                    if (c == N) w[0] |= 0x3F80u;              // bf16(1.0) in the low half (N even)
+                    if (c + 1 == N) w[0] |= 0x3F800000u;      // ... in the high half (N odd)
+                }
+            } else {
+                float v0 = 0.f, v1 = 0.f;
+                if (r < nvalid) {
+                    v0 = c < N ? Xs[r * ld + c] : (c == N ? 1.f : 0.f);
+                    v1 = c + 1 < N ? Xs[r * ld + c + 1] : (c + 1 == N ? 1.f : 0.f);
+                }
+                split3(v0, v1, w);
             }
-            unsigned w[3];
-            split3(v0, v1, w);
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(pl + p * plane + (int64_t)(b0 + r) * 128 + c) = w[p];
         }
@@ -374,6 +498,7 @@ struct BwdLayer {
     int64_t dz_off;     // workspace [A,B,N]: dZ of this layer (stored)
     int64_t act_off;    // workspace [A,B,N]: saved output of this layer (ReLU mask), -1 = identity
     int K, N;
+    int pl_slot = -1;   // fp32x3 form: index of this layer's TRANSPOSED weight planes ([K][N]) in Layout::pl_small
 };
 struct ChainBwdArgs {
     int nlayers;
@@ -391,17 +516,26 @@ struct ChainBwdArgs {
     // float4s this launch zeroes first (the first launch of a backward pass: all backward accumulator sets)
     int64_t acc_in_off, acc_out_off, zero_off;
     int zero_n4;
+    int64_t wpl_off;        // fp32x3 form (k_chain_bwd<true>): workspace offset of Layout::pl_small
     int B, ld, wrows;
     int64_t per_arm;
 };
 
+// X3: the fp32x3 form (see k_chain_fwd): the gradient tile as three planes [row][n], the weights TRANSPOSED as three
+// planes [k][n] (slots 9.. of Layout::pl_small), so that G_prev[row][k] = sum_n dZ[row][n] W[n][k] is the same
+// both-operands-k-contiguous product as the forward one, with the contraction over n.
+template <bool X3>
 __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, const float* __restrict__ params,
                                                    float* __restrict__ ws) {
     const ChainBwdArgs a = a_in;   // see k_chain_fwd: keep the argument block out of memory
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Gs = smem;                        // [CHAIN_ROWS][ld]
-    float* Ws = smem + CHAIN_ROWS * a.ld;    // [wrows][ld]  rows = n (output features), cols = k (input features)
-    float* sums_s = Ws + a.wrows * a.ld;     // [2][128]: sum G, sum G*xhat over the batch
+    constexpr int NPL = X3 ? 3 : 1;
+    float* Gs = smem;                              // [CHAIN_ROWS][ld]           (X3: three planes, pitch ld dwords)
+    float* Ws = smem + NPL * CHAIN_ROWS * a.ld;    // [wrows][ld]  rows = n (output features), cols = k (input features)
+    float* sums_s = Ws + NPL * a.wrows * a.ld;     // [2][128]: sum G, sum G*xhat over the batch
+    unsigned* const Gp = reinterpret_cast<unsigned*>(Gs);
+    unsigned* const Wp = reinterpret_cast<unsigned*>(Ws);
+    const int xpl = CHAIN_ROWS * a.ld, wpl = a.wrows * a.ld;     // dwords per plane (X3)
     const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * CHAIN_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rt = wv >> 2, ct = wv & 3;
     const int B = a.B, ld = a.ld;
@@ -431,7 +565,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
     // ---- prologue: dZ of the first (= last forward) layer
     {
         const BwdLayer L0 = a.L[0];
-        const int N = L0.N, c4n = rup(N, 8) >> 2;
+        const int N = L0.N, c4n = rup(N, X3 ? 16 : 8) >> 2;
         const bool has_act = L0.act_off >= 0, bnb = a.bnb_part_off >= 0;
         const float* G = ws + a.g_off + (int64_t)arm * B * N;
         const float* act = has_act ? ws + L0.act_off + (int64_t)arm * B * N : G;
@@ -490,7 +624,16 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
                     v.z = (rok && col + 2 < N && (!has_act || av.z > 0.f)) ? g.z : 0.f;
                     v.w = (rok && col + 3 < N && (!has_act || av.w > 0.f)) ? g.w : 0.f;
                     if (c < c4n) {
-                        *reinterpret_cast<float4*>(&Gs[row * ld + col]) = v;
+                        if constexpr (X3) {
+                            unsigned w0[3], w1[3];
+                            split3(v.x, v.y, w0);
+                            split3(v.z, v.w, w1);
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl)
+                                *reinterpret_cast<uint2*>(Gp + pl * xpl + row * ld + c * 2) = make_uint2(w0[pl], w1[pl]);
+                        } else {
+                            *reinterpret_cast<float4*>(&Gs[row * ld + col]) = v;
+                        }
                         if (rok) {
                             float* o = dz + (int64_t)(b0 + row) * N + col;
                             if (V && col + 3 < N) *reinterpret_cast<float4*>(o) = v;
@@ -508,25 +651,34 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
         if (vec) stage_g(VecTag{});
         else stage_g(ScalarTag{});
     }
-    float4 wq[WQ_N];
+    float4 wq[X3 ? 1 : WQ_N];
+    u32x4c wq3[X3 ? WP_N : 1];
     bool wq_valid = false;
+    const unsigned short* const WPL = reinterpret_cast<const unsigned short*>(ws + (X3 ? a.wpl_off : 0)) + (int64_t)arm * PL_SMALL_SLOTS * 3 * PLS;
+    if constexpr (X3) wp_load(wq3, WPL + (int64_t)a.L[0].pl_slot * 3 * PLS, a.L[0].K, a.L[0].N);   // [K][N]: rows k, contraction n
     for (int l = 0; l < a.nlayers; ++l) {
         const BwdLayer Lr = a.L[l];
         const int K = Lr.K, N = Lr.N, NP8 = rup(N, 8), KPad = rup(K, 32);
-        if (wq_valid) w_store(Ws, ld, wq, N, K, NP8, KPad);      // requested during the previous layer
+        if constexpr (X3) wp_store(Wp, wpl, ld, wq3, K, N);
+        else if (wq_valid) w_store(Ws, ld, wq, N, K, NP8, KPad);      // requested during the previous layer
         else stage_w(Ws, ld, P + Lr.w_off, N, K, NP8, KPad);
         lds_barrier();
         wq_valid = false;
         if (l + 1 < a.nlayers) {   // next layer's weights travel while this layer computes
             const BwdLayer Ln = a.L[l + 1];
-            wq_valid = w_split_ok(P + Ln.w_off, Ln.K, rup(Ln.N, 8), rup(Ln.K, 32));
-            if (wq_valid) w_load(wq, P + Ln.w_off, Ln.N, Ln.K);
+            if constexpr (X3) {
+                wp_load(wq3, WPL + (int64_t)Ln.pl_slot * 3 * PLS, Ln.K, Ln.N);
+            } else {
+                wq_valid = w_split_ok(P + Ln.w_off, Ln.K, rup(Ln.N, 8), rup(Ln.K, 32));
+                if (wq_valid) w_load(wq, P + Ln.w_off, Ln.N, Ln.K);
+            }
         }
         // the epilogue's global operands -- the saved activation that gates ReLU', or the BatchNorm input of the last
         // layer -- are requested here, in front of the GEMM: fetched after it they cost one exposed memory latency per
         // layer (five per decoder launch)
         const bool last = (l + 1 == a.nlayers);
-        float pre[2][16];
+        constexpr int NTI = X3 ? 1 : 2;   // X3: every width <= 128, one column tile per wave
+        float pre[NTI][16];
         {
             const float* src = nullptr;
             if (!last) {
@@ -536,7 +688,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
                 src = ws + a.rprev_off + (int64_t)arm * B * K;
             }
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
+            for (int ti = 0; ti < NTI; ++ti) {
                 const int col = (ct + 4 * ti) * 32 + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -547,16 +699,22 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
             }
         }
         // input width K may reach 255 (fc6: K = C + S): up to 8 column tiles, two per wave
-        f32x16 accs[2] = {zero16(), zero16()};
+        f32x16 accs[NTI];
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
+        for (int ti = 0; ti < NTI; ++ti) accs[ti] = zero16();
+#pragma unroll
+        for (int ti = 0; ti < NTI; ++ti) {
             const int cti = ct + 4 * ti;
-            if (cti * 32 < KPad) mma_nn(accs[ti], Gs, ld, rt * 32, Ws, ld, cti * 32, NP8 / 8);
+            if constexpr (X3) {
+                if (cti * 32 < KPad) mma_nt_x3(accs[ti], Gp, xpl, Wp, wpl, ld, rt * 32, cti * 32, rup(N, 16) >> 4);
+            } else {
+                if (cti * 32 < KPad) mma_nn(accs[ti], Gs, ld, rt * 32, Ws, ld, cti * 32, NP8 / 8);
+            }
         }
         lds_barrier();
         float ps1[2] = {0.f, 0.f}, ps2[2] = {0.f, 0.f};
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
+        for (int ti = 0; ti < NTI; ++ti) {
             const int cti = ct + 4 * ti;
             if (cti * 32 >= KPad) continue;
             const f32x16 acc = accs[ti];
@@ -570,7 +728,17 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
                     const bool ok = col < K && row < nvalid;
                     const float v = (ok && pre[ti][r] > 0.f) ? acc[r] : 0.f;
                     if (ok) dz[(int64_t)(b0 + row) * K + col] = v;
-                    Gs[row * ld + col] = v;
+                    if constexpr (X3) {   // pairs of columns through the even lane (see k_chain_fwd)
+                        const float nbv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xF5, 0xF, 0xF, false));
+                        if (!(lane & 1) && col < rup(K, 16)) {
+                            unsigned w3[3];
+                            split3(v, nbv, w3);
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) Gp[pl * xpl + row * ld + (col >> 1)] = w3[pl];
+                        }
+                    } else {
+                        Gs[row * ld + col] = v;
+                    }
                 }
             } else {
                 float* go = ws + a.gout_off + (int64_t)arm * B * K;
@@ -601,7 +769,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
         if (last && a.part_off >= 0) {
             // per-workgroup sums over the row tiles through LDS (Ws is free after the GEMM barrier): [rt][2][256]
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
+            for (int ti = 0; ti < NTI; ++ti) {
                 const int col = (ct + 4 * ti) * 32 + (lane & 31);
                 if (lane < 32) { Ws[(rt * 2 + 0) * 256 + col] = ps1[ti]; Ws[(rt * 2 + 1) * 256 + col] = ps2[ti]; }
             }
@@ -698,6 +866,50 @@ static int fwd_ld(int maxdim) { return rup(maxdim, 8) + 4; }
 static int bwd_ld(int maxdim) { return rup(maxdim, 32) + 4; }
 // + 256 floats: the BatchNorm statistics (forward) / batch sums (backward) every row block recombines
 static size_t chain_smem(int ld, int wrows) { return (size_t)(CHAIN_ROWS * ld + wrows * ld + 256) * sizeof(float); }
+// fp32x3 form: three planes per operand, row pitch in dwords (bf16 pairs)
+static int x3_ld(int maxdim) { return rup(maxdim, 16) / 2 + 4; }
+static size_t chain_smem_x3(int ld, int wrows) { return (size_t)(3 * CHAIN_ROWS * ld + 3 * wrows * ld + 256) * sizeof(float); }
+static int launch_fwd(const Ctx& c, ChainFwdArgs& a, int maxdim, const float* params, float* bn_running, int64_t* nbt, const char* what) {
+    const dim3 grid(c.lay.nblkc, c.d.A);
+    if (c.small_planes && chain_x3_ok(c) && maxdim <= 128) {
+        a.ld = x3_ld(maxdim);
+        a.wrows = 128;
+        a.wpl_off = c.lay.pl_small;
+        const size_t shm = chain_smem_x3(a.ld, a.wrows);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_chain_fwd<true>, grid, dim3(CH_NT), shm, c.stream, a, params, c.ws, bn_running, nbt);
+    } else {
+        hipLaunchKernelGGL(k_chain_fwd<false>, grid, dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params, c.ws, bn_running, nbt);
+    }
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(e_)); return MMVAE_E_LAUNCH; }
+    return 0;
+}
+
+static int launch_bwd(const Ctx& c, ChainBwdArgs& a, int maxdim, const float* params, const char* what) {
+    const dim3 grid(c.lay.nblkc, c.d.A);
+    if (c.small_planes && chain_x3_ok(c) && maxdim <= 128) {
+        a.ld = x3_ld(maxdim);
+        a.wrows = 128;
+        a.wpl_off = c.lay.pl_small;
+        const size_t shm = chain_smem_x3(a.ld, a.wrows);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_chain_bwd<true>, grid, dim3(CH_NT), shm, c.stream, a, params, c.ws);
+    } else {
+        hipLaunchKernelGGL(k_chain_bwd<false>, grid, dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params, c.ws);
+    }
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { set_error("%s: %s", what, hipGetErrorString(e_)); return MMVAE_E_LAUNCH; }
+    return 0;
+}
 
 int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn_running, int64_t* nbt) {
     // layer in 2..5: out = relu(BN_{layer-1}(R_{layer-1}) W^T + b), statistics of the output
@@ -735,10 +947,8 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     a.per_arm = c.po.per_arm;
     a.ablate = c.tune(MMVAE_TUNE_ABLATE_C);
     a.dbg_off = L.loss_scratch + 2048;
-    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
-                       c.ws, bn_running, nbt);
-    HIP_LAUNCH_CHECK("k_chain_fwd<enc>");
-    return 0;
+    a.L[0].pl_slot = layer - 2;
+    return launch_fwd(c, a, max(d.H, N), params, bn_running, nbt, "k_chain_fwd<enc>");
 }
 
 // eval mode: the BatchNorm statistics are fixed (running buffers), so fc2..fc5 need no launch boundary between them:
@@ -769,10 +979,8 @@ int launch_chain_fwd_enc_eval(const Ctx& c, const float* params) {
     a.per_arm = c.po.per_arm;
     a.ablate = 0;
     a.dbg_off = -1;
-    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
-                       c.ws, (float*)nullptr, (int64_t*)nullptr);
-    HIP_LAUNCH_CHECK("k_chain_fwd<enc eval>");
-    return 0;
+    for (int i = 0; i < 4; ++i) a.L[i].pl_slot = i;
+    return launch_fwd(c, a, max(d.H, d.L), params, nullptr, nullptr, "k_chain_fwd<enc eval>");
 }
 
 int launch_chain_fwd_dec(const Ctx& c, const float* params) {
@@ -799,10 +1007,8 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.per_arm = c.po.per_arm;
     a.ablate = c.tune(MMVAE_TUNE_ABLATE_C);
     a.dbg_off = L.loss_scratch + 2048;
-    hipLaunchKernelGGL(k_chain_fwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
-                       c.ws, (float*)nullptr, (int64_t*)nullptr);
-    HIP_LAUNCH_CHECK("k_chain_fwd<dec>");
-    return 0;
+    for (int i = 0; i < 5; ++i) a.L[i].pl_slot = 4 + i;
+    return launch_fwd(c, a, max(max(d.H, d.L), d.C + d.S), params, nullptr, nullptr, "k_chain_fwd<dec>");
 }
 
 int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {
@@ -832,10 +1038,8 @@ int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {
     a.ld = bwd_ld(max(max(d.H, d.L), d.C + d.S));
     a.wrows = max(rup(max(d.H, d.L), 8), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch of the epilogue's sums
     a.per_arm = c.po.per_arm;
-    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
-                       c.ws);
-    HIP_LAUNCH_CHECK("k_chain_bwd<dec>");
-    return 0;
+    for (int i = 0; i < 5; ++i) a.L[i].pl_slot = 9 + 8 - i;   // fc10 .. fc6, transposed planes
+    return launch_bwd(c, a, max(max(d.H, d.L), d.C + d.S), params, "k_chain_bwd<dec>");
 }
 
 int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
@@ -868,10 +1072,8 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.ld = bwd_ld(max(d.H, N));
     a.wrows = max(rup(N, 8), cdiv(WS_SCRATCH, a.ld));   // Ws doubles as scratch (batch-sum prologue / epilogue)
     a.per_arm = c.po.per_arm;
-    hipLaunchKernelGGL(k_chain_bwd, dim3(L.nblkc, d.A), dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params,
-                       c.ws);
-    HIP_LAUNCH_CHECK("k_chain_bwd<enc>");
-    return 0;
+    a.L[0].pl_slot = 9 + layer - 2;
+    return launch_bwd(c, a, max(d.H, N), params, "k_chain_bwd<enc>");
 }
 
 int launch_bn_bwd_apply1(const Ctx& c) {

@@ -70,6 +70,9 @@ struct Layout {
     int64_t pl_w11;                // [W11 | b11]  [D -> rup 128][H + 1 -> 128]
     int64_t pl_dz1;                // dZ1  [B -> rup 256][H -> 128]
     int64_t pl_d10;                // [d10 | 1]  [B -> rup 256][H + 1 -> 128]
+    // weights of the small layers for the fp32x3 form of the chain kernels (chain.hip): [A][PL_SMALL_SLOTS][3][128][128] bf16,
+    // slot 0..3 fc2..fc5, 4..8 fc6..fc10 ([N][K] as in the parameters), 9..17 the same layers transposed ([K][N])
+    int64_t pl_small;
     // exact batch sums (fixed-point accumulators, see acc_add below): [ACC_NSETS][A] sets of ACC_SET_FLOATS floats;
     // set k < 5: (sum, sum of squares) of BatchNorm k's input, set 5 + (l - 1): (sum G, sum G * xhat) of layer l's
     // BatchNorm backward, l = 1..5.  Sets 0..4 are zeroed by the first kernel of a forward pass, 5..9 by the first
@@ -79,6 +82,7 @@ struct Layout {
     int64_t total;
 };
 // accumulator set geometry (device side below)
+constexpr int PL_SMALL_SLOTS = 18;
 constexpr int ACC_W = 128;                             // columns per set
 constexpr int ACC_SET_I64 = 6 * ACC_W + 8;             // [6][ACC_W] slots + tail block, [0]: addends outside the window (-> NaN)
 constexpr int ACC_SET_FLOATS = 2 * ACC_SET_I64;
@@ -653,6 +657,9 @@ struct Ctx {
     // set by the launcher that zeroed [fc11_part, end of the forward accumulator sets) at the start of this call's forward
     // pass; launchers that find it unset (a stage replayed on its own) zero what they need themselves
     mutable bool fwd_zeroed = false;
+    // set by launch_x3_planes when this call has written the small-layer weight planes (Layout::pl_small): the chain
+    // launchers then take the fp32x3 form of their kernels
+    mutable bool small_planes = false;
     int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, 5) - lay.fc11_part; }
     int64_t bwd_zero_floats() const { return (int64_t)5 * d.A * ACC_SET_FLOATS; }
 };
@@ -717,8 +724,12 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit
 // (1 fc1, 2 fc11 + d(d10), 4 dW1, 8 dW11)
 inline bool split3_gemms(const Ctx& c, int op = 0) { return (c.h.gemm_bf16 & 0xFF) == 2 && c.d.H <= 124 && !((c.h.gemm_bf16 >> 8) & op); }
 inline bool bf16_gemms(const Ctx& c, int op = 0) { return ((c.h.gemm_bf16 & 0xFF) == 1 || split3_gemms(c, op)) && c.d.H <= 124; }
-int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11], bit1 [d10|1], bit2 dZ1*/);
+int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11] + small layers, bit1 [d10|1], bit2 dZ1, bit3 small layers only*/);
 // the kernels that produce dZ1 / d10 write their slice planes themselves (no k_presplit launch for them)
+// the chain kernels' own GEMMs on the fp32x3 engine: every layer within one 128 x 128 plane
+inline bool chain_x3_ok(const Ctx& c) {
+    return split3_gemms(c) && c.d.C + c.d.S <= 128 && c.d.L <= 128 && !c.tune(MMVAE_TUNE_CHAIN_FP32);
+}
 inline bool dec_chain_writes_planes(const Ctx& c) { return split3_gemms(c) && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
 inline bool bn_apply_writes_planes(const Ctx& c) { return split3_gemms(c, 4) && (c.d.H & 1) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);

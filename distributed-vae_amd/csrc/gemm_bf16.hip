@@ -301,8 +301,9 @@ struct SplitJob {
     int R, C, Rp, Cp, ones_col;
     unsigned short* dst; int64_t dst_arm;
     const float* col_src; int64_t col_arm;   // column `ones_col` reads col_src[row] instead of 1.0 (the bias column of [W11 | b11])
+    int tr;                                  // 1: the planes hold the TRANSPOSE -- element (r, c) = src[c * ld + r]; R, C are the planes' extents
 };
-struct SplitJobs { SplitJob j[4]; };
+struct SplitJobs { SplitJob j[24]; };
 __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
     const SplitJob& J = js.j[blockIdx.y];
     const float* src = J.src + (int64_t)blockIdx.z * J.src_arm;
@@ -316,7 +317,10 @@ __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int r = i / c8n, c0 = (i - r * c8n) * 8;
         float v[8];
-        if (r < J.R && vec && c0 + 8 <= J.C) {
+        if (J.tr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (r < J.R && c0 + e < J.C) ? src[(int64_t)(c0 + e) * J.ld + r] : 0.f;
+        } else if (r < J.R && vec && c0 + 8 <= J.C) {
             const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)r * J.ld + c0);
             const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)r * J.ld + c0 + 4);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -1410,11 +1414,27 @@ static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n) {
 int launch_x3_planes(const Ctx& c, const float* params, int which) {
     if (!split3_gemms(c)) return 0;
     const mmvae_dims& d = c.d;
-    SplitJob jobs[4];
+    SplitJob jobs[24];
     int n = 0;
     if (which & 1) {
         jobs[n++] = plane_job(c, PL_W1, params + c.po.o[0], d.D, c.po.per_arm);
         jobs[n++] = plane_job(c, PL_W11, params + c.po.o[26], d.H, c.po.per_arm, params + c.po.o[27], c.po.per_arm);   // bias: column fc_dim
+    }
+    if (which & 9) {   // bit 3: the small layers alone (a backward pass that is its own call)
+        if (chain_x3_ok(c) && !c.small_planes) {   // the small layers' weights for the chain kernels: slot s = [N][K] of fc2..fc5, fc6..fc10
+            const int H = d.H, L = d.L, CS = d.C + d.S;
+            const int ti[9] = {2, 4, 6, 8, 16, 18, 20, 22, 24};                    // parameter tensor index of the weight
+            const int nn[9] = {H, H, H, L, L, H, H, H, H}, kk[9] = {H, H, H, H, CS, L, H, H, H};
+            unsigned short* base = reinterpret_cast<unsigned short*>(c.ws + c.lay.pl_small);
+            for (int s = 0; s < 9; ++s) {
+                jobs[n++] = SplitJob{params + c.po.o[ti[s]], kk[s], c.po.per_arm, nn[s], kk[s], 128, 128, -1,
+                                     base + (int64_t)s * 3 * 128 * 128, (int64_t)PL_SMALL_SLOTS * 3 * 128 * 128, nullptr, 0, 0};
+                // and [K][N] for the backward chain (its contraction runs over N)
+                jobs[n++] = SplitJob{params + c.po.o[ti[s]], kk[s], c.po.per_arm, kk[s], nn[s], 128, 128, -1,
+                                     base + (int64_t)(9 + s) * 3 * 128 * 128, (int64_t)PL_SMALL_SLOTS * 3 * 128 * 128, nullptr, 0, 1};
+            }
+            c.small_planes = true;
+        }
     }
     if ((which & 2) && !dec_chain_writes_planes(c)) jobs[n++] = plane_job(c, PL_D10, c.ws + c.lay.Dk[4], d.H, (int64_t)d.B * d.H);
     if ((which & 4) && !bn_apply_writes_planes(c)) jobs[n++] = plane_job(c, PL_DZ1, c.ws + c.lay.DZ[1], d.H, (int64_t)d.B * d.H);

@@ -149,6 +149,7 @@ enum {
                                       (round 1's scheme) instead of the fixed-point atomic accumulators             */
     MMVAE_TUNE_PRESPLIT_ALL,       /* fp32x3 engine: all slice planes through k_presplit launches (none written by the kernels
                                       that produce the values)                                                       */
+    MMVAE_TUNE_CHAIN_FP32,         /* fp32x3 engine: the chain kernels' own GEMMs stay on the fp32 matrix instruction           */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {

@@ -220,15 +220,20 @@ def test_gemm_engine_names_map_to_the_abi_values(monkeypatch):
 
 def test_split_factors_follow_the_engine_hint():
     """mmvae_exec.tune[MMVAE_TUNE_ENGINE] = 2: the layout's split factors are chosen for the fp32x3 engine's one-workgroup-
-    per-CU kernels (A = 2, B = D = 5000: fc1 6, small layers 20, fc11 gene split 3, dW1 6, dW11 2)."""
+    per-CU kernels (A = 2, B = D = 5000: fc1 6, small layers 20, fc11 gene split 3, dW1 6; dW11 4 -- about 140 workgroups
+    beside the backward chain when the chain kernels run their own GEMMs on the split engine too, 2 -- about 96 -- when
+    they stay on the fp32 matrix instruction)."""
     from distributed_vae_amd import _native as N
     d = N.Dims(2, 5000, 5000, 100, 10, 92, 2)
     got = {}
-    for eng in (0, 2):
+    for eng, chain_fp32 in ((0, 0), (2, 0), (2, 1)):
         ex = N.Exec()
         ex.tune[N.TUNE_ENGINE] = eng
+        ex.tune[21] = chain_fp32                    # MMVAE_TUNE_CHAIN_FP32
         sp = (C.c_int32 * 6)()
         N.check(N.lib().mmvae_splits(C.byref(d), C.byref(ex), C.byref(sp)), "mmvae_splits")
-        got[eng] = list(sp)
-    assert got[0] == [6, 6, 12, 32, 6, 5], got
-    assert got[2] == [6, 6, 6, 20, 3, 2], got
+        got[eng, chain_fp32] = list(sp)
+    assert got[0, 0] == [6, 6, 12, 32, 6, 5], got
+    assert got[2, 0] == [6, 6, 6, 20, 3, 4], got
+    assert got[2, 1] == [6, 6, 6, 20, 3, 2], got
+    assert N.TUNE_ENV["MMVAE_CHAIN_FP32"][0] == 21
