@@ -303,8 +303,12 @@ constexpr int CHAIN_ROWS = MMVAE_CHAIN_ROWS;
 // per wave -- where 32 gave 314 workgroups on 256 CUs, i.e. 58 CUs with two (four cells per wave slot).
 constexpr int LAT_ROWS = 48;
 // The backward kernel runs beside the dW11 GEMM of the side stream, where smaller workgroups spread over all CUs
-// measured faster in the step (61 against 70 us) although slower alone (32 against 24 us).
-constexpr int LAT_ROWS_BWD = 16;
+// measured faster in the step (61 against 70 us) although slower alone (32 against 24 us); with dW11 on 160 CUs
+// (round 2, chain kernels on the split engine) 8 cells per workgroup again beat 16 (step 718 against 725 us; 32: 729).
+#ifndef MMVAE_LAT_ROWS_BWD
+#define MMVAE_LAT_ROWS_BWD 8
+#endif
+constexpr int LAT_ROWS_BWD = MMVAE_LAT_ROWS_BWD;
 constexpr int LATB_NW = 8;    // waves per workgroup of the latent backward kernel
 constexpr int LATB_NR = LAT_ROWS_BWD / LATB_NW;   // cells per wave, processed side by side
 
