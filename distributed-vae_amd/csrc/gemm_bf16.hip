@@ -303,9 +303,12 @@ struct SplitJob {
     const float* col_src; int64_t col_arm;   // column `ones_col` reads col_src[row] instead of 1.0 (the bias column of [W11 | b11])
     int tr;                                  // 1: the planes hold the TRANSPOSE -- element (r, c) = src[c * ld + r]; R, C are the planes' extents
 };
-struct SplitJobs { SplitJob j[24]; };
+struct SplitJobs { SplitJob j[24]; int first[25]; int n; };   // job i owns blocks [first[i], first[i + 1]) of grid.x
 __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
-    const SplitJob& J = js.j[blockIdx.y];
+    int ji = 0;
+    while (ji + 1 < js.n && (int)blockIdx.x >= js.first[ji + 1]) ++ji;
+    const SplitJob& J = js.j[ji];
+    const int bx = blockIdx.x - js.first[ji], nbx = js.first[ji + 1] - js.first[ji];
     const float* src = J.src + (int64_t)blockIdx.z * J.src_arm;
     const float* col = J.col_src ? J.col_src + (int64_t)blockIdx.z * J.col_arm : nullptr;
     unsigned short* dst = J.dst + (int64_t)blockIdx.z * J.dst_arm;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
     const bool vec = (J.ld & 3) == 0 && (J.C & 3) == 0;
     // a thread keeps its piece column and walks the rows (row pitch of the walk: 256 / c8n rows when c8n <= 256)
     const int n = J.Rp * c8n;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < n; i += nbx * 256) {
         const int r = i / c8n, c0 = (i - r * c8n) * 8;
         float v[8];
         if (J.tr) {
@@ -1401,10 +1404,12 @@ static SplitJob plane_job(const Ctx& c, int kind, const float* src, int64_t ld, 
 }
 static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n) {
     SplitJobs js{};
-    int64_t most = 0;
-    for (int i = 0; i < n; ++i) { js.j[i] = jobs[i]; most = most > (int64_t)jobs[i].Rp * (jobs[i].Cp / 8) ? most : (int64_t)jobs[i].Rp * (jobs[i].Cp / 8); }
-    const int blocks = (int)imin64(1024, cdiv64(most, 256));
-    hipLaunchKernelGGL(k_presplit, dim3(blocks, n, A), dim3(256), 0, s, js);
+    js.n = n;
+    for (int i = 0; i < n; ++i) {   // a job gets the blocks its size asks for (small-layer planes: 8, W11: 320)
+        js.j[i] = jobs[i];
+        js.first[i + 1] = js.first[i] + (int)imin64(1024, cdiv64((int64_t)jobs[i].Rp * (jobs[i].Cp / 8), 256));
+    }
+    hipLaunchKernelGGL(k_presplit, dim3(js.first[n], 1, A), dim3(256), 0, s, js);
     HIP_LAUNCH_CHECK("k_presplit");
     return 0;
 }
