@@ -731,8 +731,9 @@ inline bool bf16_gemms(const Ctx& c, int op = 0) { return ((c.h.gemm_bf16 & 0xFF
 int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11] + small layers, bit1 [d10|1], bit2 dZ1, bit3 small layers only*/);
 // the kernels that produce dZ1 / d10 write their slice planes themselves (no k_presplit launch for them)
 // the chain kernels' own GEMMs on the fp32x3 engine: every layer within one 128 x 128 plane
+// (also in the bf16 configuration: only its five D x H products round their operands, everything else stays fp32-grade)
 inline bool chain_x3_ok(const Ctx& c) {
-    return split3_gemms(c) && c.d.C + c.d.S <= 128 && c.d.L <= 128 && !c.tune(MMVAE_TUNE_CHAIN_FP32);
+    return bf16_gemms(c) && c.d.C + c.d.S <= 128 && c.d.L <= 128 && !c.tune(MMVAE_TUNE_CHAIN_FP32);
 }
 inline bool dec_chain_writes_planes(const Ctx& c) { return split3_gemms(c) && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
 inline bool bn_apply_writes_planes(const Ctx& c) { return split3_gemms(c, 4) && (c.d.H & 1) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }

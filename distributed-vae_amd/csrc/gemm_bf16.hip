@@ -1417,11 +1417,13 @@ static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n) {
 // fp32x3: write the slice planes of the small operands (bit 0: W1 and [W11 | b11], from the parameters; bit 1: [d10 | 1];
 // bit 2: dZ1) -- one small launch each time, ahead of the GEMMs that copy them into LDS.  No-op for the other engines.
 int launch_x3_planes(const Ctx& c, const float* params, int which) {
-    if (!split3_gemms(c)) return 0;
+    const bool x3 = split3_gemms(c);
+    if (!x3 && !chain_x3_ok(c)) return 0;
+    if (!x3) which &= 9;   // bf16 configuration: only the chain kernels take planes
     const mmvae_dims& d = c.d;
     SplitJob jobs[24];
     int n = 0;
-    if (which & 1) {
+    if (which & 1 && x3) {
         jobs[n++] = plane_job(c, PL_W1, params + c.po.o[0], d.D, c.po.per_arm);
         jobs[n++] = plane_job(c, PL_W11, params + c.po.o[26], d.H, c.po.per_arm, params + c.po.o[27], c.po.per_arm);   // bias: column fc_dim
     }
