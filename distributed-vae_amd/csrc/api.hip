@@ -283,13 +283,14 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     const bool fast = fast_path_ok(c, params, x, xs);
     // training: the loss partial slots and the forward accumulator sets start the pass at zero (inside k_make_xbits
     // when that runs); eval mode has no batch sums and the fc11 launchers zero their slots themselves
+    const bool merged = fast && prologue_merged(c);   // keep-mask + zero fill inside the k_presplit launch below
     if (c.h.training) {
-        if ((rc = launch_forward_zero(c, fast, nz))) return rc;
+        if (!merged && (rc = launch_forward_zero(c, fast, nz))) return rc;
     } else if (fast && (rc = launch_make_xbits(c, nz))) {
         return rc;
     }
     if (fast) {
-        if ((rc = launch_x3_planes(c, params, 1))) return rc;          // fp32x3: slice planes of W1 and [W11 | b11]
+        if ((rc = launch_x3_planes(c, params, merged ? 17 : 1, nz))) return rc;   // fp32x3: slice planes of W1, [W11 | b11], the small layers
         if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
         if ((rc = launch_fc1_epi(c, params))) return rc;
         if (c.tune(MMVAE_TUNE_MID_EVENT) && c.side() && hipEventRecord(c.ev(EV_SPARE), c.stream) != hipSuccess) {

@@ -639,6 +639,64 @@ __device__ __forceinline__ bool xmask_keep(const NoiseDev& nz, int arm, int row,
     const u32x4 w = xmask_words(nz, arm, (uint32_t)row, (uint32_t)col >> epg_log2);
     return xmask_field_keep(nz, w, (uint32_t)col & ((1u << epg_log2) - 1u));
 }
+// The bit-packed dropout keep-mask of x (k_make_xbits, gemm_fast.hip; also a role of the step's prologue launch,
+// gemm_bf16.hip): threads first, first + stride, ... of the A * B * ceil(wpr / words-per-thread) work items.
+__device__ __forceinline__ void make_xbits_range(const NoiseDev& nz, int A, int B, int D, int wpr, uint32_t* __restrict__ bits,
+                                                 int64_t first, int64_t stride) {
+    const uint32_t mlog2 = nz.x_mlog2, m = 1u << mlog2;
+    const int wpt = nz.mode != 0 && m <= 4 ? (int)(4u >> mlog2) : 1;      // words per thread
+    const int tpr = (wpr + wpt - 1) / wpt;                // threads per row
+    const int64_t n = (int64_t)A * B * tpr;
+    for (int64_t i = first; i < n; i += stride) {
+        const int tq = (int)(i % tpr);
+        const int64_t ar = i / tpr;
+        const int row = (int)(ar % B), arm = (int)(ar / B);
+        uint32_t* out = bits + ar * wpr;
+        if (nz.mode == 0) {
+            const uint8_t* mk = nz.x_mask + ((int64_t)arm * B + row) * D;
+            for (int k = 0; k < wpt; ++k) {
+                const int w = tq * wpt + k;
+                if (w >= wpr) break;
+                uint32_t word = 0;
+                for (int j = 0; j < 32; ++j) {
+                    const int col = 32 * w + j;
+                    if (col < D && mk[col]) word |= (1u << j);
+                }
+                out[w] = word;
+            }
+            continue;
+        }
+        if (m <= 4) {
+            // one call = genes [tq * 128/m, ...) = words tq * wpt .. + wpt - 1
+            const u32x4 r = xmask_words(nz, arm, (uint32_t)row, (uint32_t)tq);
+            for (int k = 0; k < wpt; ++k) {
+                const int w = tq * wpt + k;
+                if (w >= wpr) break;
+                uint32_t word = 0;
+                if (m == 1) {
+                    const uint32_t f = pick(r, k);   // gene j of the word <-> bit j
+                    word = nz.x_thr >= 2 ? 0xFFFFFFFFu : (nz.x_thr == 1 ? ~f : 0u);
+                } else {
+                    for (int j = 0; j < 32; ++j) word |= xmask_field_keep(nz, r, (uint32_t)(32 * k + j)) ? (1u << j) : 0u;
+                }
+                const int left = D - 32 * w;
+                if (left < 32) word &= (1u << left) - 1u;
+                out[w] = word;
+            }
+        } else {
+            // 32 genes = m / 4 calls of 128 / m genes
+            const int w = tq, ncall = (int)(m >> 2), epc = 32 / ncall;
+            uint32_t word = 0;
+            for (int j = 0; j < ncall; ++j) {
+                const u32x4 r = xmask_words(nz, arm, (uint32_t)row, (uint32_t)(w * ncall + j));
+                for (int e = 0; e < epc; ++e) word |= xmask_field_keep(nz, r, (uint32_t)e) ? (1u << (j * epc + e)) : 0u;
+            }
+            const int left = D - 32 * w;
+            if (left < 32) word &= (1u << left) - 1u;
+            out[w] = word;
+        }
+    }
+}
 #endif  // __HIPCC__
 
 // ------------------------------------------------------------------------------------------
@@ -728,12 +786,18 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which /*bit
 // (1 fc1, 2 fc11 + d(d10), 4 dW1, 8 dW11)
 inline bool split3_gemms(const Ctx& c, int op = 0) { return (c.h.gemm_bf16 & 0xFF) == 2 && c.d.H <= 124 && !((c.h.gemm_bf16 >> 8) & op); }
 inline bool bf16_gemms(const Ctx& c, int op = 0) { return ((c.h.gemm_bf16 & 0xFF) == 1 || split3_gemms(c, op)) && c.d.H <= 124; }
-int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11] + small layers, bit1 [d10|1], bit2 dZ1, bit3 small layers only*/);
+int launch_x3_planes(const Ctx& c, const float* params, int which /*bit0 W1 + [W11|b11] + small layers, bit1 [d10|1], bit2 dZ1, bit3 small layers only, bit4 + keep-mask and zero fill (head of a training step)*/,
+                     const mmvae_noise* nz = nullptr);
+// true when launch_x3_planes(.., 1 | 16, nz) takes over k_make_xbits' work (the engines that have a k_presplit launch at the head of the step)
+inline bool prologue_merged(const Ctx& c);
 // the kernels that produce dZ1 / d10 write their slice planes themselves (no k_presplit launch for them)
 // the chain kernels' own GEMMs on the fp32x3 engine: every layer within one 128 x 128 plane
 // (also in the bf16 configuration: only its five D x H products round their operands, everything else stays fp32-grade)
 inline bool chain_x3_ok(const Ctx& c) {
     return bf16_gemms(c) && c.d.C + c.d.S <= 128 && c.d.L <= 128 && !c.tune(MMVAE_TUNE_CHAIN_FP32);
+}
+inline bool prologue_merged(const Ctx& c) {
+    return c.h.training && c.h.x_drop > 0.f && (split3_gemms(c) || chain_x3_ok(c)) && !c.tune(MMVAE_TUNE_PRESPLIT_ALL);
 }
 inline bool dec_chain_writes_planes(const Ctx& c) { return split3_gemms(c) && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
 inline bool bn_apply_writes_planes(const Ctx& c) { return split3_gemms(c, 4) && (c.d.H & 1) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }

@@ -303,12 +303,23 @@ struct SplitJob {
     const float* col_src; int64_t col_arm;   // column `ones_col` reads col_src[row] instead of 1.0 (the bias column of [W11 | b11])
     int tr;                                  // 1: the planes hold the TRANSPOSE -- element (r, c) = src[c * ld + r]; R, C are the planes' extents
 };
-struct SplitJobs { SplitJob j[24]; int first[25]; int n; };   // job i owns blocks [first[i], first[i + 1]) of grid.x
+// The head of a training step as one launch: besides the split jobs, the first xb.blocks blocks of every z-slice make the
+// dropout keep-mask (k_make_xbits' work) and the whole grid zeroes the step's loss partial slots and forward accumulator
+// sets -- one launch boundary and one tail less on the critical path.
+struct XbitsJob { NoiseDev nz; int A, B, D, wpr; uint32_t* bits; int blocks; float* zero_p; int zero_n4; };
+struct SplitJobs { SplitJob j[24]; int first[25]; int n; XbitsJob xb; };   // job i owns blocks [first[i], first[i + 1]) of grid.x (behind xb.blocks)
 __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
+    if (js.xb.zero_n4 > 0) grid_zero(js.xb.zero_p, js.xb.zero_n4);
+    if ((int)blockIdx.x < js.xb.blocks) {
+        make_xbits_range(js.xb.nz, js.xb.A, js.xb.B, js.xb.D, js.xb.wpr, js.xb.bits,
+                         ((int64_t)blockIdx.z * js.xb.blocks + blockIdx.x) * 256 + threadIdx.x, (int64_t)gridDim.z * js.xb.blocks * 256);
+        return;
+    }
+    const int bx0 = (int)blockIdx.x - js.xb.blocks;
     int ji = 0;
-    while (ji + 1 < js.n && (int)blockIdx.x >= js.first[ji + 1]) ++ji;
+    while (ji + 1 < js.n && bx0 >= js.first[ji + 1]) ++ji;
     const SplitJob& J = js.j[ji];
-    const int bx = blockIdx.x - js.first[ji], nbx = js.first[ji + 1] - js.first[ji];
+    const int bx = bx0 - js.first[ji], nbx = js.first[ji + 1] - js.first[ji];
     const float* src = J.src + (int64_t)blockIdx.z * J.src_arm;
     const float* col = J.col_src ? J.col_src + (int64_t)blockIdx.z * J.col_arm : nullptr;
     unsigned short* dst = J.dst + (int64_t)blockIdx.z * J.dst_arm;
@@ -1402,23 +1413,39 @@ static SplitJob plane_job(const Ctx& c, int kind, const float* src, int64_t ld, 
     return SplitJob{src, ld, src_arm, g.R, g.C, g.Rp, g.Cp, g.ones_col, reinterpret_cast<unsigned short*>(c.ws + g.ws_off),
                     3 * (int64_t)g.Rp * g.Cp, col_src, col_arm};
 }
-static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n) {
+static int launch_presplit(hipStream_t s, int A, const SplitJob* jobs, int n, const XbitsJob* xb = nullptr) {
     SplitJobs js{};
+    if (xb) js.xb = *xb;
     js.n = n;
     for (int i = 0; i < n; ++i) {   // a job gets the blocks its size asks for (small-layer planes: 8, W11: 320)
         js.j[i] = jobs[i];
         js.first[i + 1] = js.first[i] + (int)imin64(1024, cdiv64((int64_t)jobs[i].Rp * (jobs[i].Cp / 8), 256));
     }
-    hipLaunchKernelGGL(k_presplit, dim3(js.first[n], 1, A), dim3(256), 0, s, js);
+    hipLaunchKernelGGL(k_presplit, dim3(js.xb.blocks + js.first[n], 1, A), dim3(256), 0, s, js);
     HIP_LAUNCH_CHECK("k_presplit");
     return 0;
 }
 
 // fp32x3: write the slice planes of the small operands (bit 0: W1 and [W11 | b11], from the parameters; bit 1: [d10 | 1];
 // bit 2: dZ1) -- one small launch each time, ahead of the GEMMs that copy them into LDS.  No-op for the other engines.
-int launch_x3_planes(const Ctx& c, const float* params, int which) {
+int launch_x3_planes(const Ctx& c, const float* params, int which, const mmvae_noise* nz) {
     const bool x3 = split3_gemms(c);
     if (!x3 && !chain_x3_ok(c)) return 0;
+    // bit 4 (the head of a training step's forward pass, dropout on): this launch also makes the keep-mask and zeroes the
+    // loss partial slots and the forward accumulator sets -- k_make_xbits' work (launch_forward_zero) without its launch
+    XbitsJob xb{};
+    const bool head = (which & 16) && c.h.training && c.h.x_drop > 0.f && !c.tune(MMVAE_TUNE_PRESPLIT_ALL);
+    if (head) {
+        const mmvae_dims& dd = c.d;
+        xb.nz = make_noise_dev(nz, c.h);
+        xb.A = dd.A; xb.B = dd.B; xb.D = dd.D; xb.wpr = cdiv(dd.D, 32);
+        xb.bits = reinterpret_cast<uint32_t*>(c.ws + c.lay.xbits);
+        const int wpt = xb.nz.mode != 0 && xb.nz.x_mlog2 <= 2 ? (int)(4u >> xb.nz.x_mlog2) : 1;   // as in make_xbits_range
+        xb.blocks = (int)imin64(2048, cdiv64((int64_t)dd.B * cdiv(xb.wpr, wpt), 256));
+        xb.zero_p = c.ws + c.lay.fc11_part;
+        xb.zero_n4 = (int)(c.fwd_zero_floats() / 4);
+        c.fwd_zeroed = true;
+    }
     if (!x3) which &= 9;   // bf16 configuration: only the chain kernels take planes
     const mmvae_dims& d = c.d;
     SplitJob jobs[24];
@@ -1445,7 +1472,7 @@ int launch_x3_planes(const Ctx& c, const float* params, int which) {
     }
     if ((which & 2) && !dec_chain_writes_planes(c)) jobs[n++] = plane_job(c, PL_D10, c.ws + c.lay.Dk[4], d.H, (int64_t)d.B * d.H);
     if ((which & 4) && !bn_apply_writes_planes(c)) jobs[n++] = plane_job(c, PL_DZ1, c.ws + c.lay.DZ[1], d.H, (int64_t)d.B * d.H);
-    return n ? launch_presplit(c.stream, d.A, jobs, n) : 0;
+    return (n || head) ? launch_presplit(c.stream, d.A, jobs, n, head ? &xb : nullptr) : 0;
 }
 
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs) {

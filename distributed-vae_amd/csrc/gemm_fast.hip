@@ -39,59 +39,7 @@ __device__ __forceinline__ float4 mask4(float4 v, uint32_t nib) {
 __global__ void k_make_xbits(NoiseDev nz, int A, int B, int D, int wpr, uint32_t* __restrict__ bits,
                              float* __restrict__ zero_p, int zero_n4) {
     grid_zero(zero_p, zero_n4);   // the step's loss partial slots and forward accumulator sets (launch_forward_zero)
-    const uint32_t mlog2 = nz.x_mlog2, m = 1u << mlog2;
-    const int wpt = nz.mode != 0 && m <= 4 ? (int)(4u >> mlog2) : 1;      // words per thread
-    const int tpr = (wpr + wpt - 1) / wpt;                // threads per row
-    const int64_t n = (int64_t)A * B * tpr;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int tq = (int)(i % tpr);
-        const int64_t ar = i / tpr;
-        const int row = (int)(ar % B), arm = (int)(ar / B);
-        uint32_t* out = bits + ar * wpr;
-        if (nz.mode == 0) {
-            const uint8_t* mk = nz.x_mask + ((int64_t)arm * B + row) * D;
-            for (int k = 0; k < wpt; ++k) {
-                const int w = tq * wpt + k;
-                if (w >= wpr) break;
-                uint32_t word = 0;
-                for (int j = 0; j < 32; ++j) {
-                    const int col = 32 * w + j;
-                    if (col < D && mk[col]) word |= (1u << j);
-                }
-                out[w] = word;
-            }
-            continue;
-        }
-        if (m <= 4) {
-            // one call = genes [tq * 128/m, ...) = words tq * wpt .. + wpt - 1
-            const u32x4 r = xmask_words(nz, arm, (uint32_t)row, (uint32_t)tq);
-            for (int k = 0; k < wpt; ++k) {
-                const int w = tq * wpt + k;
-                if (w >= wpr) break;
-                uint32_t word = 0;
-                if (m == 1) {
-                    const uint32_t f = pick(r, k);   // gene j of the word <-> bit j
-                    word = nz.x_thr >= 2 ? 0xFFFFFFFFu : (nz.x_thr == 1 ? ~f : 0u);
-                } else {
-                    for (int j = 0; j < 32; ++j) word |= xmask_field_keep(nz, r, (uint32_t)(32 * k + j)) ? (1u << j) : 0u;
-                }
-                const int left = D - 32 * w;
-                if (left < 32) word &= (1u << left) - 1u;
-                out[w] = word;
-            }
-        } else {
-            // 32 genes = m / 4 calls of 128 / m genes
-            const int w = tq, ncall = (int)(m >> 2), epc = 32 / ncall;
-            uint32_t word = 0;
-            for (int j = 0; j < ncall; ++j) {
-                const u32x4 r = xmask_words(nz, arm, (uint32_t)row, (uint32_t)(w * ncall + j));
-                for (int e = 0; e < epc; ++e) word |= xmask_field_keep(nz, r, (uint32_t)e) ? (1u << (j * epc + e)) : 0u;
-            }
-            const int left = D - 32 * w;
-            if (left < 32) word &= (1u << left) - 1u;
-            out[w] = word;
-        }
-    }
+    make_xbits_range(nz, A, B, D, wpr, bits, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // =============================================================================================

@@ -5,8 +5,9 @@ f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [re.search(r"(k_\w+)", r["Kernel_Name"]).group(1) if re.search(r"(k_\w+)", r["Kernel_Name"]) else r["Kernel_Name"][:20] for r in rows]
-# a step starts at k_make_xbits
-starts = [i for i, n in enumerate(names) if n == "k_make_xbits"]
+# a step starts at its head launch (k_make_xbits, or the k_presplit launch that does its work too) behind the previous
+# step's reduction
+starts = [i for i, n in enumerate(names) if n in ("k_make_xbits", "k_presplit") and i > 0 and names[i - 1] == "k_reduce"]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 a, b = starts[k], starts[k + 1]
 t0 = int(rows[a]["Start_Timestamp"])
