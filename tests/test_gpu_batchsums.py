@@ -102,3 +102,64 @@ def test_sums_outside_the_window_poison_the_statistics(bad):
     # and the next, ordinary step is clean (the sets are zeroed at the start of every pass)
     _, buf2, _ = _step(h, B, 11, False)
     assert bool(torch.isfinite(buf2).all())
+
+
+def _step_env(h, B, seed, env, dtype="fp32"):
+    from tests import gpu_util as U
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sd = R.init_state_dict(h, seed)
+        x = R.synthetic_batch(B, h.input_dim, seed=seed + 1)
+        noise = R.draw_noise(h, B, seed=seed + 2)
+        m = U.build_model(h, sd)
+        m.train()
+        m.gemm_dtype = dtype
+        m.set_explicit_noise(U.noise_to_device(noise))
+        buf = m.fused_train_step(x.to(DEV).expand(h.n_arm, -1, -1), 1.0, None, do_adam=False).clone()
+        torch.cuda.synchronize()
+        grads = {k: gv.detach().cpu().clone() for (k, _), gv in zip(m.named_parameters(), m._grad_views)}
+        return sd, x, noise, buf.cpu(), grads
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_chain_products_on_the_split_engine_agree_with_the_fp32_matrix_instruction(dtype):
+    """csrc/chain.hip k_chain_fwd<true> / k_chain_bwd<true> (operands as three bf16 slice planes, six slice products per
+    product) against the same kernels on v_mfma_f32_32x32x2_f32 (``MMVAE_CHAIN_FP32=1``): the fused step's loss vector and
+    gradients agree to fp32 rounding -- typical entry; the worst entry allows one flipped ReLU decision -- in the fp32
+    configuration and in the bf16 one (whose chain kernels take the same form)."""
+    A, B, D, H = 2, 1100, 2600, 100
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=12, state_dim=2, lowD_dim=6, n_arm=A)
+    _, _, _, b3, g3 = _step_env(h, B, 91, {"MMVAE_CHAIN_FP32": "0"}, dtype)
+    _, _, _, b0, g0 = _step_env(h, B, 91, {"MMVAE_CHAIN_FP32": "1"}, dtype)
+    assert float(((b3 - b0).abs() / (b0.abs() + 1e-30)).max()) < 1e-5
+    for k in g3:
+        sc = float(g0[k].abs().max()) + 1e-30
+        e = ((g3[k] - g0[k]).abs() / sc).flatten()
+        assert float(e.median()) < (5e-5 if e.numel() < 1000 else 2e-6), (k, float(e.median()))
+        assert float(e.max()) < 5e-3, (k, float(e.max()))
+
+
+@pytest.mark.parametrize("cs", [(125, 4), (92, 2), (13, 1)])
+def test_chain_forms_by_width_against_the_oracle(cs):
+    """Decoder input width C + S = 129 keeps the chain kernels on the fp32 form (one 128 x 128 plane per weight does not hold
+    it), 94 and 14 (not multiples of four: element-wise loads of the input tile) take the split form: forward outputs, loss
+    and gradients against the oracle at the fp32 gates of tests/test_gpu_parity.py."""
+    from tests import golden_util as G
+    C, S = cs
+    A, B, D, H = 2, 150, 260, 100
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=10, n_arm=A)
+    sd, x, noise, buf, grads = _step_env(h, B, 17, {})
+    _, lt, gref = R.grads_autograd(sd, [x] * A, h, noise)
+    lt = [v.detach() if torch.is_tensor(v) else v for v in lt]
+    want = [float(lt[0]), float(lt[2]), float(lt[3]), float(lt[4]), float(lt[5])] + [float(v) for v in lt[1]]
+    for got, w in zip(buf[:5 + A].tolist(), want):
+        assert abs(got - w) <= 1e-5 * abs(w) + 1e-7, (got, w)
+    for k, v in grads.items():
+        assert G.rel_err(v, gref[k]) < 1e-3, k
