@@ -81,6 +81,7 @@ TUNE_ENV = {
     "MMVAE_FC11_NSZ": (10, int), "MMVAE_GD10_V2": (11, int), "MMVAE_DW1_V2": (12, int), "MMVAE_DW11_V2": (13, int),
     "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_ABLATE_B": (16, int),
     "MMVAE_BN_PARTIALS": (19, int), "MMVAE_PRESPLIT_ALL": (20, int), "MMVAE_CHAIN_FP32": (21, int),
+    "MMVAE_REDUCE11_MAIN": (22, int),
 }
 TUNE_ENGINE = 17    # MMVAE_TUNE_ENGINE: the GEMM engine the caller runs (the layout's split factors are chosen for it)
 TUNE_MID_EVENT = 18  # MMVAE_TUNE_MID_EVENT: record ev[7] behind fc1 (see Engine.mid_event)

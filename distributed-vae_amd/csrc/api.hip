@@ -355,6 +355,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     bool forked = false;
     const bool use_side = fast && c.side();
     const bool early = use_side && !adam && c.ex.early_grad_event != nullptr;
+    const bool side_red = use_side && adam && dw11_at == 0 && !c.tune(MMVAE_TUNE_REDUCE11_MAIN);
     if (c.ex_out) c.ex_out->early_recorded = 0;
     Ctx cs = c;
     cs.stream = c.side();
@@ -370,6 +371,11 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
                 return MMVAE_E_LAUNCH;
             }
             if (c.ex_out) c.ex_out->early_recorded = 1;
+        }
+        if (side_red) {
+            // fused Adam: fc11.weight / fc11.bias (47 % of the parameters) are reduced and updated here, behind their GEMM on
+            // the side stream -- nothing reads W11 again in this step, and the side stream is idle from here to the join
+            if (int r = launch_reduce_grads(cs, grads, grad_scale, adam, true, 1)) return r;
         }
         if (scalars_out) {
             if (int r = launch_loss_finalize(cs, scalars_out, 2)) return r;
@@ -415,7 +421,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     if (!small_on_side && (rc = launch_dw_small(c))) return rc;
     if (forked && (rc = join_from_side(c, EV_JOIN))) return rc;
     if (scalars_out && !forked && (rc = launch_loss_finalize(c, scalars_out, 2))) return rc;
-    return launch_reduce_grads(c, grads, grad_scale, adam, fast, (early && forked) ? 2 : 3);
+    return launch_reduce_grads(c, grads, grad_scale, adam, fast, ((early || side_red) && forked) ? 2 : 3);
 }
 
 }  // namespace mmvae

@@ -150,6 +150,8 @@ enum {
     MMVAE_TUNE_PRESPLIT_ALL,       /* fp32x3 engine: all slice planes through k_presplit launches (none written by the kernels
                                       that produce the values)                                                       */
     MMVAE_TUNE_CHAIN_FP32,         /* fp32x3 engine: the chain kernels' own GEMMs stay on the fp32 matrix instruction           */
+    MMVAE_TUNE_REDUCE11_MAIN,      /* fused Adam: reduce / update the fc11 tensors on the main stream with the rest instead of
+                                      behind their GEMM on the side stream                                              */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {
