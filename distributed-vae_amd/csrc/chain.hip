@@ -876,11 +876,6 @@ static int launch_fwd(const Ctx& c, ChainFwdArgs& a, int maxdim, const float* pa
         a.wrows = 128;
         a.wpl_off = c.lay.pl_small;
         const size_t shm = chain_smem_x3(a.ld, a.wrows);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
         hipLaunchKernelGGL(k_chain_fwd<true>, grid, dim3(CH_NT), shm, c.stream, a, params, c.ws, bn_running, nbt);
     } else {
         hipLaunchKernelGGL(k_chain_fwd<false>, grid, dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params, c.ws, bn_running, nbt);
@@ -897,11 +892,6 @@ static int launch_bwd(const Ctx& c, ChainBwdArgs& a, int maxdim, const float* pa
         a.wrows = 128;
         a.wpl_off = c.lay.pl_small;
         const size_t shm = chain_smem_x3(a.ld, a.wrows);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
         hipLaunchKernelGGL(k_chain_bwd<true>, grid, dim3(CH_NT), shm, c.stream, a, params, c.ws);
     } else {
         hipLaunchKernelGGL(k_chain_bwd<false>, grid, dim3(CH_NT), chain_smem(a.ld, a.wrows), c.stream, a, params, c.ws);
