@@ -1013,22 +1013,30 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     // LDS-DMA of W11 tile t into buffer (t - t0) % 3: 3 slices x 64 rows x 16 sixteen-byte blocks = 48 wave instructions of
     // 1 KB, twelve per wave; LDS slot (row, block b) takes the plane's block b ^ fw_swz(row) (blocks 14, 15: the planes'
     // zero padding).
+    // Addressing is split into what depends on the lane (once, one VGPR: the byte offset of the lane's block inside the
+    // first rows of a tile's plane; the swizzle term does not depend on j because rows advance by 16) and what is uniform
+    // (per instruction: a 64-bit scalar base and the LDS address for M0, a few scalar adds).  Written with a pointer into
+    // Wl and a per-lane source pointer, hipcc converted the generic LDS pointer to a local one (null check included) and
+    // moved both halves through v_readfirstlane for every one of the twelve instructions: ~130 of the loop's ~1060
+    // non-matrix instructions, in a kernel that is bound by instruction issue.
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned wl_base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&Wl[0]);
+    const int lrow = 4 * wv + (lane >> 4);                                  // the lane's row inside a 16-row group
+    const unsigned dma_voff = 2u * ((unsigned)lrow * 128u + 8u * (unsigned)((lane & 15) ^ fw_swz(lrow)));
     auto dma = [&](int t) __attribute__((always_inline)) {
         const int buf = (t - t0) % 3;
+        const unsigned lds0 = wl_base + 4u * (unsigned)(buf * FW_TILE) + 1024u * (unsigned)wv_s;
+        const unsigned short* src0 = Wp + (int64_t)t * (64 * 128);
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            const int ii = wv + 4 * j;
-            const int pl = ii >> 4, chunk = ii & 15;
-            const int row = chunk * 4 + (lane >> 4), c = (lane & 15) ^ fw_swz(row);
-            // (32-bit element offsets: the planes of an arm are a few MB)
-            const unsigned off = (unsigned)pl * (unsigned)wplane + (unsigned)(t * 64 + row) * 128u + 8u * c;
-            const unsigned short* src = Wp + off;
+            // instruction j of this wave: slice j >> 2, rows 16 (j & 3) + 4 wv .. + 3 of the tile (one 1 KB LDS chunk)
+            const unsigned short* src = src0 + (int64_t)(j >> 2) * wplane + (j & 3) * (16 * 128);
+            const unsigned lds_addr = lds0 + 4u * (unsigned)((j >> 2) * FW_PLANE) + 4096u * (unsigned)(j & 3);
             // (inline assembly, not __builtin_amdgcn_global_load_lds: hipcc's wait-count pass treats the builtin as a store to
             // "some" LDS and puts s_waitcnt vmcnt(0) in front of the next LDS read -- which, with the x prefetch just issued,
             // stalled every tile for a full memory round trip.  The waits for the DMA are the counted ones in the loop.)
-            const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(&Wl[buf * FW_TILE + pl * FW_PLANE + chunk * 256]);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                         :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(src) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(lds_addr), "v"(dma_voff), "s"(src) : "memory");
         }
     };
     if (t0 < t1) dma(t0);

@@ -719,7 +719,7 @@ def test_full_size_more_arms_fused_step_matches_api_path(A):
     # API path: forward(need_grad) + loss + backward
     eng.forward(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, None, True)
     l_api = eng.loss(hyper).clone()
-    g_api = torch.empty_like(m._flat_grad)
+    g_api = torch.zeros_like(m._flat_grad)     # zeros: the flat buffer's alignment gaps are never written (the model's own hold zeros)
     eng.backward(hyper, noise, m._flat, x, 0, g_api)
     # fused path from the same state
     m._bn_flat.copy_(bn0)
