@@ -1419,12 +1419,8 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         hipError_t e = c.fwd_zeroed ? hipSuccess : hipMemsetAsync(c.ws + L.fc11_part, 0, sizeof(float) * 2 * (size_t)d.A * L.n11, c.stream);
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
         const size_t shm = (size_t)(3 * 64 * ldk + 8 * 32 * ZG_LD + 16) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {   // more than 64 KB of dynamic LDS needs the opt-in
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fc11_zg<13, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            attr_done = true;
-        }
+        // (152 KB of dynamic LDS: this runtime takes it without the hipFuncSetAttribute opt-in, and the library keeps no
+        // per-process flag for having asked)
         hipLaunchKernelGGL((k_fc11_zg<13, true, true>), dim3(cdiv(d.B, 256), L.sp.ks_gd10, d.A), dim3(512), shm, c.stream,
                            c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,
                            c.ws + L.fc11_part, L.n11, coef, need_grad, d.A, d.B, d.D, d.H, ldk, c.ws + L.GD10_slab);
