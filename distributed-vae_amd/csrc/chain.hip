@@ -1022,7 +1022,7 @@ int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {
     a.acc_in_off = a.acc_out_off = -1;
     // the first launch of every backward pass: it zeroes the backward accumulator sets (the latent backward behind it is
     // their first producer)
-    a.zero_off = acc_set_off(L, d.A, 5);
+    a.zero_off = acc_set_off(L, d.A, ACC_BWD);
     a.zero_n4 = c.use_acc() ? (int)(c.bwd_zero_floats() / 4) : 0;
     a.B = d.B;
     a.ld = bwd_ld(max(max(d.H, d.L), d.C + d.S));
@@ -1054,8 +1054,8 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.rprev_off = L.R[i - 1];
     a.rprev_mean_off = L.bn_mean[i - 1];
     a.rprev_rstd_off = L.bn_rstd[i - 1];
-    a.acc_in_off = c.use_acc() ? acc_set_off(L, d.A, 5 + layer - 1) : -1;
-    a.acc_out_off = c.use_acc() ? acc_set_off(L, d.A, 5 + layer - 2) : -1;
+    a.acc_in_off = c.use_acc() ? acc_set_off(L, d.A, ACC_BWD + layer - 1) : -1;
+    a.acc_out_off = c.use_acc() ? acc_set_off(L, d.A, ACC_BWD + layer - 2) : -1;
     a.zero_off = 0;
     a.zero_n4 = 0;
     a.B = d.B;
@@ -1074,7 +1074,7 @@ int launch_bn_bwd_apply1(const Ctx& c) {
     const int Rp = rup(d.B, 256);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(planes ? Rp / 32 : L.nblk32, d.A), dim3(256), 0, c.stream, c.ws + L.G[1],
                        c.ws + L.R[0], c.ws + L.bn_mean[0], c.ws + L.bn_rstd[0], c.ws + L.bnb_part[1], L.nblkc,
-                       c.use_acc() ? reinterpret_cast<const long long*>(c.ws + acc_set_off(L, d.A, 5)) : nullptr,
+                       c.use_acc() ? reinterpret_cast<const long long*>(c.ws + acc_set_off(L, d.A, ACC_BWD)) : nullptr,
                        c.ws + L.DZ[1], d.B, d.H, planes ? reinterpret_cast<unsigned short*>(c.ws + L.pl_dz1) : nullptr, Rp);
     HIP_LAUNCH_CHECK("k_bn_bwd_apply");
     return 0;

@@ -86,7 +86,12 @@ constexpr int PL_SMALL_SLOTS = 18;
 constexpr int ACC_W = 128;                             // columns per set
 constexpr int ACC_SET_I64 = 6 * ACC_W + 8;             // [6][ACC_W] slots + tail block, [0]: addends outside the window (-> NaN)
 constexpr int ACC_SET_FLOATS = 2 * ACC_SET_I64;
-constexpr int ACC_NSETS = 10;
+constexpr int ACC_NSETS = 12;
+// set indices: 0..4 BatchNorm 1..5 forward (sum, sum of squares), ACC_C the statistics of c for the coupling terms (both
+// zeroed by the first kernel of a training forward pass), ACC_T the coupling's T sums (sum 1 only; zeroed by the coupling
+// launcher, which may run more than once per forward pass), ACC_BWD + l - 1 the BatchNorm backward sums of layer l = 1..5
+// (zeroed by the first kernel of a backward pass)
+constexpr int ACC_C = 5, ACC_T = 6, ACC_BWD = 7;
 inline int64_t acc_set_off(const Layout& L, int A, int set) { return L.acc + (int64_t)set * A * ACC_SET_FLOATS; }
 
 Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex);
@@ -722,7 +727,7 @@ struct Ctx {
     // set by launch_x3_planes when this call has written the small-layer weight planes (Layout::pl_small): the chain
     // launchers then take the fp32x3 form of their kernels
     mutable bool small_planes = false;
-    int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, 5) - lay.fc11_part; }
+    int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, ACC_T) - lay.fc11_part; }
     int64_t bwd_zero_floats() const { return (int64_t)5 * d.A * ACC_SET_FLOATS; }
 };
 // events of mmvae_exec.ev by role

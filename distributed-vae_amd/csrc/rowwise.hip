@@ -76,6 +76,7 @@ struct LatArgs {
     int64_t bn_part5, run_mean_off, run_var_off, run_arm_stride;
     int bn5_n;             // partials fc5's launch emitted (one per CHAIN_ROWS cells)
     int64_t acc_bn5, acc_bnb5;   // accumulator sets ([A] each) instead of bn_part5 (read) / bnb_part5 (added to); -1 = partials
+    int64_t acc_c, acc_T;        // ... instead of c_part (added to by the forward kernels) / T (read by the backward kernels)
     float bn_momentum;
 };
 
@@ -403,9 +404,13 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
             float m2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) m2 += sh_ps[k][col];
-            float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
-            p[col] = mean;
-            p[C + col] = m2;
+            if (a.acc_c >= 0) {
+                acc_add_stats(reinterpret_cast<long long*>(ws + a.acc_c) + (int64_t)arm * ACC_SET_I64, col, (float)nv, mean, m2);
+            } else {
+                float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
+                p[col] = mean;
+                p[C + col] = m2;
+            }
         }
     }
     if (threadIdx.x == 0) {
@@ -728,9 +733,13 @@ __global__ __launch_bounds__(64 * LH_NW) void k_lat_fwd_h(const LatArgs a_in, co
             float m2 = 0.f;
 #pragma unroll
             for (int k = 0; k < G; ++k) m2 += sh_ps[k][col];
-            float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
-            p[col] = mean;
-            p[C + col] = m2;
+            if (a.acc_c >= 0) {
+                acc_add_stats(reinterpret_cast<long long*>(ws + a.acc_c) + (int64_t)arm * ACC_SET_I64, col, (float)nv, mean, m2);
+            } else {
+                float* p = ws + a.c_part + (((int64_t)arm * gridDim.x + blk) * 2) * C;
+                p[col] = mean;
+                p[C + col] = m2;
+            }
         }
     }
     if (threadIdx.x == 0) {
@@ -749,89 +758,125 @@ __global__ __launch_bounds__(64 * LH_NW) void k_lat_fwd_h(const LatArgs a_in, co
 //   T_part[a][k] += G_a[k] * log(c_a[k] + eps),  G_a = (2 lam / B) (A u_a - sum_b u_b)
 // grid (ceil(B/32)), 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_couple(int A, int B, int C, float eps, float lam, const float* __restrict__ CCp,
+// AT: the number of arms (a template parameter: every loop over arms is static, so that all loads of a batch of rows
+// issue before the first use -- with a run-time arm count inside the row loop the kernel waited for every row in turn:
+// 54 us).  c_acc / t_acc != null: the statistics of c come from the accumulator set the latent forward kernels added to,
+// and this kernel adds its T sums to another (the latent backward reads W numbers; no reduction launch); else the
+// partial arrays (c_part recombined here, T_part summed by k_loss_finalize).
+template <int AT>
+__global__ __launch_bounds__(256) void k_couple(int B, int C, float eps, float lam, const float* __restrict__ CCp,
                                                 const float* __restrict__ CSMPp, const float* __restrict__ c_part, int c_n,
-                                                float* __restrict__ c_mean, float* __restrict__ c_iv,
-                                                float* __restrict__ couple_part, float* __restrict__ T_part) {
-    __shared__ __attribute__((aligned(16))) float shT[4][MMVAE_MAX_ARMS][CPL * 64];
-    __shared__ float sh_red[4][2], sh_iv[MMVAE_MAX_ARMS][CPL * 64];
+                                                const long long* __restrict__ c_acc, float* __restrict__ c_mean,
+                                                float* __restrict__ c_iv, float* __restrict__ couple_part,
+                                                float* __restrict__ T_part, long long* __restrict__ t_acc) {
+    constexpr int A = AT;
+    __shared__ __attribute__((aligned(16))) float shT[4][AT][CPL * 64];
+    __shared__ float sh_red[4][2], sh_iv[AT][CPL * 64];
+    __shared__ __attribute__((aligned(16))) float sh_scr[3 * PART_MAXG * CPL * 64];
     const int blk = blockIdx.x, b0 = blk * 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // inv_var of every arm's c over the batch (nn_model.py:558-560): mean and unbiased variance recombined
-    // from k_lat_fwd's per-row-block partials [A][nblk][2][C]; row block 0 keeps them for the backward
-    for (int aa = 0; aa < A; ++aa) {
-        float mean, m2;
-        stats_from_partials<256>(c_part + (int64_t)aa * c_n * 2 * C, c_n, B, LAT_ROWS, C, &shT[0][0][0], mean, m2);
-        if (threadIdx.x < C) {
-            const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
-            sh_iv[aa][threadIdx.x] = ivv;
-            if (blk == 0) { c_mean[aa * C + threadIdx.x] = mean; c_iv[aa * C + threadIdx.x] = ivv; }
+    // inv_var of every arm's c over the batch (nn_model.py:558-560): mean and unbiased variance; row block 0 keeps them
+    // for the backward
+    if (c_acc) {
+        if ((int)threadIdx.x < C) {
+#pragma unroll
+            for (int aa = 0; aa < A; ++aa) {
+                float mean, m2;
+                acc_mean_m2(c_acc + (int64_t)aa * ACC_SET_I64, threadIdx.x, B, mean, m2);
+                const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
+                sh_iv[aa][threadIdx.x] = ivv;
+                if (blk == 0) { c_mean[aa * C + threadIdx.x] = mean; c_iv[aa * C + threadIdx.x] = ivv; }
+            }
         }
         lds_barrier();
-    }
-    float iv[MMVAE_MAX_ARMS][CPL], Tacc[MMVAE_MAX_ARMS][CPL];
-#pragma unroll
-    for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
-#pragma unroll
-        for (int t = 0; t < CPL; ++t) {
-            const int col = lane + 64 * t;
-            iv[aa][t] = (aa < A && col < C) ? sh_iv[aa][col] : 0.f;
-            Tacc[aa][t] = 0.f;
+    } else {
+        for (int aa = 0; aa < A; ++aa) {
+            float mean, m2;
+            stats_from_partials<256>(c_part + (int64_t)aa * c_n * 2 * C, c_n, B, LAT_ROWS, C, sh_scr, mean, m2);
+            if ((int)threadIdx.x < C) {
+                const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
+                sh_iv[aa][threadIdx.x] = ivv;
+                if (blk == 0) { c_mean[aa * C + threadIdx.x] = mean; c_iv[aa * C + threadIdx.x] = ivv; }
+            }
+            lds_barrier();
         }
+    }
+    float iv[AT][CPL], Tacc[AT][CPL];
+    bool vc[CPL];
+    int colc[CPL];
+#pragma unroll
+    for (int t = 0; t < CPL; ++t) {
+        const int col = lane + 64 * t;
+        vc[t] = col < C;
+        colc[t] = min(col, C - 1);
+#pragma unroll
+        for (int aa = 0; aa < A; ++aa) { iv[aa][t] = vc[t] ? sh_iv[aa][col] : 0.f; Tacc[aa][t] = 0.f; }
+    }
     float dist = 0.f, l2 = 0.f;
     const float coefG = 2.f * lam / (float)B;
-    for (int row = wv; row < 32; row += 4) {
-        const int b = b0 + row;
-        if (b >= B) break;
-        float u[MMVAE_MAX_ARMS][CPL], lc[MMVAE_MAX_ARMS][CPL], cs[MMVAE_MAX_ARMS][CPL], us[CPL] = {0.f, 0.f};
+    // a wave owns rows wv, wv + 4, ..., wv + 28 of the block; RB rows at a time, every load of the batch requested (clamped
+    // addresses, no branches) before the first logarithm
+    constexpr int RB = AT <= 2 ? 4 : (AT <= 4 ? 2 : 1);
+    for (int i0 = 0; i0 < 8; i0 += RB) {
+        float ccv[RB][AT][CPL], csv[RB][AT][CPL];
 #pragma unroll
-        for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+        for (int rb = 0; rb < RB; ++rb) {
+            const int bc = min(b0 + wv + 4 * (i0 + rb), B - 1);
+#pragma unroll
+            for (int aa = 0; aa < A; ++aa)
+#pragma unroll
+                for (int t = 0; t < CPL; ++t) {
+                    const int64_t o = ((int64_t)aa * B + bc) * C + colc[t];
+                    ccv[rb][aa][t] = CCp[o];
+                    csv[rb][aa][t] = CSMPp[o];
+                }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const bool rok = b0 + wv + 4 * (i0 + rb) < B;     // wave-uniform
+            float u[AT][CPL], lc[AT][CPL], us[CPL];
 #pragma unroll
             for (int t = 0; t < CPL; ++t) {
-                const int col = lane + 64 * t;
-                u[aa][t] = lc[aa][t] = cs[aa][t] = 0.f;
-                if (aa < A && col < C) {
-                    const int64_t o = ((int64_t)aa * B + b) * C + col;
-                    lc[aa][t] = logf(CCp[o] + eps);
+                us[t] = 0.f;
+#pragma unroll
+                for (int aa = 0; aa < A; ++aa) {
+                    lc[aa][t] = (vc[t] && rok) ? logf(ccv[rb][aa][t] + eps) : 0.f;
                     u[aa][t] = lc[aa][t] * iv[aa][t];
-                    cs[aa][t] = CSMPp[o];
                     us[t] += u[aa][t];
                 }
             }
 #pragma unroll
-        for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa) {
-            if (aa < A) {
+            for (int aa = 0; aa < A; ++aa) {
 #pragma unroll
                 for (int t = 0; t < CPL; ++t) {
                     const float G = coefG * ((float)A * u[aa][t] - us[t]);
                     Tacc[aa][t] += G * lc[aa][t];
                 }
 #pragma unroll
-                for (int bb = aa + 1; bb < MMVAE_MAX_ARMS; ++bb) {
-                    if (bb < A) {
+                for (int bb = aa + 1; bb < A; ++bb)
 #pragma unroll
-                        for (int t = 0; t < CPL; ++t) {
-                            const float du = u[aa][t] - u[bb][t];
-                            const float dc = cs[aa][t] - cs[bb][t];
-                            dist += du * du;
-                            l2 += dc * dc;
-                        }
+                    for (int t = 0; t < CPL; ++t) {
+                        const float du = u[aa][t] - u[bb][t];
+                        const float dc = (vc[t] && rok) ? csv[rb][aa][t] - csv[rb][bb][t] : 0.f;
+                        dist += du * du;
+                        l2 += dc * dc;
                     }
-                }
             }
         }
     }
     dist = wave_sum(dist);
     l2 = wave_sum(l2);
 #pragma unroll
-    for (int aa = 0; aa < MMVAE_MAX_ARMS; ++aa)
+    for (int aa = 0; aa < A; ++aa)
 #pragma unroll
         for (int t = 0; t < CPL; ++t) shT[wv][aa][lane + 64 * t] = Tacc[aa][t];
     if (lane == 0) { sh_red[wv][0] = dist; sh_red[wv][1] = l2; }
     lds_barrier();
     for (int i = threadIdx.x; i < A * C; i += 256) {
         const int aa = i / C, col = i % C;
-        T_part[((int64_t)blk * A + aa) * C + col] = shT[0][aa][col] + shT[1][aa][col] + shT[2][aa][col] + shT[3][aa][col];
+        const float tsum = shT[0][aa][col] + shT[1][aa][col] + shT[2][aa][col] + shT[3][aa][col];
+        if (t_acc) acc_add(t_acc + (int64_t)aa * ACC_SET_I64, 0, col, (double)tsum);
+        else T_part[((int64_t)blk * A + aa) * C + col] = tsum;
     }
     if (threadIdx.x == 0) {
         couple_part[blk * 2] = sh_red[0][0] + sh_red[1][0] + sh_red[2][0] + sh_red[3][0];
@@ -946,6 +991,11 @@ __global__ __launch_bounds__(64 * LATB_NW) void k_lat_bwd(const LatArgs a_in, co
     for (int t = 0; t < CPL; ++t) {
         const int col = lane + 64 * t;
         Tk[t] = col < C ? ws[a.T + arm * C + col] : 0.f;
+        if (a.acc_T >= 0 && col < C) {
+            double s1, s2;
+            acc_get(reinterpret_cast<const long long*>(ws + a.acc_T) + (int64_t)arm * ACC_SET_I64, col, s1, s2);
+            Tk[t] = (float)s1;
+        }
         cmean[t] = col < C ? ws[a.c_mean + arm * C + col] : 0.f;
         ivm[t] = col < C ? ws[a.c_iv + arm * C + col] : 0.f;
 #pragma unroll
@@ -1141,6 +1191,11 @@ __global__ __launch_bounds__(64 * LBH_NW) void k_lat_bwd_h(const LatArgs a_in, c
         const int col = sub + 32 * t;
         vcol[t] = col < C;
         Tk[t] = vcol[t] ? ws[a.T + arm * C + col] : 0.f;
+        if (a.acc_T >= 0 && vcol[t]) {
+            double s1, s2;
+            acc_get(reinterpret_cast<const long long*>(ws + a.acc_T) + (int64_t)arm * ACC_SET_I64, col, s1, s2);
+            Tk[t] = (float)s1;
+        }
         cmean[t] = vcol[t] ? ws[a.c_mean + arm * C + col] : 0.f;
         ivm[t] = vcol[t] ? ws[a.c_iv + arm * C + col] : 0.f;
 #pragma unroll
@@ -1482,7 +1537,9 @@ static LatArgs make_lat_args(const Ctx& c) {
     a.bn_part5 = c.h.training ? L.bn_part[4] : -1;
     a.bn5_n = L.nblkc;
     a.acc_bn5 = (c.h.training && c.use_acc()) ? acc_set_off(L, d.A, 4) : -1;
-    a.acc_bnb5 = c.use_acc() ? acc_set_off(L, d.A, 9) : -1;
+    a.acc_bnb5 = c.use_acc() ? acc_set_off(L, d.A, ACC_BWD + 4) : -1;
+    a.acc_c = (c.h.training && c.use_acc()) ? acc_set_off(L, d.A, ACC_C) : -1;
+    a.acc_T = (c.h.training && c.use_acc()) ? acc_set_off(L, d.A, ACC_T) : -1;
     a.run_mean_off = c.po.bn_mean[4]; a.run_var_off = c.po.bn_var[4]; a.run_arm_stride = c.po.bn_per_arm;
     a.bn_momentum = c.h.bn_momentum;
     const int abl = c.tune(MMVAE_TUNE_ABLATE_L);
@@ -1532,9 +1589,28 @@ int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, flo
 int launch_couple(const Ctx& c) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
-    hipLaunchKernelGGL(k_couple, dim3(L.nblk32), dim3(256), 0, c.stream, d.A, d.B, d.C, c.h.eps, c.h.lam, c.ws + L.CC,
-                       c.ws + L.CSMP, c.ws + L.c_part, L.nblkl, c.ws + L.c_mean, c.ws + L.c_iv, c.ws + L.couple_part,
-                       c.ws + L.T_part);
+    const bool acc = c.h.training && c.use_acc();
+    long long* t_acc = acc ? reinterpret_cast<long long*>(c.ws + acc_set_off(L, d.A, ACC_T)) : nullptr;
+    const long long* c_acc = acc ? reinterpret_cast<const long long*>(c.ws + acc_set_off(L, d.A, ACC_C)) : nullptr;
+    if (acc) {   // the T sums start at zero every time the coupling runs (it may run more than once per forward pass)
+        hipError_t e = hipMemsetAsync(t_acc, 0, sizeof(float) * (size_t)d.A * ACC_SET_FLOATS, c.stream);
+        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
+    }
+#define MMVAE_COUPLE(AT)                                                                                               \
+    hipLaunchKernelGGL(k_couple<AT>, dim3(L.nblk32), dim3(256), 0, c.stream, d.B, d.C, c.h.eps, c.h.lam, c.ws + L.CC,    \
+                       c.ws + L.CSMP, c.ws + L.c_part, L.nblkl, c_acc, c.ws + L.c_mean, c.ws + L.c_iv,                    \
+                       c.ws + L.couple_part, c.ws + L.T_part, t_acc)
+    switch (d.A) {
+        case 1: MMVAE_COUPLE(1); break;
+        case 2: MMVAE_COUPLE(2); break;
+        case 3: MMVAE_COUPLE(3); break;
+        case 4: MMVAE_COUPLE(4); break;
+        case 5: MMVAE_COUPLE(5); break;
+        case 6: MMVAE_COUPLE(6); break;
+        case 7: MMVAE_COUPLE(7); break;
+        default: MMVAE_COUPLE(8); break;
+    }
+#undef MMVAE_COUPLE
     HIP_LAUNCH_CHECK("k_couple");
     return 0;
 }
@@ -1542,6 +1618,10 @@ int launch_couple(const Ctx& c) {
 int launch_loss_finalize(const Ctx& c, float* loss_out, int mode) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
+    if (c.h.training && c.use_acc()) {   // the coupling kernel has added the T sums to their accumulator set itself
+        if (mode == 1) return 0;
+        mode = 2;
+    }
     const int nT = cdiv(d.A * d.C, 32);
     hipLaunchKernelGGL(k_loss_finalize, dim3(mode == 0 ? 1 + nT : (mode == 1 ? nT : 1)), dim3(256), 0, c.stream, d.A, d.B, d.D, d.C,
                        c.h.beta, c.h.lam, c.ws + L.fc11_part, L.n11, c.ws + L.lat_part, L.nblkl, L.nblk32, c.ws + L.couple_part,
