@@ -163,3 +163,42 @@ def test_chain_forms_by_width_against_the_oracle(cs):
         assert abs(got - w) <= 1e-5 * abs(w) + 1e-7, (got, w)
     for k, v in grads.items():
         assert G.rel_err(v, gref[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("fill", ["nan", "big"])
+def test_results_do_not_depend_on_what_the_workspace_held(fill):
+    """The caller's workspace is uninitialised memory: every pass zeroes what it accumulates into and writes
+    every padded region it later reads.  Pre-filling the workspace with NaN or with 3e38 must give bit-identical loss vectors
+    and gradients, on the API path (forward, loss, backward as three calls) and in the fused step."""
+    from tests import gpu_util as U
+    from distributed_vae_amd import _native as N
+    A, B, D = 2, 1100, 2600
+    h = R.Hyper(input_dim=D, fc_dim=100, n_categories=92, state_dim=2, lowD_dim=10, n_arm=A)
+    torch.manual_seed(5)
+    m = U.build_model(h, None)
+    m.train()
+    x = R.synthetic_batch(B, D, seed=3).to(DEV)
+    eng = m._ensure(B)
+    hyper, noise = m._hyper(1.0, False), N.make_noise(None, 11, A)
+    bn0, nbt0 = m._bn_flat.clone(), m._nbt.clone()
+
+    def run(path, value):
+        eng.ws.fill_(value)
+        m._bn_flat.copy_(bn0)
+        m._nbt.copy_(nbt0)
+        g = torch.zeros_like(m._flat_grad)
+        if path == "api":
+            eng.forward(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, None, True)
+            lv = eng.loss(hyper).clone()
+            eng.backward(hyper, noise, m._flat, x, 0, g)
+        else:
+            lv = eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, g, False, None, None, 1, 0.0).clone()
+        torch.cuda.synchronize()
+        return lv, g
+
+    for path in ("api", "fused"):
+        l0, g0 = run(path, 0.0)
+        l1, g1 = run(path, float("nan") if fill == "nan" else 3.0e38)
+        assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(l1).all()), path
+        assert torch.equal(l0, l1), path
+        assert torch.equal(g0, g1), path
