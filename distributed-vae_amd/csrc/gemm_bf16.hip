@@ -555,6 +555,10 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
 // (two LDS buffers, indexed by the K tile's parity; group 1 multiplies tile t while group 0 already stages tile t + 1), a
 // quarter less traffic per pair of tiles.  LDS: two private + two shared buffer sets of 30 KB = 120 KB.
 // SPL: the shared operand comes as slice planes (k_presplit) and is copied, not split again by every block.
+// SHARE = 3: BOTH groups work on the SAME block tile and take alternate K tiles (group g: tiles g, g + 2, ...); group 1's
+// accumulators are added to group 0's through LDS before the epilogue.  For GEMMs with fewer tiles than CUs (the augmenter's
+// 500- and 1000-wide trunk layers at M = 5000: 40 to 160 tiles): twice the workgroups, half the K loop each.  With SPL the B
+// operand comes from planes, copied by each group for its own K tiles.
 template <bool AMINOR, bool BMINOR, int EPI = 0, int SHARE = 0, bool SPL = false>
 __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     typedef Eng<3> E;
@@ -579,17 +583,23 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     int tm, tn;
     if (SHARE == 2) { tn = bi % tiles_n; tm = 2 * (bi / tiles_n) + grp; }
     else if (SHARE == 1) { tm = bi % tiles_m; tn = 2 * (bi / tiles_m) + grp; }
+    else if (SHARE == 3) { tm = bi / tiles_n; tn = bi % tiles_n; }
     else { const int wg = 2 * bi + grp; tm = wg / tiles_n; tn = wg % tiles_n; }
     const bool active = tm < tiles_m && tn < tiles_n;
     const int m0 = tm * BT, n0 = tn * BT;
     const int nkt = cdiv(g.K, KTv);
     const int kb = (int)(((int64_t)blockIdx.y * nkt) / g.KS) * KTv;
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KTv);
-    const int n = ke > kb ? cdiv(ke - kb, KTv) : 0;  // K tiles of this block (the same for both groups)
+    const int n_all = ke > kb ? cdiv(ke - kb, KTv) : 0;  // K tiles of this block
+    // SHARE = 3: this group's share of them (tiles grp, grp + 2, ...); the phase loop runs for the larger share
+    const int n = SHARE == 3 ? (n_all + 1) / 2 : n_all;
+    const int n_mine = SHARE == 3 ? (n_all + 1 - grp) / 2 : n_all;
+    constexpr int KSTEP = SHARE == 3 ? 2 * KTv : KTv;      // distance between consecutive K tiles of a group
+    const int kfirst = SHARE == 3 ? kb + grp * KTv : kb;
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegsT<true, E::NQ> ta, tb;
     PlaneRegs ps;
-    constexpr bool APL = SPL && SHARE == 1, BPL = SPL && SHARE == 2;
+    constexpr bool APL = SPL && SHARE == 1, BPL = SPL && (SHARE == 2 || SHARE == 3);
     const PlaneDev dp = make_plane_dev(SHARE == 1 ? g.a : g.b, arm);
     const bool do_a = SHARE != 1 || grp == 0, do_b = SHARE != 2 || grp == 0;   // which operands this group stages
     // one piece of each operand in turn; a piece's registers request the next tile as soon as they have been written out
@@ -621,19 +631,19 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             }
         }
     };
-    if (active && n > 0) {
+    if (active && n_mine > 0) {
         if constexpr (APL) {
             if (do_a) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) plane_load<AMINOR>(ps, dp, m0, kb, i);
+                for (int i = 0; i < 6; ++i) plane_load<AMINOR>(ps, dp, m0, kfirst, i);
             }
-        } else if (do_a) tile_load<AMINOR, true, 3>(ta, oa, m0, kb, ke);
+        } else if (do_a) tile_load<AMINOR, true, 3>(ta, oa, m0, kfirst, ke);
         if constexpr (BPL) {
             if (do_b) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) plane_load<BMINOR>(ps, dp, n0, kb, i);
+                for (int i = 0; i < 6; ++i) plane_load<BMINOR>(ps, dp, n0, kfirst, i);
             }
-        } else if (do_b) tile_load<BMINOR, true, 3>(tb, ob, n0, kb, ke);
+        } else if (do_b) tile_load<BMINOR, true, 3>(tb, ob, n0, kfirst, ke);
     }
 #ifdef X3_STAMPS
     long long t_st = 0, t_mf = 0, t_bar = 0, t_ld = 0, t0 = __builtin_amdgcn_s_memtime(), t_begin = t0;
@@ -641,8 +651,8 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     // phase p: group g is at step q = p - g of its own sequence stage(0), mfma(0), stage(1), mfma(1), ...
     for (int p = 0; p <= 2 * n; ++p) {
         const int q = p - grp;
-        if (active && q >= 0 && q < 2 * n) {
-            const int t = q >> 1, k0 = kb + t * KTv;
+        if (active && q >= 0 && q < 2 * n_mine) {
+            const int t = q >> 1, k0 = kfirst + t * KSTEP;
             unsigned* const Ad = As[SHARE == 1 ? (t & 1) : grp];
             unsigned* const Bd = Bs[SHARE == 2 ? (t & 1) : grp];
             if (q & 1) {
@@ -656,7 +666,7 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): how long the stage waits for its operands
                 { const long long t1 = __builtin_amdgcn_s_memtime(); t_ld += t1 - t0; t0 = t1; }
 #endif
-                if (k0 + KTv < ke) stage(Ad, Bd, k0, k0 + KTv, VecTag{});
+                if (k0 + KSTEP < ke) stage(Ad, Bd, k0, k0 + KSTEP, VecTag{});
                 else stage(Ad, Bd, k0, k0, ScalarTag{});
 #ifdef X3_STAMPS
                 __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS writes have been issued and accepted
@@ -676,6 +686,30 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
         g.dbg[grp * 8 + 5] = t_ld;
     }
 #endif
+    if constexpr (SHARE == 3) {
+        // group 1's partial sums join group 0's through LDS (the operand images are dead: every wave is past the loop's last
+        // barrier), one row-tile pair of accumulators at a time: 2 x 16 floats per lane = 32 KB
+        float* red = reinterpret_cast<float*>(&As[0][0]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (grp == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 256 + tid] = acc[i][j][r];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(j * 16 + r) * 256 + tid];
+            }
+            __syncthreads();
+        }
+        if (active && grp == 0) gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, arm);
+        return;
+    }
     if (active) gemm_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane, arm);
 }
 
@@ -1639,7 +1673,14 @@ int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, in
         // fp32x3 with the weight's slice planes (written at pack time): the two tiles of a block are m neighbours of one
         // n tile and share its weight tile, copied from the planes; the activations are split on their way into LDS
         g.b.pl = w_planes; g.b.pl_plane = (int64_t)Np * Kp; g.b.pl_arm = 0; g.b.pl_ld = Kp;
-        hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 2, true>), dim3(cdiv(cdiv(M, BT), 2) * cdiv(ncols, BT), 1, 1), dim3(512), 0, s, g);
+        const int tiles = cdiv(M, BT) * cdiv(ncols, BT);
+        // fewer tile pairs than half the CUs: one tile per block, the groups split K (trunk layers 1000 -> 500, 500 -> 500,
+        // 500 -> 100 at M = 5000: 77 -> 51, 45 -> 32, 44 -> 31 us; at 320 tiles the lost sharing of the weight tile costs more:
+        // 360 -> 385, 82 -> 92, 50 -> 62 us)
+        if (tiles <= 192 && Kpad >= 4 * Eng<3>::KT)
+            hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 3, true>), dim3(tiles, 1, 1), dim3(512), 0, s, g);
+        else
+            hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 2, true>), dim3(cdiv(cdiv(M, BT), 2) * cdiv(ncols, BT), 1, 1), dim3(512), 0, s, g);
     } else if (split3)
         hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 0>), dim3(cdiv(cdiv(M, BT) * cdiv(ncols, BT), 2), 1, 1), dim3(512), 0, s, g);
     else

@@ -100,7 +100,9 @@ def test_production_shape_against_oracle(D):
     s64b, x64b = OA.forward_eval(sd64, xs.double(), z0.double(), eps.double(), 0.1)
     s2, xa2 = m(xs.to(DEV), True, 0.1)
     assert _rel(s2.double(), s64b) < max(TOL / 4, 4 * floor_s) and _rel(xa2.double(), x64b) < max(TOL / 4, 4 * floor_x)
-    assert _rel(xa2[0], xa[0].cpu()) < 1e-6                            # arm 0 saw the same x on both paths
+    # arm 0 saw the same x on both paths (fp32 rounding only: the shared trunk at M = B and the per-arm trunk at M = A B take
+    # different tile pairings -- split K inside a block against two row tiles per block -- hence different summation orders)
+    assert _rel(xa2[0], xa[0].cpu()) < 5e-6
 
 
 def test_device_noise_statistics_and_determinism():
