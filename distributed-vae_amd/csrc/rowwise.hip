@@ -166,7 +166,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
         float mean, m2;
         if (a.acc_bn5 >= 0) {
             mean = m2 = 0.f;
-            if (threadIdx.x < L)
+            if ((int)threadIdx.x < L)
                 acc_mean_m2(reinterpret_cast<const long long*>(ws + a.acc_bn5) + (int64_t)arm * ACC_SET_I64, threadIdx.x, B, mean, m2);
         } else {
             stats_from_partials<64 * LAT_NW>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L,
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64 * LH_NW) void k_lat_fwd_h(const LatArgs a_in, co
         float mean, m2;
         if (a.acc_bn5 >= 0) {
             mean = m2 = 0.f;
-            if (threadIdx.x < L)
+            if ((int)threadIdx.x < L)
                 acc_mean_m2(reinterpret_cast<const long long*>(ws + a.acc_bn5) + (int64_t)arm * ACC_SET_I64, threadIdx.x, B, mean, m2);
         } else {
             stats_from_partials<NT>(ws + a.bn_part5 + (int64_t)arm * a.bn5_n * 2 * L, a.bn5_n, B, CHAIN_ROWS, L, sh_buf, mean, m2);
