@@ -87,11 +87,15 @@ TUNE_ENGINE = 17    # MMVAE_TUNE_ENGINE: the GEMM engine the caller runs (the la
 TUNE_MID_EVENT = 18  # MMVAE_TUNE_MID_EVENT: record ev[7] behind fc1 (see Engine.mid_event)
 
 
+AT_MID_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)    # mmvae_exec.at_mid(user, stream)
+
+
 class Exec(C.Structure):
     """mmvae_exec: the caller-owned execution context of one engine (side stream, fork / join events, split factors,
     experiment switches)."""
     _fields_ = [("side_stream", C.c_void_p), ("ev", C.c_void_p * N_EVENTS), ("early_grad_event", C.c_void_p),
-                ("early_recorded", C.c_int32), ("split", C.c_int32 * 6), ("tune", C.c_int32 * N_TUNE)]
+                ("early_recorded", C.c_int32), ("split", C.c_int32 * 6), ("tune", C.c_int32 * N_TUNE),
+                ("at_mid", AT_MID_FN), ("at_mid_user", C.c_void_p)]
 
 
 def exec_from_env(engine: int = 0) -> Exec:
@@ -278,6 +282,34 @@ class Engine:
             return None
         self.ex.tune[TUNE_MID_EVENT] = 1 if on else 0
         return self._events[7] if on else None
+
+    def at_mid(self, fn=None):
+        """Install (or, with None, remove) the producer of the next batch: ``fn(stream)`` is called on the host from inside
+        the next forward / train_step call, right behind its first layer, with ``stream`` a ``torch.cuda.ExternalStream``
+        of the engine's side stream forked from that point; what it enqueues there (row gather, H2D copy) runs beside the
+        latency-bound encoder chain and is complete when the step is.  An exception raised by ``fn`` is re-raised by
+        ``raise_at_mid_error()`` (ctypes cannot propagate it through the C call).  No-op without a side stream."""
+        self._at_mid_err = None
+        if fn is None or self.side is None:
+            self._at_mid_cb = None
+            self.ex.at_mid = AT_MID_FN()
+            return False
+        ext = torch.cuda.ExternalStream(self.side.cuda_stream, device=self.device)
+
+        def _cb(_user, _stream):
+            try:
+                fn(ext)
+            except BaseException as e:      # noqa: BLE001 -- handed to the caller after the C call returns
+                self._at_mid_err = e
+
+        self._at_mid_cb = AT_MID_FN(_cb)    # keep the thunk alive as long as the library may call it
+        self.ex.at_mid = self._at_mid_cb
+        return True
+
+    def raise_at_mid_error(self):
+        e, self._at_mid_err = getattr(self, "_at_mid_err", None), None
+        if e is not None:
+            raise e
 
     def _x(self):
         return C.byref(self.ex)

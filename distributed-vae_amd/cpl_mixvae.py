@@ -230,7 +230,7 @@ class cpl_mixVAE:
         aug_out = {}
         count = [0]
 
-        def produce():
+        def produce(record=True):
             b = next(it, None)
             if b is None:
                 return None
@@ -243,6 +243,8 @@ class cpl_mixVAE:
                                     torch.empty(A, x.shape[0], x.shape[1], device=self.device))
                 xs = self.netA(xs, True, 0.1, out=aug_out[key])[1]   # cpl_mixvae.py:422-423
             count[0] += 1
+            if not record:                                      # enqueued from inside the step's call (at_mid): the step's own join covers it
+                return xs, x, None
             ev = torch.cuda.Event()
             ev.record(side)
             return xs, x, ev
@@ -256,32 +258,54 @@ class cpl_mixVAE:
         # encoder chain -- so that it streams through HBM while the chip is mostly idle, not beside fc1 (measured at the
         # benchmark shape: 0.80 ms per shuffled step with the copy issued in front of the step).  With an augmenter the
         # production is a 1.7 ms chain of GEMMs: it starts in front of the step, as before.
+        # Issued from here behind the step's C call, though, the copy reaches the device ~300 us into the step and lands
+        # beside the fc11 kernel (tools/epoch_timeline.py: 98 us instead of 36, fc11 151 -> 182 us).  So the engine calls
+        # the producer itself, from inside the step's call, right behind fc1 (mmvae_exec.at_mid): the copy is enqueued on the
+        # engine's own side stream at that point and is complete when the step is -- no event of its own.
         late = self.netA is None and not D.is_dist()
-        while cur is not None:
-            # ring buffers (loader batches, augmenter outputs) are reused every few batches: the side stream may only
-            # overwrite a slot once the step that read it is over (two steps back is enough for rings of >= 3)
-            if len(done) >= 2:
-                side.wait_event(done[-2])
-            if not late:
-                with torch.cuda.stream(side):
-                    nxt = produce()
-            xs, x, ev = cur
-            main.wait_event(ev)
-            buf = self._step(xs)
-            if late:
-                mid = self.model._engine.mid_event() if self.model._engine is not None else None
-                if mid is not None:
-                    side.wait_event(mid)
-                with torch.cuda.stream(side):
-                    nxt = produce()
-            x.record_stream(main)                               # produced on the side stream, read on the main one
-            fin = torch.cuda.Event()
-            fin.record(main)
-            done.append(fin)
-            if len(done) > 4:
-                done.pop(0)
-            yield buf
-            cur = nxt
+        held = {}
+
+        def at_mid(stream):
+            with torch.cuda.stream(stream):
+                held["nxt"] = produce(record=False)
+
+        hooked = []
+        try:
+            while cur is not None:
+                # ring buffers (loader batches, augmenter outputs) are reused every few batches: the side stream may only
+                # overwrite a slot once the step that read it is over (two steps back is enough for rings of >= 3)
+                if len(done) >= 2:
+                    side.wait_event(done[-2])
+                if not late:
+                    with torch.cuda.stream(side):
+                        nxt = produce()
+                xs, x, ev = cur
+                if ev is not None:
+                    main.wait_event(ev)
+                eng = self.model._ensure(xs.shape[1]) if late and os.environ.get("MMVAE_AT_MID", "1") != "0" else None
+                in_call = eng is not None and eng.at_mid(at_mid)
+                if in_call and eng not in hooked:
+                    hooked.append(eng)
+                held.pop("nxt", None)
+                buf = self._step(xs)
+                if in_call:
+                    eng.raise_at_mid_error()
+                if late and "nxt" in held:
+                    nxt = held.pop("nxt")
+                elif late:                                      # no side stream / the step did not reach the hook
+                    with torch.cuda.stream(side):
+                        nxt = produce()
+                x.record_stream(main)                           # produced on the side stream, read on the main one
+                fin = torch.cuda.Event()
+                fin.record(main)
+                done.append(fin)
+                if len(done) > 4:
+                    done.pop(0)
+                yield buf
+                cur = nxt
+        finally:
+            for eng in hooked:
+                eng.at_mid(None)
 
     def train(self, train_loader, test_loader, n_epoch, n_epoch_p=0, c_p=0, c_onehot=0, min_con=0.5,
               max_prun_it=0, rank=None, run=None, ws=1, good_enuf_consensus=0.75):

@@ -293,7 +293,11 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         if ((rc = launch_x3_planes(c, params, merged ? 17 : 1, nz))) return rc;   // fp32x3: slice planes of W1, [W11 | b11], the small layers
         if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
         if ((rc = launch_fc1_epi(c, params))) return rc;
-        if (c.tune(MMVAE_TUNE_MID_EVENT) && c.side() && hipEventRecord(c.ev(EV_SPARE), c.stream) != hipSuccess) {
+        if (c.ex.at_mid && c.side()) {
+            // the caller's producer of the next batch: on the side stream from here, ahead of the coupling fork's work
+            if ((rc = fork_to_side(c, EV_SPARE))) return rc;
+            c.ex.at_mid(c.ex.at_mid_user, c.ex.side_stream);
+        } else if (c.tune(MMVAE_TUNE_MID_EVENT) && c.side() && hipEventRecord(c.ev(EV_SPARE), c.stream) != hipSuccess) {
             set_error("event record failed");
             return MMVAE_E_LAUNCH;
         }

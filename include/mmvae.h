@@ -161,6 +161,15 @@ typedef struct mmvae_exec {
     int32_t early_recorded;
     int32_t split[6];
     int32_t tune[MMVAE_N_TUNE];
+    /* Optional (NULL = none; needs side_stream): called ON THE HOST by mmvae_forward / mmvae_train_step while they enqueue
+     * their work, right behind the first layer (fc1 + its epilogue), with the side stream forked from that point
+     * (ev[7]).  Whatever the callee enqueues on `stream` -- the row gather or H2D copy of the NEXT batch -- runs beside
+     * the latency-bound encoder chain, ahead of the step's own side-stream work, and is complete when the call's work on
+     * its main stream is (the step joins the side stream before its gradient reduction).  Issued from the caller's
+     * own code behind the call instead, such a copy reaches the device some 300 us into the step and lands beside
+     * the fc11 kernel. */
+    void (*at_mid)(void *user, void *stream);
+    void *at_mid_user;
 } mmvae_exec;
 
 /* Where things are, in floats.  Filled by mmvae_param_layout. Tensor order t = 0..27:
