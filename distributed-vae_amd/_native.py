@@ -168,6 +168,8 @@ def lib():
     L.mmvae_aug_pack.argtypes = [C.POINTER(AugDims), C.POINTER(AugTensors), vp, vp]
     L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, i32, ex, vp]
     L.mmvae_gather_rows.argtypes = [vp, i64, i64, vp, i64, i32, vp, vp]
+    L.mmvae_gather_rows_ex.argtypes = [vp, i64, i64, vp, i64, i32, vp, i32, vp]
+    L.mmvae_gather_rows_ex.restype = C.c_int
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_splits", "mmvae_forward", "mmvae_loss",
                "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",
                "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus", "mmvae_aug_pack",
@@ -438,8 +440,10 @@ def consensus(counts: torch.Tensor, want_norm: bool = False):
     return (out, norm) if want_norm else out
 
 
-def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[i] = data[idx[i]] for a 2-D float32 CUDA matrix (rows may be strided) and int64 CUDA indices."""
+def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None,
+                max_workgroups: int = 0) -> torch.Tensor:
+    """out[i] = data[idx[i]] for a 2-D float32 CUDA matrix (rows may be strided) and int64 CUDA indices;
+    ``max_workgroups`` > 0 caps the copy's grid (a copy running beside a train step: see mmvae_gather_rows_ex)."""
     if data.device.type != "cuda" or idx.device.type != "cuda":
         raise NativeError("gather_rows needs CUDA tensors (no CPU fallback)")
     assert data.dim() == 2 and data.dtype == torch.float32 and data.stride(1) == 1
@@ -448,8 +452,8 @@ def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tenso
     if out is None:
         out = torch.empty(n, Dm, dtype=torch.float32, device=data.device)
     if n:
-        check(lib().mmvae_gather_rows(_ptr(data), data.stride(0), data.shape[0], _ptr(idx), n, Dm, _ptr(out),
-                                      _stream(data.device)),
+        check(lib().mmvae_gather_rows_ex(_ptr(data), data.stride(0), data.shape[0], _ptr(idx), n, Dm, _ptr(out),
+                                         int(max_workgroups), _stream(data.device)),
               "mmvae_gather_rows")
     return out
 

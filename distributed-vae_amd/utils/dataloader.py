@@ -92,6 +92,9 @@ class DeviceLoader:
         # of 70-90 ms instead of 11).  A yielded batch stays valid until `ring` - 1 more batches have been drawn --
         # training loops consume a batch at once; ring = 0 returns a new tensor per batch, as a DataLoader does.
         self.ring = int(ring)
+        # cap of the row gather's grid, 0 = none: the trainer sets 512 while the gather runs beside its train step
+        # (mmvae_gather_rows_ex: slower alone, cheaper for the step's latency-bound chain kernels)
+        self.gather_workgroups = 0
         self._bufs = None
         self._slot = 0
         self._pin, self._pin_ev, self._pin_k, self._copy_stream = None, None, 0, None
@@ -196,11 +199,11 @@ class DeviceLoader:
                 xb, ib = self._bufs[self._slot]
                 self._slot = (self._slot + 1) % self.ring
                 xb, ib = xb[:r.numel()], ib[:r.numel()]
-                N.gather_rows(self.data, r, xb)
+                N.gather_rows(self.data, r, xb, max_workgroups=self.gather_workgroups)
                 ib.copy_(r)
                 yield xb, ib
             else:
-                yield N.gather_rows(self.data, r), r.to(torch.float32)
+                yield N.gather_rows(self.data, r, max_workgroups=self.gather_workgroups), r.to(torch.float32)
 
 
 def get_loaders(dataset, label: Sequence = [], seed=None, batch_size=128, train_size=0.9, use_dist_sampler=False,
