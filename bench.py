@@ -16,10 +16,14 @@ N>1 is plain data parallelism: each rank trains on its own shard of cells, ONE R
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   "roofline":     dominant kernel (fc11 forward + loss + dZ11 + d(d10) in one launch: k_x3_fc11g under the default fp32x3
-                  engine, k_fc11_zg under --gemm-dtype fp32_mfma), ALGORITHMIC fp32 FLOPs per launch / its average
-                  duration measured with HIP events on the launch stream, against the fp32 MFMA peak (157.3 TFLOP/s,
-                  MI355X_MICROARCH.md); under fp32x3 also "executed": the bf16 MFMAs actually issued (six slice products
-                  per product on padded tiles) against the bf16 matrix peak;
+                  engine, k_fc11_zg under --gemm-dtype fp32_mfma): ALGORITHMIC FLOPs (A 4 B D H) and bytes (A 8 B D) per
+                  launch / its average duration measured with HIP events on the launch stream.  `bound` / `achieved` /
+                  `peak` / `frac` are the BINDING roof for the engine in use -- the one that needs more time for the
+                  algorithmic work: HBM (8 TB/s) against the matrix pipe at the engine's ceiling (fp32 matrix instruction
+                  157.3 TFLOP/s; fp32x3: 2.5 PFLOP/s bf16 dense / 6 slice products = 416.7 TFLOP/s fp32-equivalent);
+                  "hbm" and "mfma" carry both fractions ("mfma.frac_of_fp32_mfma_peak" = rounds 1-2's figure), "executed"
+                  the bf16 MFMAs actually issued (six slice products on padded tiles), "step" the whole step against
+                  both roofs by SURVEY.md 8(d)'s per-cell arithmetic;
   "cpu_baseline": the oracle (oracle/restatement.py, kind "port": the reference's arithmetic restated,
                   pinned to the reference by tests/) timed on this box's host cores on the same workload.
 """
@@ -263,6 +267,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_ranks = None
+    backend = None
     if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -271,6 +276,7 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
+            backend = "gloo" if args.share_gpu else "nccl"
             if args.share_gpu:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             else:
@@ -280,7 +286,7 @@ def main():
             torch.cuda.synchronize()
             rccl_ranks = int(round(float(warm[0])))
             if rccl_ranks != dist.get_world_size() or rccl_ranks != world:
-                raise SystemExit(f"RCCL all-reduce saw {rccl_ranks} ranks, expected {world}")
+                raise SystemExit(f"{backend} all-reduce saw {rccl_ranks} ranks, expected {world}")
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
@@ -361,8 +367,16 @@ def main():
             roof = measure_stages(model, batches[0], A, B, D, H)
         except Exception as e:   # noqa: BLE001
             roof = {"error": f"{type(e).__name__}: {e}"}
-        roof["step_flops_frac_of_fp32_mfma_peak"] = cells_per_s / world * fl_cell / (PEAK_FP32_MFMA_TFLOPS * 1e12)
-        roof["step_bytes_frac_of_hbm_peak"] = cells_per_s / world * by_cell / (PEAK_HBM_GBS * 1e9)
+        # the whole step by SURVEY.md section 8(d)'s arithmetic, with the engine in use: ns per cell each roof allows
+        eng_peak = roof.get("mfma", {}).get("engine_peak", PEAK_FP32_MFMA_TFLOPS)
+        t_m, t_h = fl_cell / (eng_peak * 1e12), by_cell / (PEAK_HBM_GBS * 1e9)
+        per_gpu = cells_per_s / world
+        roof["step"] = {"bound": "hbm" if t_h >= t_m else "mfma", "ns_per_cell_hbm_roof": t_h * 1e9,
+                        "ns_per_cell_mfma_roof": t_m * 1e9, "ns_per_cell_measured": 1e9 / per_gpu,
+                        "frac": per_gpu * max(t_h, t_m),
+                        "bytes_frac_of_hbm_peak": per_gpu * t_h, "flops_frac_of_engine_peak": per_gpu * t_m}
+        roof["step_flops_frac_of_fp32_mfma_peak"] = per_gpu * fl_cell / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+        roof["step_bytes_frac_of_hbm_peak"] = per_gpu * by_cell / (PEAK_HBM_GBS * 1e9)
 
     out = {
         "metric": "cells/sec per train step (fwd+loss+bwd+opt)",
@@ -387,7 +401,10 @@ def main():
                    "flop_per_cell": fl_cell, "bytes_per_cell": by_cell, "last_loss": loss_last},
     }
     if rccl_ranks is not None:
-        out["rccl_ranks"] = rccl_ranks
+        # ranks that contributed to a real all-reduce, and through which backend ("nccl" is RCCL on ROCm; "gloo" only in
+        # the --share-gpu rehearsal, which is not an RCCL observation)
+        out["collective_ranks"] = rccl_ranks
+        out["collective_backend"] = "rccl (torch.distributed nccl)" if backend == "nccl" else backend
     if args.gemm_dtype != "bf16" and not args.no_bf16:
         # BASELINE.json configs[2] beside the headline: the same step with bf16 operands in the five D x H GEMMs
         try:
@@ -651,12 +668,13 @@ def measure_stages(model, x, A, B, D, H):
     eng.loss(hyper)
     eng.backward(hyper, noise, model._flat, x, 0, model._flat_grad)
     stream = torch.cuda.current_stream()
-    res = {}
+    res, sid_of = {}, {}
     for sid, (names, fl, by, crit) in STAGES.items():
         # fc_dim 100 runs the 96 + 4 column kernels (v3), any other width the 128-wide tiles (v2)
         name = names.split("|")[0 if (H == 100 or "|" not in names) else 1]
         if x3:
             name = STAGES_X3[sid]
+        sid_of[name] = sid
         for _ in range(3):
             eng.debug_stage(sid, hyper, noise, model._flat, x, 0)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -670,19 +688,44 @@ def measure_stages(model, x, A, B, D, H):
         res[name] = {"avg_launch_ms": ms, "tflops": fl(A, B, D, H) / (ms * 1e-3) / 1e12,
                      "algorithmic_GBs": by(A, B, D, H) / (ms * 1e-3) / 1e9, "critical_path": crit}
     dom = max((k for k in res if res[k]["critical_path"]), key=lambda k: res[k]["avg_launch_ms"])
-    ach = res[dom]["tflops"]
+    dom_sid = sid_of[dom]
+    t_s = res[dom]["avg_launch_ms"] * 1e-3
+    fl_launch, by_launch = STAGES[dom_sid][1](A, B, D, H), STAGES[dom_sid][2](A, B, D, H)
+    bf16_engine = (hyper.gemm_bf16 & 0xFF) == 1
+    # The ceiling of the matrix pipe FOR THE ENGINE IN USE: the fp32 matrix instruction runs at 157.3 TFLOP/s; the fp32x3
+    # engine forms an fp32 product from six bf16 slice products on the bf16 pipe (2.5 PFLOP/s dense / 6 = 416.7 TFLOP/s of
+    # fp32-equivalent work); bf16 operands run at the bf16 peak.  The kernel's binding roof is the one that takes longer
+    # for its ALGORITHMIC work (per launch A 4 B D H FLOP and A 8 B D bytes for the fused fc11 kernel).
+    engine_peak = PEAK_BF16_MFMA_TFLOPS if bf16_engine else (PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_FP32_MFMA_TFLOPS)
+    t_mfma, t_hbm = fl_launch / (engine_peak * 1e12), by_launch / (PEAK_HBM_GBS * 1e9)
+    ach_tf, ach_gbs = fl_launch / t_s / 1e12, by_launch / t_s / 1e9
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
     traffic, src = pmc_traffic(dom, A, B, D, H)
-    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-           "traffic_source": src, "avg_launch_ms": res[dom]["avg_launch_ms"], "stages": res}
+    out = {"bound": bound, "kernel": dom,
+           "achieved": ach_gbs if bound == "hbm" else ach_tf,
+           "peak": PEAK_HBM_GBS if bound == "hbm" else engine_peak,
+           "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+           "frac": ach_gbs / PEAK_HBM_GBS if bound == "hbm" else ach_tf / engine_peak,
+           "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": src,
+           "avg_launch_ms": res[dom]["avg_launch_ms"],
+           "algorithmic_flop_per_launch": fl_launch, "algorithmic_bytes_per_launch": by_launch,
+           "roof_times_us": {"mfma_engine": t_mfma * 1e6, "hbm": t_hbm * 1e6},
+           "hbm": {"achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_gbs / PEAK_HBM_GBS},
+           "mfma": {"achieved": ach_tf, "unit": "TFLOP/s (algorithmic fp32 FLOPs)", "engine_peak": engine_peak,
+                    "frac_of_engine_peak": ach_tf / engine_peak, "peak_fp32_mfma": PEAK_FP32_MFMA_TFLOPS,
+                    # continuity with rounds 1-2 (which priced every engine against the fp32 matrix instruction's peak;
+                    # under fp32x3 that ratio can exceed 1 and is not a distance to any roof)
+                    "frac_of_fp32_mfma_peak": ach_tf / PEAK_FP32_MFMA_TFLOPS},
+           "stages": res}
+    for k, r in res.items():
+        r["frac_of_engine_peak"] = r["tflops"] / engine_peak
+        r["frac_of_hbm_peak"] = r["algorithmic_GBs"] / PEAK_HBM_GBS
     if x3:
-        # `achieved` / `frac` stay ALGORITHMIC fp32 FLOPs against the fp32 matrix peak (the contract's pricing).  What the
-        # kernel executes is six bf16 MFMAs per pair of fragments on padded tiles (k_x3_fc11g: 90 v_mfma_f32_32x32x16_bf16
-        # per wave and piece of 32 cells x 32 genes); against the bf16 matrix peak:
+        # what the kernel executes: six bf16 MFMAs per pair of fragments on padded tiles (k_x3_fc11g: 90
+        # v_mfma_f32_32x32x16_bf16 per wave and piece of 32 cells x 32 genes); against the bf16 matrix peak:
         ex_fl = A * (4 * ((B + 127) // 128)) * (2 * ((D + 63) // 64)) * 90 * 32768.0 if dom == "k_x3_fc11g" else None
         out["engine"] = "fp32x3 (fp32 operands as three exact bf16 slices, six slice products per product)"
         if ex_fl:
-            t_s = res[dom]["avg_launch_ms"] * 1e-3
             out["executed"] = {"mfma_tflops": ex_fl / t_s / 1e12, "peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS,
                                "frac_of_bf16_mfma_peak": ex_fl / t_s / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                                "executed_over_algorithmic_flops": ex_fl / STAGES[1][1](A, B, D, H)}
@@ -692,7 +735,7 @@ def measure_stages(model, x, A, B, D, H):
     return out
 
 
-PMC_ROUND = "r02"
+PMC_ROUND = "r03"
 
 
 def _pmc_rows(kind, A, B, D, H):

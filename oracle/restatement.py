@@ -166,14 +166,31 @@ def _bn(r: Tensor, sd, key: str, h: Hyper, training: bool, update: bool):
 
 def forward(sd: Dict[str, Tensor], xs: Sequence[Tensor], h: Hyper, noise, *,
             temp: Optional[float] = None, training: bool = True, eval_flag: bool = False,
-            update_running: bool = True, keep: bool = False):
+            update_running: bool = True, keep: bool = False, relu_override=None):
     """``mixVAE_model.forward`` (nn_model.py:297-368) with explicit noise.
 
     Returns the reference's 10-tuple; with ``keep`` also a per-arm dict of the
-    intermediates the HIP kernels save for backward.
+    intermediates the HIP kernels save for backward (and the pre-activation
+    ``z<site>`` of every ReLU, sites ``r1..r5``, ``d6..d10``, ``x_rec``).
+
+    ``relu_override``: ``{(arm, site): bool tensor}`` -- decisions forced on the
+    ReLU of that site (``relu(z)`` becomes ``z * mask``, so the gradient flows
+    exactly where the mask says).  Test infrastructure for full-size parity: a
+    pre-activation within fp32 rounding of zero is decided either way by ANY
+    fp32 evaluation, and ONE differing decision moves every bias gradient below
+    it; a test that has read the device's decisions evaluates the reference
+    arithmetic (nn_model.py:263-287) on exactly those decisions and can then
+    hold every tensor to the tight gate.
     """
     temp = h.temp if temp is None else temp
     eps = h.eps
+
+    def _relu(z, a, site, iv):
+        if keep:
+            iv["z" + site] = z.detach()
+        if relu_override is not None and (a, site) in relu_override:
+            return z * relu_override[(a, site)].to(z.dtype)
+        return F.relu(z)
     x_recs, x_lows, cs, s_smps, c_smps, s_means, s_logvars, c_probs = ([] for _ in range(8))
     saved = []
     for a, x in enumerate(xs):
@@ -187,7 +204,7 @@ def forward(sd: Dict[str, Tensor], xs: Sequence[Tensor], h: Hyper, noise, *,
             xt = x
         hcur = xt
         for i, name in enumerate(["fc1", "fc2", "fc3", "fc4", "fc5"], start=1):
-            r = F.relu(F.linear(hcur, W(name), b(name)))
+            r = _relu(F.linear(hcur, W(name), b(name)), a, f"r{i}", iv)
             hcur, mean, rstd = _bn(r, sd, f"batch_l{i}.{a}", h, training, update_running)
             iv[f"r{i}"], iv[f"mean{i}"], iv[f"rstd{i}"] = r, mean, rstd
         x_low = hcur
@@ -225,9 +242,9 @@ def forward(sd: Dict[str, Tensor], xs: Sequence[Tensor], h: Hyper, noise, *,
         z = torch.cat((c_smp, s_in), dim=1)
         d = z
         for i, name in enumerate(["fc6", "fc7", "fc8", "fc9", "fc10"], start=6):
-            d = F.relu(F.linear(d, W(name), b(name)))
+            d = _relu(F.linear(d, W(name), b(name)), a, f"d{i}", iv)
             iv[f"d{i}"] = d
-        x_rec = F.relu(F.linear(d, W("fc11"), b("fc11")))
+        x_rec = _relu(F.linear(d, W("fc11"), b("fc11")), a, "x_rec", iv)
 
         x_recs.append(x_rec); x_lows.append(x_low); cs.append(c); s_smps.append(s_smp)
         c_smps.append(c_smp); s_means.append(s_mean); s_logvars.append(s_logvar); c_probs.append(c_prob)
@@ -355,6 +372,10 @@ def grads_manual(sd, xs, h: Hyper, noise, **fw):
         lt = loss(out, xs, h)
         x_recs, _, _, x_lows, cs, s_smps, c_smps, s_means, s_logvars, c_probs = out
         A, eps, B = h.n_arm, h.eps, xs[0].shape[0]
+        ovr = fw.get("relu_override") or {}
+
+        def on(a_, site, val):   # ReLU decisions: the forced ones where given, else the sign of the value
+            return (ovr[(a_, site)] if (a_, site) in ovr else (val > 0)).to(val.dtype)
         temp = fw.get("temp") or h.temp
         am1 = float(max(A - 1, 1))
         L, C, S = h.lowD_dim, h.n_categories, h.state_dim
@@ -373,7 +394,7 @@ def grads_manual(sd, xs, h: Hyper, noise, **fw):
             W = lambda n: sd[f"{n}.{a}.weight"]
             x = xs[a]
             # ---- reconstruction: d total / d x_rec = (A-1)' (x_rec - x)/B, through ReLU
-            gz11 = am1 * (x_recs[a] - x) / B * (x_recs[a] > 0).to(x.dtype)
+            gz11 = am1 * (x_recs[a] - x) / B * on(a, "x_rec", x_recs[a])
             grads[f"fc11.{a}.weight"] = gz11.t() @ sv["d10"]
             grads[f"fc11.{a}.bias"] = gz11.sum(0)
             gd = gz11 @ W("fc11")
@@ -381,7 +402,7 @@ def grads_manual(sd, xs, h: Hyper, noise, **fw):
             # ---- decoder fc10..fc6
             for i in (10, 9, 8, 7, 6):
                 name = f"fc{i}"
-                dz = gd * (sv[f"d{i}"] > 0).to(x.dtype)
+                dz = gd * on(a, f"d{i}", sv[f"d{i}"])
                 xin = sv[f"d{i-1}"] if i > 6 else sv["z"]
                 grads[f"{name}.{a}.weight"] = dz.t() @ xin
                 grads[f"{name}.{a}.bias"] = dz.sum(0)
@@ -439,7 +460,7 @@ def grads_manual(sd, xs, h: Hyper, noise, **fw):
                 name = f"fc{i}"
                 r = sv[f"r{i}"]
                 gr = _bn_bwd(g_h, r, sv[f"mean{i}"], sv[f"rstd{i}"])
-                dz = gr * (r > 0).to(x.dtype)
+                dz = gr * on(a, f"r{i}", r)
                 if i > 1:
                     rp = sv[f"r{i-1}"]
                     xin = (rp - sv[f"mean{i-1}"]) * sv[f"rstd{i-1}"]

@@ -50,3 +50,101 @@ def run_step(m, x, noise, temp=1.0, eval_flag=False, backward=True):
 
 def ws(m, name, width):
     return m._engine.ws_view(name, width).detach().cpu().clone()
+
+
+# ---------------------------------------------------------------------------------------------------
+# Flip-aware reference for the full-size parity gates.
+#
+# At B = 5000 a step takes ~4 M hidden ReLU decisions per arm (r1..r5, d6..d10) and 25 M at fc11.  A pre-activation within
+# fp32 rounding of zero is decided either way by ANY fp32 evaluation order, and one differing hidden decision moves the
+# back-propagated row of its cell, i.e. every entry of the bias gradients below it.  Instead of loosening the gate for the
+# small tensors, the oracle is evaluated on the decisions the DEVICE took: the test reads the device's decision patterns
+# from the workspace, checks that every decision that differs from the fp64 oracle's belongs to a pre-activation within
+# rounding of zero (and that there are only a handful), forces exactly those in the oracle
+# (oracle/restatement.py::forward(relu_override=...)) and then holds every tensor -- bias gradients included -- to the
+# tight gate.  Reference arithmetic: mmidas/nn_model.py:263-287.
+HIDDEN_SITES = ("r1", "r2", "r3", "r4", "r5", "d6", "d7", "d8", "d9", "d10")
+
+
+def _site_width(h, site):
+    return h.lowD_dim if site in ("r5", "d6") else h.fc_dim
+
+
+def device_relu_patterns(eng, h):
+    """{site: bool [A,B,W] (cpu)} for the hidden ReLUs, from the post-ReLU activations the engine keeps for backward;
+    site "x_rec": from dZ11 (non-zero where the fc11 pre-activation was positive, up to z == x coincidences)."""
+    pat = {s: (eng.ws_view(s, _site_width(h, s)) > 0).cpu() for s in HIDDEN_SITES}
+    pat["x_rec"] = (eng.ws_view("dz11", h.input_dim) != 0).cpu()
+    return pat
+
+
+def flip_aware_oracle(h, sd, x, noise, patterns, max_hidden=None, verbose=True):
+    """fp32 and fp64 oracle gradients of one step evaluated on the device's ReLU decisions.
+
+    Returns dict(lt_32, g_32, lt_64, g_64, saved64, k_hidden, k_fc11, flips=[(arm, site, row, col, z64)], override,
+    d10_32 = the un-forced fp32 oracle's d10).
+    Asserts: every differing hidden decision has |z64| within max(1e-5 of the site's scale, 4 x the fp32 oracle's own
+    distance from fp64 in that cell); at most max(8, 4 A) hidden decisions differ; at fc11 at most 64 A near-zero ones and 16 elsewhere
+    (z == x coincidences of the pattern read from dZ11, left at the oracle's decision)."""
+    A, B = h.n_arm, x.shape[0]
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    n64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in noise.items()}
+    with torch.no_grad():
+        _, saved64 = R.forward({k: v.clone() for k, v in sd64.items()}, [x.double()] * A, h, n64, keep=True)
+        _, saved32 = R.forward({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise, keep=True)
+    override, flips, d10_32 = {}, [], []
+    k_hidden = k_fc11 = k_far11 = 0
+    for a in range(A):
+        for site in HIDDEN_SITES + ("x_rec",):
+            z64 = saved64[a]["z" + site]
+            scale = float(z64.abs().max())
+            # "within fp32 rounding of zero", per cell: the fp32 CPU oracle's own distance from fp64 in that cell's row of
+            # the site is the noise floor of ANY fp32 evaluation there (a cell whose c_smp sits at a category boundary of the
+            # tau = 0.005 softmax carries ~1e-4 of the scale into d6..d10, most cells 1e-7)
+            floor_row = (saved32[a]["z" + site].double() - z64).abs().amax(dim=1, keepdim=True)
+            own = z64 > 0
+            dev = patterns[site][a]
+            diff = dev != own
+            near = z64.abs() <= torch.maximum(4.0 * floor_row, torch.full_like(floor_row, 1e-5 * scale))
+            tol = float((4.0 * floor_row.max()) / scale)
+            if site == "x_rec":
+                k_fc11 += int((diff & near).sum())
+                k_far11 += int((diff & ~near).sum())
+            else:
+                far = diff & ~near
+                assert not bool(far.any()), (a, site, int(far.sum()), float(z64[far].abs().max()), tol * scale)
+                k_hidden += int(diff.sum())
+            if bool((diff & near).any()):
+                for r, c in (diff & near).nonzero().tolist()[:32]:
+                    flips.append((a, site, r, c, float(z64[r, c])))
+            override[(a, site)] = torch.where(near, dev, own)
+        d10_32.append(saved32[a]["d10"])
+        saved32[a] = None
+    del saved32
+    if verbose:
+        print(f"ReLU decisions differing from the fp64 oracle: hidden {k_hidden}, fc11 near zero {k_fc11}, "
+              f"fc11 elsewhere {k_far11}; first: {flips[:6]}")
+    assert k_hidden <= (max_hidden if max_hidden is not None else max(8, 4 * A)), k_hidden
+    assert k_fc11 <= 64 * A and k_far11 <= 16, (k_fc11, k_far11)
+    _, lt_32, g_32 = R.grads_autograd({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise, relu_override=override)
+    _, lt_64, g_64 = R.grads_autograd({k: v.clone() for k, v in sd64.items()}, [x.double()] * A, h, n64,
+                                      relu_override=override)
+    return dict(lt_32=lt_32, g_32=g_32, lt_64=lt_64, g_64=g_64, saved64=saved64, k_hidden=k_hidden, k_fc11=k_fc11,
+                flips=flips, override=override, d10_32=torch.stack(d10_32))
+
+
+def assert_gradients_tight(grads, fo, grad_tol=1e-3):
+    """The round-1 gate for EVERY tensor, bias gradients included, against the oracle on the device's decisions:
+    90th-percentile entry error below max(3 x the fp32 CPU oracle's, 1e-4) of the tensor's scale, worst entry below
+    5 x grad_tol, and at most max(3, 1 %) of the entries above max(grad_tol / 4, 2 x the fp32 oracle's worst)."""
+    def p90(e):
+        return float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
+    for k, v in grads.items():
+        ref = fo["g_64"][k]
+        sc = float(ref.abs().max()) + 1e-30
+        e_gpu = ((v.double() - ref).abs() / sc).flatten()
+        e_cpu = ((fo["g_32"][k].double() - ref).abs() / sc).flatten()
+        assert p90(e_gpu) < max(3.0 * p90(e_cpu), 1e-4), (k, p90(e_gpu), p90(e_cpu))
+        assert float(e_gpu.max()) < 5 * grad_tol, (k, float(e_gpu.max()))
+        thr = max(grad_tol / 4, 2.0 * float(e_cpu.max()))
+        assert int((e_gpu > thr).sum()) <= max(3, e_gpu.numel() // 100), (k, thr, float(e_gpu.max()))

@@ -155,3 +155,73 @@ def test_split_configuration_at_full_size_is_as_close_to_the_fp64_oracle_as_the_
         floor = 1e-5 if flips == 0 else (1e-4 if big else 1e-3 / 3)
         assert q3 < max(floor, 3.0 * q0), k
         assert m3e < (5e-3 if flips == 0 else 2e-2), k   # a flipped cell's own row: up to its share of the gradient
+
+
+@pytest.mark.parametrize("dtype", ["fp32x3", "fp32_mfma"])
+def test_denormal_and_infinite_operands_through_the_split(dtype):
+    """Operands the exact three-slice split does not represent like fp32 does, against torch (fc1: nn_model.py:264).
+
+    Denormals (|v| < 2^-126) in x and W1: bf16 has fp32's exponent range, so the slices keep a denormal's leading bits or
+    flush it -- either way its products are below 1e-38 * max|w| and the result must equal torch's to the usual bound.
+    +-inf: bf16(inf) = inf and inf - inf = NaN, so the second and third slices of an infinite operand are NaN and every
+    product it enters is NaN, where torch's fp32 product is +-inf (0 after the ReLU for -inf).  The documented contract:
+    a non-finite operand makes its cell's / unit's results non-finite (the loss is non-finite in both), a finite row
+    beside it is not touched.  Checked on r1 = relu(fc1(x_dp)) of the cells without the infinity and on the loss."""
+    from tests import gpu_util as U
+    A, B, D, H = 2, 130, 192, 100
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=12, state_dim=2, lowD_dim=6, n_arm=A)
+    sd = R.init_state_dict(h, 5)
+    x = R.synthetic_batch(B, D, seed=6)
+    noise = R.draw_noise(h, B, seed=7)
+    keep = 1.0 / (1.0 - h.x_drop)
+    for a in range(A):                     # the special entries are kept by the input dropout (a dropped inf is NaN in torch: inf * 0)
+        noise["x_mask"][a][3, :4] = 1
+        noise["x_mask"][a][7, 10:14] = 1
+        noise["x_mask"][a][11, 17] = 1
+    tiny = torch.tensor([1e-39, -3e-40, 1.1754942e-38, 1e-45], dtype=torch.float32)     # denormals (and the largest one)
+    x[3, :4] = tiny
+    x[7, 10:14] = tiny * 3
+    for a in range(A):
+        sd[f"fc1.{a}.weight"][5, :4] = tiny
+        sd[f"fc1.{a}.weight"][6, 20:24] = -tiny
+    want = {}
+    for a in range(A):
+        xm = (x * noise["x_mask"][a].float()).double()
+        want[a] = torch.relu(keep * (xm @ sd[f"fc1.{a}.weight"].double().t()) + sd[f"fc1.{a}.bias"].double())
+
+    def r1_of(xin, sd_):
+        m = U.build_model(h, sd_)
+        m.train()
+        m.gemm_dtype = dtype
+        m.set_explicit_noise(U.noise_to_device(noise))
+        buf = m.fused_train_step(xin.to(DEV).expand(A, -1, -1), 1.0, None, do_adam=False).clone()
+        torch.cuda.synchronize()
+        return m._engine.ws_view("r1", H).cpu().double(), buf.cpu()
+
+    r1, buf = r1_of(x, sd)
+    assert bool(torch.isfinite(buf).all())
+    for a in range(A):
+        assert _rel(r1[a], want[a]) < ABS_TOL, (a, _rel(r1[a], want[a]))
+    # the same batch with +inf in one cell of x and -inf in one weight of unit 9 of arm 1
+    xi = x.clone()
+    xi[11, 17] = float("inf")
+    sdi = {k: v.clone() for k, v in sd.items()}
+    sdi["fc1.1.weight"][9, 40] = float("-inf")
+    r1i, bufi = r1_of(xi, sdi)
+    xdp = lambda a_: xi * noise["x_mask"][a_].float() * keep                                  # nn.Dropout, torch fp32
+    t_ref = torch.relu(torch.nn.functional.linear(xdp(1), sdi["fc1.1.weight"], sdi["fc1.1.bias"]))
+    assert not bool(torch.isfinite(t_ref[11]).all()) and not bool(torch.isfinite(t_ref[:, 9]).all())
+    assert not bool(torch.isfinite(bufi[0]))                       # the loss is lost, as the reference's is
+    rows = [b for b in range(B) if b != 11]
+    cols = [c for c in range(H) if c != 9]
+    # arm 0: only cell 11 is affected; arm 1: cell 11 and unit 9 (every cell with a non-zero gene 40)
+    for a, cs in ((0, list(range(H))), (1, cols)):
+        got, ref = r1i[a][rows][:, cs], want[a][rows][:, cs]
+        assert bool(torch.isfinite(got).all()), a
+        assert _rel(got, ref) < ABS_TOL, (a, _rel(got, ref))
+    # the affected cell / unit: an entry is non-finite, or it is what torch's fp32 arithmetic gives (0 behind the ReLU of -inf)
+    t_ref0 = torch.relu(torch.nn.functional.linear(xdp(0), sdi["fc1.0.weight"], sdi["fc1.0.bias"])).double()
+    for got, ref in ((r1i[0][11], t_ref0[11]), (r1i[1][:, 9], t_ref[:, 9].double()), (r1i[1][11], t_ref[11].double())):
+        fin = torch.isfinite(got)
+        assert bool((got[fin] == ref[fin]).all())
+        assert not bool(fin.all())

@@ -510,28 +510,14 @@ def test_full_size_against_oracle(full):
     flipped decision moves one row of a weight gradient by ~1e-4..1e-3 of its scale in ANY fp32
     evaluation order (tools/gpu_err_stats.py prints the statistics for both sides)."""
     U, h, sd, x, noise, m = full
-    A = h.n_arm
-    _, lt_r, g_r = R.grads_autograd({k: v.clone() for k, v in sd.items()}, [x] * A, h, noise)
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    n64 = {k: [t.double() if t.is_floating_point() else t for t in v] for k, v in noise.items()}
-    _, lt_64, g_64 = R.grads_autograd(sd64, [x.double()] * A, h, n64)
     out, lt, grads = U.run_step(m, x.to(U.DEV), noise)
-    _loss_close(lt[0], lt_64[0])
-    _loss_close(lt[0], lt_r[0])
-    assert G.rel_err(lt[1].cpu(), lt_64[1]) < LOSS_TOL
-    p90 = lambda e: float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
-    for k, v in grads.items():
-        ref = g_64[k]
-        sc = float(ref.abs().max()) + 1e-30
-        e_gpu = ((v.double() - ref).abs() / sc).flatten()
-        e_cpu = ((g_r[k].double() - ref).abs() / sc).flatten()
-        assert p90(e_gpu) < max(3.0 * p90(e_cpu), 1e-4), (k, p90(e_gpu), p90(e_cpu))
-        assert float(e_gpu.max()) < 5 * GRAD_TOL, (k, float(e_gpu.max()))
-        # beyond a quarter of the stated gradient tolerance only isolated elements (ReLU flips) may lie; batch-summed
-        # tensors such as fc1.bias collect every flip of 5000 cells, and how many there are moves with the fp32
-        # accumulation order (split-K count) of the fc1 GEMM
-        thr = max(GRAD_TOL / 4, 2.0 * float(e_cpu.max()))
-        assert int((e_gpu > thr).sum()) <= max(3, e_gpu.numel() // 100), (k, thr, float(e_gpu.max()))
+    # the oracle on the device's own ReLU decisions (tests/gpu_util.py::flip_aware_oracle: a decision may differ from the
+    # fp64 oracle's only at a pre-activation within fp32 rounding of zero, at most 8 hidden ones do)
+    fo = U.flip_aware_oracle(h, sd, x, noise, U.device_relu_patterns(m._engine, h))
+    _loss_close(lt[0], fo["lt_64"][0])
+    _loss_close(lt[0], fo["lt_32"][0])
+    assert G.rel_err(lt[1].cpu(), fo["lt_64"][1]) < LOSS_TOL
+    U.assert_gradients_tight(grads, fo, GRAD_TOL)
 
 
 def test_full_size_properties(full):
@@ -564,16 +550,22 @@ def test_full_size_properties(full):
     _, lt4, g4 = U.run_step(m4, xd, noise)
     assert m4._engine.splits()[:4] == [3, 5, 7, 9]
     _loss_close(lt4[0], lt1[0], 1e-6)
-    # summation-order noise only -- which, through ReLU decisions that sit within fp32 rounding of zero, shows up as a
-    # few isolated elements: same two-part bound as test_full_size_against_oracle (typical element tight, worst loose)
-    # (tensors under 1000 entries -- bias gradients -- are sums over the whole batch: ONE flipped decision moves every entry
-    # of the biases below it, so they are held to a third of the gradient tolerance at the median, as in
-    # tests/test_gpu_fullsize.py; seen at 1.004e-4 for fc1.1.bias on the fp32 matrix-instruction engine)
-    for k in g1:
-        e = ((g4[k].double() - g1[k].double()).abs() / (float(g1[k].abs().max()) + 1e-30)).flatten()
-        small = e.numel() < 1000
-        q = float(e.kthvalue(max(1, int((0.5 if small else 0.9) * e.numel()))).values)
-        assert q < (GRAD_TOL / 3 if small else 1e-4) and float(e.max()) < 5 * GRAD_TOL, (k, q, float(e.max()))
+    # summation-order noise only.  A pre-activation within fp32 rounding of zero may be decided differently under another
+    # summation order, and one differing hidden decision moves every bias gradient below it: when the two runs took the
+    # same hidden decisions everywhere, EVERY tensor is held to the tight bound against the first run; otherwise the
+    # second run is held to the flip-aware oracle gate by itself (as the first is in test_full_size_against_oracle)
+    p1, p4 = U.device_relu_patterns(m._engine, h), U.device_relu_patterns(m4._engine, h)
+    k_diff = sum(int((p1[s_] != p4[s_]).sum()) for s_ in U.HIDDEN_SITES)
+    print("hidden ReLU decisions that differ between the two split settings:", k_diff)
+    assert k_diff <= 8
+    if k_diff == 0:
+        for k in g1:
+            e = ((g4[k].double() - g1[k].double()).abs() / (float(g1[k].abs().max()) + 1e-30)).flatten()
+            q = float(e.kthvalue(max(1, int(0.9 * e.numel()))).values)
+            assert q < 1e-4 and float(e.max()) < 5 * GRAD_TOL, (k, q, float(e.max()))
+    else:
+        U.assert_gradients_tight(g4, U.flip_aware_oracle(h, sd, x, noise, p4), GRAD_TOL)
+    del p1, p4
     # the fused train step (fused fc11 / d(d10) kernel, side stream) against the separately-called API path
     m6 = U.build_model(h, sd); m6.train()
     m6.set_explicit_noise(U.noise_to_device(noise))
