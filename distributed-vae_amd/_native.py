@@ -31,7 +31,7 @@ BN_NAMES = ["batch_l1", "batch_l2", "batch_l3", "batch_l4", "batch_l5", "batch_s
 WS_IDS = {name: i for i, name in enumerate([
     "x_low", "c_prob", "c", "c_smp", "s_mean", "s_logvar", "s_smp", "y_soft",
     "r1", "r2", "r3", "r4", "r5", "d6", "d7", "d8", "d9", "d10", "zin", "dz11", "dz1", "gzin", "gzc", "g5",
-    "bn_mean1", "gd10_slab",
+    "bn_mean1", "gd10_slab", "g1", "g2", "g3", "g4", "dz2", "dz3", "dz4", "dz5",
 ])}
 
 LOSS_TOTAL, LOSS_JOINT, LOSS_CENT, LOSS_CDIST, LOSS_CL2, LOSS_REC0 = 0, 1, 2, 3, 4, 5
@@ -81,7 +81,7 @@ TUNE_ENV = {
     "MMVAE_FC11_NSZ": (10, int), "MMVAE_GD10_V2": (11, int), "MMVAE_DW1_V2": (12, int), "MMVAE_DW11_V2": (13, int),
     "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_ABLATE_B": (16, int),
     "MMVAE_BN_PARTIALS": (19, int), "MMVAE_PRESPLIT_ALL": (20, int), "MMVAE_CHAIN_FP32": (21, int),
-    "MMVAE_REDUCE11_MAIN": (22, int),
+    "MMVAE_REDUCE11_MAIN": (22, int), "MMVAE_FUSED_CHAIN": (23, int),
 }
 TUNE_ENGINE = 17    # MMVAE_TUNE_ENGINE: the GEMM engine the caller runs (the layout's split factors are chosen for it)
 TUNE_MID_EVENT = 18  # MMVAE_TUNE_MID_EVENT: record ev[7] behind fc1 (see Engine.mid_event)

@@ -162,7 +162,10 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.fc1_slab = take((int64_t)L.sp.ks_fc1 * A * B * NP);
     L.n11 = (L.nblk64 + 2) * (max(L.sp.ns_fc11, L.sp.ks_gd10) + 1) + cdiv(d.D, 64);
     L.fc11_part = take(A * (int64_t)L.n11 * 2 + 64);   // + diagnostic stamp counters
-    L.acc = take((int64_t)ACC_NSETS * A * ACC_SET_FLOATS);   // directly behind fc11_part: one zero fill at the start of a forward pass
+    L.sync_arm_words = rup(4 * rup(L.nblkc, 32) + 2 * 4 * 32, 64);
+    L.sync_fwd = take(A * (int64_t)L.sync_arm_words);
+    L.acc = take((int64_t)ACC_NSETS * A * ACC_SET_FLOATS);   // behind fc11_part and sync_fwd: one zero fill at the start of a forward pass
+    L.sync_bwd = take(A * (int64_t)L.sync_arm_words);       // directly behind the backward accumulator sets: one zero fill
     L.GD10_slab = take((int64_t)max(L.sp.ns_fc11, L.sp.ks_gd10) * A * B * H);
     L.DZ11 = take(A * B * D);
     L.couple_part = take(nb * 2);
@@ -309,6 +312,8 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     if ((rc = launch_bn_eval_stats(c, bn_running))) return rc;
     if (!c.h.training && !c.tune(MMVAE_TUNE_EVAL_CHAIN_OFF)) {
         if ((rc = launch_chain_fwd_enc_eval(c, params))) return rc;
+    } else if (enc_fused_ok(c)) {
+        if ((rc = launch_chain_fwd_enc_fused(c, params, bn_running, nbt))) return rc;
     } else {
         for (int layer = 2; layer <= 5; ++layer)
             if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
@@ -408,8 +413,12 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     if (wait_loss && (rc = join_from_side(c, EV_COUPLE))) return rc;
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
     if (use_side && dw11_at == 2 && (rc = fork_dw11())) return rc;   // (3: not forked -- dW11 behind dW1 on the main stream)
-    for (int layer = 5; layer >= 2; --layer)
-        if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
+    if (enc_bwd_fused_ok(c)) {
+        if ((rc = launch_chain_bwd_enc_fused(c, params))) return rc;
+    } else {
+        for (int layer = 5; layer >= 2; --layer)
+            if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
+    }
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
     if (small_on_side) {
         if ((rc = fork_to_side(c, EV_ENC))) return rc;
@@ -488,6 +497,8 @@ int64_t mmvae_ws_offset(const mmvae_dims* d, const mmvae_exec* ex, int id) {
         case MMVAE_WS_G5: return L.G[5];
         case MMVAE_WS_BN_MEAN1: return L.bn_mean[0];
         case MMVAE_WS_GD10_SLAB: return L.GD10_slab;
+        case MMVAE_WS_G1: case MMVAE_WS_G2: case MMVAE_WS_G3: case MMVAE_WS_G4: return L.G[1 + id - MMVAE_WS_G1];
+        case MMVAE_WS_DZ2: case MMVAE_WS_DZ3: case MMVAE_WS_DZ4: case MMVAE_WS_DZ5: return L.DZ[2 + id - MMVAE_WS_DZ2];
         default: set_error("unknown workspace id %d", id); return -1;
     }
 }
@@ -641,6 +652,12 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
         case 9: return launch_make_xbits(c, nz);
         case 20: return launch_chain_fwd_enc(c, 3, params, nullptr, nullptr);   // one encoder layer (fc3)
         case 21: return launch_chain_bwd_enc(c, 3, params);
+        // the encoder chains as one launch each (timing only: replayed on their own they add to the accumulator sets a complete
+        // pass has left behind)
+        case 22: if (!enc_fused_ok(c)) { set_error("stage 22 needs the one-launch encoder chain"); return MMVAE_E_UNSUPPORTED; }
+                 return launch_chain_fwd_enc_fused(c, params, nullptr, nullptr);
+        case 23: if (!enc_bwd_fused_ok(c)) { set_error("stage 23 needs the one-launch encoder chain"); return MMVAE_E_UNSUPPORTED; }
+                 return launch_chain_bwd_enc_fused(c, params);
         // single kernels of the fast path (per-kernel roofline timing)
         case 10: case 11: case 12: case 13: case 14:
             if (!fast_path_ok(c, params, x, x_arm_stride)) { set_error("stage %d needs the fast path", stage); return MMVAE_E_UNSUPPORTED; }

@@ -78,6 +78,11 @@ struct Layout {
     // BatchNorm backward, l = 1..5.  Sets 0..4 are zeroed by the first kernel of a forward pass, 5..9 by the first
     // kernel of a backward pass.
     int64_t acc;
+    // claim / done words of the one-launch encoder chains (chain.hip k_enc_fwd_fused / k_enc_bwd_fused): uint32, [A] blocks of
+    // enc_sync_words(rup(nblkc, 32)).  sync_fwd lies between fc11_part and acc (inside the range the head of a forward pass
+    // zeroes), sync_bwd directly behind acc (inside the range the first kernel of a backward pass zeroes).
+    int64_t sync_fwd, sync_bwd;
+    int sync_arm_words;
     int64_t loss_scratch;          // small
     int64_t total;
 };
@@ -728,7 +733,8 @@ struct Ctx {
     // launchers then take the fp32x3 form of their kernels
     mutable bool small_planes = false;
     int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, ACC_T) - lay.fc11_part; }
-    int64_t bwd_zero_floats() const { return (int64_t)5 * d.A * ACC_SET_FLOATS; }
+    int64_t bwd_zero_floats() const { return lay.sync_bwd + (int64_t)d.A * lay.sync_arm_words - acc_set_off(lay, d.A, ACC_BWD); }
+    mutable bool bwd_zeroed = false;   // set by the launcher of the first kernel of a backward pass (it zeroes that range)
 };
 // events of mmvae_exec.ev by role
 enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE /* MMVAE_TUNE_MID_EVENT: behind fc1 */ };
@@ -742,6 +748,11 @@ int launch_fc1_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, con
 int launch_bn_eval_stats(const Ctx& c, const float* bn_running);   // eval mode: all five layers, one launch
 int launch_chain_fwd_enc(const Ctx& c, int layer /*2..5*/, const float* params, float* bn_running, int64_t* nbt);
 int launch_chain_fwd_enc_eval(const Ctx& c, const float* params);   // eval mode: fc2..fc5 in one launch
+// training mode: fc2..fc5 in one launch with a barrier per BatchNorm (fp32x3 form, accumulator sets; chain.hip)
+bool enc_fused_ok(const Ctx& c);
+int launch_chain_fwd_enc_fused(const Ctx& c, const float* params, float* bn_running, int64_t* nbt);
+bool enc_bwd_fused_ok(const Ctx& c);
+int launch_chain_bwd_enc_fused(const Ctx& c, const float* params);
 int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
                    int32_t* labels = nullptr /*eval: argmax of c per cell and arm*/);
 int launch_chain_fwd_dec(const Ctx& c, const float* params);

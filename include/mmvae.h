@@ -152,6 +152,11 @@ enum {
     MMVAE_TUNE_CHAIN_FP32,         /* fp32x3 engine: the chain kernels' own GEMMs stay on the fp32 matrix instruction           */
     MMVAE_TUNE_REDUCE11_MAIN,      /* fused Adam: reduce / update the fc11 tensors on the main stream with the rest instead of
                                       behind their GEMM on the side stream                                              */
+    MMVAE_TUNE_FUSED_CHAIN,        /* training mode, fc2..fc5 and their backward as ONE launch per chain with an in-launch barrier per
+                                      BatchNorm (chain.hip k_enc_fwd_fused / k_enc_bwd_fused) instead of one launch per layer: 1 = on
+                                      (measured: the same step time at A = 2, slower at A = 3: DESIGN.md section 15); tests: 2 = on and
+                                      every third workgroup exits at once (the others pick its row blocks up), 3 = on even when
+                                      the grid exceeds the chip, 4 / 5 = forward / backward chain only */
     MMVAE_TUNE_COUNT_
 };
 typedef struct mmvae_exec {
@@ -224,6 +229,10 @@ typedef enum mmvae_ws_id {
     MMVAE_WS_G5,        /* [A,B,L]  d loss / d x_low */
     MMVAE_WS_BN_MEAN1,  /* [A,H] batch mean of R1 (then BN_MEAN1+i for layer i+1) */
     MMVAE_WS_GD10_SLAB, /* [n_slab][A,B,H] gene-split partial sums of d loss / d d10 = dZ11 W11 (n_slab: mmvae_splits[4]) */
+    MMVAE_WS_G1,        /* [A,B,H]  d loss / d BatchNorm1's output (then G1 + i for i < 4; G5 above)               */
+    MMVAE_WS_G2, MMVAE_WS_G3, MMVAE_WS_G4,
+    MMVAE_WS_DZ2,       /* [A,B,H]  d loss / d fc2's pre-activation (then DZ2 + i; DZ5 is [A,B,L])                 */
+    MMVAE_WS_DZ3, MMVAE_WS_DZ4, MMVAE_WS_DZ5,
     MMVAE_WS_COUNT_
 } mmvae_ws_id;
 

@@ -1,0 +1,87 @@
+"""-m gpu: the train-mode encoder chains as ONE launch each (csrc/chain.hip k_enc_fwd_fused / k_enc_bwd_fused) against the
+one-launch-per-layer kernels they replace -- same arithmetic, so every result must be BIT-identical:
+
+  * the default path (every workgroup carries its own row block through all layers, activations in registers);
+  * with every third workgroup exiting at once, as if it had never become resident (MMVAE_TUNE_FUSED_CHAIN = 2): the
+    running workgroups pick its row blocks up layer by layer from global memory -- the path that makes the in-launch
+    barrier independent of co-residency (two processes on one GPU, grids larger than the chip);
+  * a grid larger than the chip for real (A = 5 at B = 5000: 395 workgroups of 138 KB LDS on 256 CUs, switch value 3).
+
+Reference arithmetic: nn_model.py:264-268 (Linear -> ReLU -> BatchNorm1d, running statistics) and its autograd.
+"""
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TUNE_FUSED = 23        # include/mmvae.h MMVAE_TUNE_FUSED_CHAIN: 0 one launch per layer (default), 1 one launch per chain
+
+
+def _step(h, B, seed, fused_switch, steps=2):
+    """`steps` fused train steps (Adam included) on explicit noise; returns what must not depend on the chain's form."""
+    from distributed_vae_amd import _native as N
+    from distributed_vae_amd.cpl_mixvae import FusedAdam
+    from tests import gpu_util as U
+    sd = R.init_state_dict(h, seed)
+    x = R.synthetic_batch(B, h.input_dim, seed=seed + 1)
+    m = U.build_model(h, sd)
+    m.train()
+    ex = N.exec_from_env(N.gemm_mode("fp32") & 0xFF)
+    ex.tune[TUNE_FUSED] = fused_switch
+    m._exec = ex
+    opt = FusedAdam(m, lr=1e-3)
+    xs = x.to(DEV).expand(h.n_arm, -1, -1)
+    bufs = []
+    for s in range(steps):
+        m.set_explicit_noise(U.noise_to_device(R.draw_noise(h, B, seed=seed + 2 + s)))
+        bufs.append(m.fused_train_step(xs, 1.0, opt, do_adam=True).clone())
+    torch.cuda.synchronize()
+    eng = m._engine
+    out = {"loss": torch.stack(bufs).cpu(), "params": m.flat_parameters().detach().cpu().clone(),
+           "grads": m._flat_grad.detach().cpu().clone(), "bn": m._bn_flat.detach().cpu().clone()}
+    for name, w in (("r1", h.fc_dim), ("r2", h.fc_dim), ("r3", h.fc_dim), ("r4", h.fc_dim), ("r5", h.lowD_dim),
+                    ("dz1", h.fc_dim), ("g5", h.lowD_dim)):
+        out[name] = eng.ws_view(name, w).cpu().clone()
+    return out
+
+
+def _same(a, b):
+    for k in a:
+        # NaN-safe bit comparison
+        assert torch.equal(a[k].view(torch.int32) if a[k].dtype == torch.float32 else a[k],
+                           b[k].view(torch.int32) if b[k].dtype == torch.float32 else b[k]), k
+    assert bool(torch.isfinite(a["loss"]).all())
+
+
+SHAPES = [
+    # A, B, D, H, L, C
+    (2, 96, 256, 32, 6, 12),       # two row blocks per arm, the second half empty
+    (3, 1000, 520, 100, 10, 92),   # 16 row blocks, ragged last one (40 rows)
+    (2, 5000, 1000, 100, 10, 92),  # the benchmark's chain shape: 79 row blocks per arm
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_one_launch_chain_equals_one_launch_per_layer(shape):
+    A, B, D, H, L, C = shape
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=2, lowD_dim=L, n_arm=A)
+    ref = _step(h, B, 11, 0)
+    _same(_step(h, B, 11, 1), ref)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_row_blocks_of_absent_workgroups_are_picked_up(shape):
+    A, B, D, H, L, C = shape
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=2, lowD_dim=L, n_arm=A)
+    ref = _step(h, B, 12, 0)
+    _same(_step(h, B, 12, 2), ref)
+
+
+def test_grid_larger_than_the_chip():
+    """A = 5 at B = 5000: 395 workgroups, at most 256 resident -- the rest of the row blocks are picked up by the running
+    workgroups or processed by their own workgroups when those become resident; either way bit-identical results."""
+    h = R.Hyper(input_dim=1000, n_arm=5)
+    ref = _step(h, 5000, 13, 0, steps=1)
+    _same(_step(h, 5000, 13, 3, steps=1), ref)
