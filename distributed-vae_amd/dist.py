@@ -67,12 +67,11 @@ def allreduce_mean_(buf: torch.Tensor):
 def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
     """One data-parallel step: fused forward + loss + backward, gradient all-reduce (average), Adam.
 
-    Default: ONE all-reduce of the whole flat buffer when backward is done.  MMVAE_DP_OVERLAP=1 (RCCL only) splits it:
-    the fc11.weight / fc11.bias ranges of every arm (47 % of the buffer) are final as soon as their GEMM has finished
-    on the side stream, so their all-reduce starts there, on a communication stream, beside the rest of backward, and
-    the remaining ranges follow.  Off by default: on one rank (`bench.py --rehearse-dp`) the 2 A collectives and the
-    extra reduction launch cost 65 us per step (1.07 ms against 1.005 ms), more than half of an 8.6 MB all-reduce
-    over xGMI can give back; it needs a multi-GPU node to be tuned (fewer, coalesced collectives)."""
+    Default: ONE all-reduce of the whole flat buffer when backward is done.  MMVAE_DP_OVERLAP=1 (RCCL only) splits it in
+    TWO: the fc11.weight / fc11.bias ranges of every arm (47 % of the buffer) are final as soon as their GEMM has finished
+    on the side stream, so they are gathered into one staging buffer and all-reduced there, on a communication stream,
+    beside the rest of backward; the remaining ranges follow as the second collective.  Off by default: no multi-GPU node
+    has been available to tune it on (round 2's form, 2 A collectives, cost 65 us per step on one rank)."""
     import os
     from . import _native as N
     active = is_dist() or (rehearse and dist.is_available() and dist.is_initialized())   # rehearse: world size 1
@@ -83,19 +82,29 @@ def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
     buf = model.fused_train_step(xs, temp, optimizer, do_adam=False)
     flat = model.flat_grad()
     if overlap and eng.early_event is not None and eng.early_recorded():
+        # TWO collectives (round 2 issued 2 A): the fc11 ranges of all arms are gathered into one contiguous staging buffer
+        # (one strided copy kernel) and all-reduced on the communication stream as soon as their GEMM has finished; the
+        # remaining ranges follow the same way when backward is done
         lay = model._layout
         per_arm, o26 = int(lay.per_arm), int(lay.offset[26])
         A = flat.numel() // per_arm
+        v = flat.view(A, per_arm)
+        st = getattr(model, "_dp_stage", None)
+        if st is None or st[0].numel() != A * (per_arm - o26) or st[0].device != flat.device:
+            st = (torch.empty(A, per_arm - o26, device=flat.device), torch.empty(A, o26, device=flat.device))
+            model._dp_stage = st
         comm = N.shared_stream(flat.device, "comm")
         comm.wait_event(eng.early_event)
-        works = []
         with torch.cuda.stream(comm):
-            for a in range(A):
-                works.append(dist.all_reduce(flat[a * per_arm + o26:(a + 1) * per_arm], op=dist.ReduceOp.AVG, async_op=True))
-        for a in range(A):
-            dist.all_reduce(flat[a * per_arm:a * per_arm + o26], op=dist.ReduceOp.AVG)
-        for w in works:
-            w.wait()
+            st[0].copy_(v[:, o26:])
+            work = dist.all_reduce(st[0], op=dist.ReduceOp.AVG, async_op=True)
+        st[1].copy_(v[:, :o26])
+        dist.all_reduce(st[1], op=dist.ReduceOp.AVG)
+        v[:, :o26].copy_(st[1])
+        with torch.cuda.stream(comm):
+            work.wait()                      # the communication stream waits for its collective
+            v[:, o26:].copy_(st[0])
+        torch.cuda.current_stream(flat.device).wait_stream(comm)
     elif active and not is_dist():
         dist.all_reduce(flat, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
     else:
