@@ -14,7 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB") or os.path.join(HERE, "libmmvae_hip.so")   # env override: A/B timing of builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 N_PARAM_TENSORS = 28
 N_BN = 6
 MAX_ARMS = 8
@@ -44,7 +44,8 @@ class Dims(C.Structure):
 class Hyper(C.Structure):
     _fields_ = [("tau", C.c_float), ("temp", C.c_float), ("beta", C.c_float), ("lam", C.c_float),
                 ("eps", C.c_float), ("bn_momentum", C.c_float), ("x_drop", C.c_float), ("s_drop", C.c_float),
-                ("hard", C.c_int32), ("training", C.c_int32), ("eval_flag", C.c_int32), ("gemm_bf16", C.c_int32)]
+                ("hard", C.c_int32), ("training", C.c_int32), ("eval_flag", C.c_int32), ("gemm_bf16", C.c_int32),
+                ("cat_mask", C.c_uint32 * 4)]
 
 
 class Noise(C.Structure):
@@ -250,7 +251,14 @@ class Engine:
             raise NativeError("the HIP engine needs a GPU device (no CPU fallback)")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.ex = ex if ex is not None else exec_from_env(self.gemm_engine)
+        # the engine's OWN execution context: from a caller's Exec only the split factors and the switches are taken --
+        # stream, events and the hook are per engine (two engines built from one Exec must not share them)
+        self.ex = exec_from_env(self.gemm_engine)
+        if ex is not None:
+            for i in range(6):
+                self.ex.split[i] = ex.split[i]
+            for i in range(N_TUNE):
+                self.ex.tune[i] = ex.tune[i]
         self.side = None
         self.early_event = None
         self._events = []
@@ -287,7 +295,7 @@ class Engine:
 
     def at_mid(self, fn=None):
         """Install (or, with None, remove) the producer of the next batch: ``fn(stream)`` is called on the host from inside
-        the next forward / train_step call, right behind its first layer, with ``stream`` a ``torch.cuda.ExternalStream``
+        the next train_step call (no other call invokes it), right behind its first layer, with ``stream`` a ``torch.cuda.ExternalStream``
         of the engine's side stream forked from that point; what it enqueues there (row gather, H2D copy) runs beside the
         latency-bound encoder chain and is complete when the step is.  An exception raised by ``fn`` is re-raised by
         ``raise_at_mid_error()`` (ctypes cannot propagate it through the C call).  No-op without a side stream."""

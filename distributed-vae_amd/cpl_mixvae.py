@@ -270,7 +270,12 @@ class cpl_mixVAE:
                 held["nxt"] = produce(record=False)
 
         hooked = []
-        thin = late and hasattr(loader, "gather_workgroups") and os.environ.get("MMVAE_AT_MID", "1") != "0"
+        # batch n + 1 is gathered from inside step n, which still reads batch n afterwards (fc11 + loss, dW1): the loader's
+        # ring needs a second slot (ring = 0: a fresh tensor per batch), else the producer stays behind the step
+        ring_ok = getattr(loader, "ring", 0) == 0 or getattr(loader, "ring", 0) >= 2
+        use_hook = late and ring_ok and os.environ.get("MMVAE_AT_MID", "1") != "0"
+        thin = use_hook and hasattr(loader, "gather_workgroups")
+        prev_wg = getattr(loader, "gather_workgroups", 0)
         if thin:
             loader.gather_workgroups = 512                      # beside the step: thinner and 10 us longer, 7 us cheaper per step
         try:
@@ -285,7 +290,7 @@ class cpl_mixVAE:
                 xs, x, ev = cur
                 if ev is not None:
                     main.wait_event(ev)
-                eng = self.model._ensure(xs.shape[1]) if late and os.environ.get("MMVAE_AT_MID", "1") != "0" else None
+                eng = self.model._ensure(xs.shape[1]) if use_hook else None
                 in_call = eng is not None and eng.at_mid(at_mid)
                 if in_call and eng not in hooked:
                     hooked.append(eng)
@@ -310,7 +315,7 @@ class cpl_mixVAE:
             for eng in hooked:
                 eng.at_mid(None)
             if thin:
-                loader.gather_workgroups = 0
+                loader.gather_workgroups = prev_wg
 
     def train(self, train_loader, test_loader, n_epoch, n_epoch_p=0, c_p=0, c_onehot=0, min_con=0.5,
               max_prun_it=0, rank=None, run=None, ws=1, good_enuf_consensus=0.75):

@@ -220,8 +220,21 @@ static int make_ctx(Ctx& c, const mmvae_dims* d, const mmvae_hyper* h, void* ws,
         set_error("training mode needs B >= 2 for the batch statistics (got B=%d)", d->B);
         return MMVAE_E_BADARG;
     }
+    // the fixed-point batch-sum accumulators (common.hpp acc_add) hold 2^12 addends of the largest magnitude per column
+    // without a carry between their slots; the producer with the fewest cells per workgroup is the latent backward kernel
+    if (h->training && cdiv(d->B, LAT_ROWS_BWD) > 4096) {
+        set_error("training mode takes at most %d cells per batch and rank (got B=%d): capacity of the exact batch-sum accumulators",
+                  4096 * LAT_ROWS_BWD, d->B);
+        return MMVAE_E_UNSUPPORTED;
+    }
     c.d = *d;
     c.h = *h;
+    if (h->cat_mask[0] | h->cat_mask[1] | h->cat_mask[2] | h->cat_mask[3]) {
+        // bits beyond n_categories are ignored; at least one category must be kept
+        uint32_t any = 0;
+        for (int k = 0; k < d->C; ++k) any |= (h->cat_mask[k >> 5] >> (k & 31)) & 1u;
+        if (!any) { set_error("cat_mask keeps none of the %d categories", d->C); return MMVAE_E_BADARG; }
+    }
     c.ex_out = ex;
     if (ex) c.ex = *ex; else memset(&c.ex, 0, sizeof(c.ex));
     if (c.ex.side_stream) {
@@ -296,7 +309,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         if ((rc = launch_x3_planes(c, params, merged ? 17 : 1, nz))) return rc;   // fp32x3: slice planes of W1, [W11 | b11], the small layers
         if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
         if ((rc = launch_fc1_epi(c, params))) return rc;
-        if (c.ex.at_mid && c.side()) {
+        if (c.ex.at_mid && c.side() && couple_done) {   // only mmvae_train_step joins the side stream before it returns
             // the caller's producer of the next batch: on the side stream from here, ahead of the coupling fork's work
             if ((rc = fork_to_side(c, EV_SPARE))) return rc;
             c.ex.at_mid(c.ex.at_mid_user, c.ex.side_stream);
@@ -443,7 +456,7 @@ using namespace mmvae;
 
 extern "C" {
 
-int mmvae_abi_version(void) { return 2; }
+int mmvae_abi_version(void) { return 3; }
 const char* mmvae_last_error_string(void) { return g_err; }
 int mmvae_check_dims(const mmvae_dims* d) { return check_dims(d); }
 

@@ -78,7 +78,14 @@ struct LatArgs {
     int64_t acc_bn5, acc_bnb5;   // accumulator sets ([A] each) instead of bn_part5 (read) / bnb_part5 (added to); -1 = partials
     int64_t acc_c, acc_T;        // ... instead of c_part (added to by the forward kernels) / T (read by the backward kernels)
     float bn_momentum;
+    // category subset of the pruning-time forward (nn_model.py:332-335: c = softmax(c_prob[:, mask] / tau) on the kept
+    // categories, 0 elsewhere): bit k of cmask = category k is kept; use_mask == 0: all of them
+    uint32_t cmask[4];
+    int use_mask;
 };
+__device__ __forceinline__ bool cat_kept(const LatArgs& a, int col) {
+    return !a.use_mask || ((a.cmask[(col >> 5) & 3] >> (col & 31)) & 1u) != 0u;
+}
 
 __device__ __forceinline__ float gumbel_u(const NoiseDev& nz, int arm, int B, int C, int b, int col) {
     if (nz.mode == 0) return nz.u_gumbel[((int64_t)arm * B + b) * C + col];
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(1024) void k_lat_fwd(const LatArgs a_in, const Nois
 #pragma unroll
     for (int r = 0; r < LAT_NR; ++r)
 #pragma unroll
-        for (int t = 0; t < CPL; ++t) tmp[r][t] = cp[r][t] * inv_tau;
+        for (int t = 0; t < CPL; ++t) tmp[r][t] = cat_kept(a, lane + 64 * t) ? cp[r][t] * inv_tau : -INFINITY;   // masked-out: exp(-inf) = 0
     softmax_rows(tmp, cc);
 #pragma unroll
     for (int r = 0; r < LAT_NR; ++r)
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(64 * LH_NW) void k_lat_fwd_h(const LatArgs a_in, co
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int t = 0; t < CP; ++t) tmp[r][t] = cp[r][t] * inv_tau;
+        for (int t = 0; t < CP; ++t) tmp[r][t] = cat_kept(a, sub + 32 * t) ? cp[r][t] * inv_tau : -INFINITY;   // masked-out: exp(-inf) = 0
     softmax_rows(tmp, cc);
 #pragma unroll
     for (int r = 0; r < NR; ++r)
@@ -1526,6 +1533,8 @@ static LatArgs make_lat_args(const Ctx& c) {
     LatArgs a{};
     a.A = d.A; a.B = d.B; a.L = d.L; a.C = d.C; a.S = d.S;
     a.tau = c.h.tau; a.temp = c.h.temp; a.eps = c.h.eps; a.s_drop = c.h.s_drop;
+    a.use_mask = (c.h.cat_mask[0] | c.h.cat_mask[1] | c.h.cat_mask[2] | c.h.cat_mask[3]) != 0u;
+    for (int i = 0; i < 4; ++i) a.cmask[i] = c.h.cat_mask[i];
     a.hard = c.h.hard; a.training = c.h.training; a.eval_flag = c.h.eval_flag;
     a.per_arm = c.po.per_arm; a.o_wc = c.po.o[10]; a.o_bc = c.po.o[11]; a.o_wms = c.po.o[12]; a.o_bms = c.po.o[14];
     a.R5 = L.R[4]; a.mean5 = L.bn_mean[4]; a.rstd5 = L.bn_rstd[4];

@@ -281,14 +281,20 @@ class mixVAE_model(nn.Module):
         assert not self.loss_mode == "ZINB", "ZINB not implemented"
         assert self.varitional, "Non-variational not implemented"
         assert len(x) == self.n_arm
+        mask_words = None
         if mask is not None:
-            # eval_model passes the indices of the categories whose fcc bias is non-zero (cpl_mixvae.py:1476-1478, :1524):
-            # for an unpruned model that is every category, which leaves forward unchanged (nn_model.py:332-337)
+            # nn_model.py:332-335: c = softmax(c_prob[:, mask] / tau) on the kept categories, 0 elsewhere.  eval_model passes the
+            # indices of the categories whose fcc bias is non-zero (cpl_mixvae.py:1476-1478, :1524): every category for an
+            # unpruned model, a subset for a checkpoint of a pruned one.  (A boolean mask selects like an index list.)
             import numpy as _np
-            mk = _np.unique(_np.asarray(mask.detach().cpu() if isinstance(mask, torch.Tensor) else mask).astype(_np.int64))
-            if not (mk.size == self.n_categories and mk[0] == 0 and mk[-1] == self.n_categories - 1):
-                raise NotImplementedError("a category mask that removes categories belongs to the pruning phase, which "
-                                          "the reference disables (cpl_mixvae.py:1005-1008); not part of the HIP path")
+            mk = _np.asarray(mask.detach().cpu() if isinstance(mask, torch.Tensor) else mask)
+            mk = _np.flatnonzero(mk) if mk.dtype == _np.bool_ else _np.unique(mk.astype(_np.int64))
+            if mk.size == 0 or mk[0] < 0 or mk[-1] >= self.n_categories:
+                raise IndexError(f"category mask {mk.tolist()} outside [0, {self.n_categories})")
+            if mk.size < self.n_categories:
+                mask_words = [0, 0, 0, 0]
+                for k in mk.tolist():
+                    mask_words[k >> 5] |= 1 << (k & 31)
         if self.ref_prior:
             raise NotImplementedError("ref_prior is rejected by the reference loss (nn_model.py:578)")
         xt, xs = self._prep_x(x)
@@ -298,6 +304,9 @@ class mixVAE_model(nn.Module):
         assert D == self.input_dim
         eng = self._ensure(B)
         hyper = self._hyper(temp, eval)
+        if mask_words is not None:
+            for i in range(4):
+                hyper.cat_mask[i] = mask_words[i]
         noise = self._next_noise()
         need_grad = bool(self.training and torch.is_grad_enabled())
         x_rec = torch.empty(A, B, D, dtype=torch.float32, device=xt.device)

@@ -79,6 +79,10 @@ typedef struct mmvae_hyper {
                           fast path (D % 4 == 0, fc_dim % 4 == 0, fc_dim <= 124; engine 2's fused fc11 kernel fc_dim <= 111),
                           else engine 0 runs.  Bits 8..11 (diagnostics, engine 2 only): products that stay on engine 0
                           (1 fc1, 2 fc11 + d(d10), 4 dW1, 8 dW11). */
+    uint32_t cat_mask[4]; /* category subset of forward(mask=...) (nn_model.py:332-335, the pruning-time forward; eval_model passes
+                          the categories whose fcc bias is non-zero, cpl_mixvae.py:1476-1478): bit k of the 128-bit mask set =
+                          category k is kept; c = softmax(c_prob[:, kept] / tau) on the kept categories and 0 elsewhere.
+                          All four words zero = no mask (every category kept). */
 } mmvae_hyper;
 
 /* Noise descriptor.  mode 0 = explicit buffers (parity tests; the reference's RNG stream cannot
@@ -166,13 +170,14 @@ typedef struct mmvae_exec {
     int32_t early_recorded;
     int32_t split[6];
     int32_t tune[MMVAE_N_TUNE];
-    /* Optional (NULL = none; needs side_stream): called ON THE HOST by mmvae_forward / mmvae_train_step while they enqueue
-     * their work, right behind the first layer (fc1 + its epilogue), with the side stream forked from that point
-     * (ev[7]).  Whatever the callee enqueues on `stream` -- the row gather or H2D copy of the NEXT batch -- runs beside
-     * the latency-bound encoder chain, ahead of the step's own side-stream work, and is complete when the call's work on
-     * its main stream is (the step joins the side stream before its gradient reduction).  Issued from the caller's
-     * own code behind the call instead, such a copy reaches the device some 300 us into the step and lands beside
-     * the fc11 kernel. */
+    /* Optional (NULL = none; needs side_stream): called ON THE HOST by mmvae_train_step -- and only by it: it is the one
+     * call that joins the side stream before its work on the main stream ends -- while it enqueues its work, right behind
+     * the first layer (fc1 + its epilogue), with the side stream forked from that point (ev[7]).  Whatever the callee
+     * enqueues on `stream` -- the row gather or H2D copy of the NEXT batch -- runs beside the latency-bound encoder chain,
+     * ahead of the step's own side-stream work, and is complete when the call's work on its main stream is (the step
+     * joins the side stream before its gradient reduction).  mmvae_forward, mmvae_eval_classify and mmvae_backward never
+     * call it.  Issued from the caller's own code behind the call instead, such a copy reaches the device some 300 us
+     * into the step and lands beside the fc11 kernel. */
     void (*at_mid)(void *user, void *stream);
     void *at_mid_user;
 } mmvae_exec;
@@ -240,7 +245,8 @@ typedef enum mmvae_ws_id {
 int mmvae_abi_version(void);
 const char *mmvae_last_error_string(void);
 /* 0 if the kernels support these dims (H,C<=128, L<=64, S<=32, L+C,C+S<=255, A<=MMVAE_MAX_ARMS).  Calls with
- * h->training != 0 additionally need B >= 2 (batch statistics); eval mode takes a one-cell batch. */
+ * h->training != 0 additionally need 2 <= B <= 32768 (batch statistics; capacity of the exact batch-sum accumulators); eval
+ * mode takes any batch from one cell up. */
 int mmvae_check_dims(const mmvae_dims *d);
 int mmvae_param_layout(const mmvae_dims *d, mmvae_param_layout_t *out);
 /* bytes of caller-provided workspace that forward/loss/backward/train_step need */

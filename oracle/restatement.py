@@ -166,7 +166,7 @@ def _bn(r: Tensor, sd, key: str, h: Hyper, training: bool, update: bool):
 
 def forward(sd: Dict[str, Tensor], xs: Sequence[Tensor], h: Hyper, noise, *,
             temp: Optional[float] = None, training: bool = True, eval_flag: bool = False,
-            update_running: bool = True, keep: bool = False, relu_override=None):
+            update_running: bool = True, keep: bool = False, relu_override=None, mask=None):
     """``mixVAE_model.forward`` (nn_model.py:297-368) with explicit noise.
 
     Returns the reference's 10-tuple; with ``keep`` also a per-arm dict of the
@@ -181,9 +181,14 @@ def forward(sd: Dict[str, Tensor], xs: Sequence[Tensor], h: Hyper, noise, *,
     it; a test that has read the device's decisions evaluates the reference
     arithmetic (nn_model.py:263-287) on exactly those decisions and can then
     hold every tensor to the tight gate.
+
+    ``mask``: indices of the kept categories (the pruning-time forward, nn_model.py:332-335): the second softmax runs
+    over ``c_prob[:, mask]`` and ``c`` is zero elsewhere.
     """
     temp = h.temp if temp is None else temp
     eps = h.eps
+    if mask is not None:
+        mask = torch.as_tensor(mask, dtype=torch.long)
 
     def _relu(z, a, site, iv):
         if keep:
@@ -210,8 +215,11 @@ def forward(sd: Dict[str, Tensor], xs: Sequence[Tensor], h: Hyper, noise, *,
         x_low = hcur
         zc = F.linear(x_low, W("fcc"), b("fcc"))
         c_prob = F.softmax(zc, dim=-1)
-        # nn_model.py:337
-        c = F.softmax(c_prob / h.tau, dim=-1)
+        # nn_model.py:332-337
+        if mask is not None:
+            c = torch.zeros_like(c_prob).index_copy(1, mask, F.softmax(c_prob[:, mask] / h.tau, dim=-1))
+        else:
+            c = F.softmax(c_prob / h.tau, dim=-1)
         # nn_model.py:339-345 / :430-493
         if eval_flag:
             y_soft = c

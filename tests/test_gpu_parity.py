@@ -728,3 +728,62 @@ def test_full_size_more_arms_fused_step_matches_api_path(A):
     scale = float(g_api.abs().max())
     assert float(err.max()) <= 5 * GRAD_TOL * scale                      # a few ReLU flips at 25 M decisions per arm
     assert float(torch.quantile(err[::97].float(), 0.9)) <= 1e-4 * scale
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward(mask=...): the pruning-time forward (scope row f-4; nn_model.py:332-335)
+# ---------------------------------------------------------------------------------------------------
+def test_masked_forward_against_the_reference_fixture():
+    """tests/golden/mask_a2.npz, generated by the REAL reference (oracle/gen_golden_mask.py): train mode -- forward outputs,
+    loss and every gradient through ``loss.backward()`` -- then eval mode on the updated running statistics (what
+    ``eval_model`` runs on a checkpoint with pruned categories)."""
+    U = _U()
+    g = G.load("mask_a2")
+    h = G.hyper_of(g)
+    A = h.n_arm
+    mask = [int(v) for v in g["mask"]]
+    off = sorted(set(range(h.n_categories)) - set(mask))
+    m = U.build_model(h, G.state_dict_of(g))
+    m.train()
+    x = torch.from_numpy(g["x"]).to(U.DEV)
+    xs = x.expand(A, -1, -1)
+    m.set_explicit_noise(U.noise_to_device(G.noise_of(g)))
+    out = m(xs, 1.0, 0.0, eval=False, mask=mask)
+    lt = m.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)
+    m.zero_grad()
+    lt[0].backward()
+    torch.cuda.synchronize()
+    names = {0: "x_rec", 3: "x_low", 4: "c", 5: "s_smp", 6: "c_smp", 7: "s_mean", 8: "s_logvar", 9: "c_prob"}
+    for i, nm in names.items():
+        assert G.rel_err(torch.stack(list(out[i])).cpu(), g["fwd/" + nm]) < FWD_TOL, nm
+    for a in range(A):
+        assert float(out[4][a][:, off].abs().max()) == 0.0                     # masked-out categories: exactly zero
+        assert float((out[4][a].sum(1) - 1).abs().max()) < 1e-5
+    assert abs(float(lt[0]) - float(g["loss/total"])) <= 1e-4 * abs(float(g["loss/total"]))
+    for k, p in m.named_parameters():
+        assert G.rel_err(p.grad.cpu(), g["grad/" + k]) < GRAD_TOL, k
+    # eval mode (boolean mask form), running statistics after the one training step
+    for k in g.files:
+        if k.startswith("sd1/"):
+            ref = torch.from_numpy(np.asarray(g[k]))
+            if ref.dtype.is_floating_point:
+                assert G.rel_err(m.state_dict()[k[4:]].cpu(), ref) < 1e-4, k
+    m.eval()
+    bmask = torch.zeros(h.n_categories, dtype=torch.bool)
+    bmask[mask] = True
+    m.set_explicit_noise(U.noise_to_device(G.noise_of(g, "noise_eval/")))
+    with torch.no_grad():
+        oe = m(xs, 1.0, 0.0, eval=True, mask=bmask)
+    for i, nm in names.items():
+        assert G.rel_err(torch.stack(list(oe[i])).cpu(), g["eval/" + nm]) < FWD_TOL, nm
+    # the full mask and no mask are the same forward
+    m.set_explicit_noise(U.noise_to_device(G.noise_of(g, "noise_eval/")))
+    with torch.no_grad():
+        o1 = m(xs, 1.0, 0.0, eval=True, mask=list(range(h.n_categories)))
+    m.set_explicit_noise(U.noise_to_device(G.noise_of(g, "noise_eval/")))
+    with torch.no_grad():
+        o2 = m(xs, 1.0, 0.0, eval=True)
+    for i in names:
+        assert torch.equal(torch.stack(list(o1[i])), torch.stack(list(o2[i]))), i
+    with pytest.raises(IndexError):
+        m(xs, 1.0, 0.0, eval=True, mask=[0, h.n_categories])

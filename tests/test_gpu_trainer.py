@@ -341,3 +341,36 @@ def test_at_mid_hook_runs_inside_the_step_and_its_work_is_complete_with_the_step
     eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, g1, False, None, None, 1, 0.0)
     torch.cuda.synchronize()
     assert len(calls) == 1
+
+
+def test_at_mid_hook_is_not_called_by_forward_or_eval_classify():
+    """Only mmvae_train_step joins the side stream before it returns, so only it may hand the side stream to the caller's
+    producer: with the hook installed, ``mmvae_forward`` (training and eval mode) and ``mmvae_eval_classify`` must not call
+    it -- a forward between two training steps would otherwise consume (and lose) a loader batch and leave a copy unordered
+    with the main stream."""
+    from tests import gpu_util as U
+    from distributed_vae_amd import _native as N
+    from distributed_vae_amd._utils import confmat_counts
+    A, B, D = 2, 300, 520
+    h = R.Hyper(input_dim=D, fc_dim=100, n_categories=12, state_dim=2, lowD_dim=6, n_arm=A)
+    torch.manual_seed(3)
+    m = U.build_model(h, None)
+    m.train()
+    x = R.synthetic_batch(B, D, seed=4).to(U.DEV)
+    xs = x.expand(A, -1, -1)
+    eng = m._ensure(B)
+    calls = []
+    assert eng.at_mid(lambda stream: calls.append(1))
+    out = m(xs, 1.0, 0.0)                                   # training-mode forward through the three-call path
+    m.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)[0].backward()
+    m.eval()
+    with torch.no_grad():
+        m(xs, 1.0, 0.0, eval=True)
+    m.eval_labels(xs, 1.0, confmat_counts(A, h.n_categories, U.DEV))
+    torch.cuda.synchronize()
+    assert calls == []
+    m.train()
+    m.fused_train_step(xs, 1.0, None, do_adam=False)        # the train step does call it
+    torch.cuda.synchronize()
+    assert calls == [1]
+    eng.at_mid(None)

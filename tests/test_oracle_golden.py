@@ -185,3 +185,25 @@ def test_oracle_replays_the_reference_trainer_epochs():
     for k in R.param_keys(h):
         d = (sd[k] - torch.from_numpy(g["sdT/" + k])).abs()
         assert float(d.median()) < 1e-5 and float(d.max()) < 2.1e-3, k
+
+
+def test_oracle_reproduces_the_masked_forward_fixture():
+    """tests/golden/mask_a2.npz (oracle/gen_golden_mask.py: the REAL reference's forward(mask=...), nn_model.py:332-335,
+    train mode with loss and gradients, then eval mode on the updated running statistics)."""
+    g = G.load("mask_a2")
+    h = G.hyper_of(g)
+    A = h.n_arm
+    mask = [int(v) for v in g["mask"]]
+    x = torch.from_numpy(g["x"])
+    sd = G.state_dict_of(g)
+    out, lt, grads = R.grads_autograd(sd, [x] * A, h, G.noise_of(g), mask=mask)
+    names = {0: "x_rec", 3: "x_low", 4: "c", 5: "s_smp", 6: "c_smp", 7: "s_mean", 8: "s_logvar", 9: "c_prob"}
+    for i, nm in names.items():
+        assert G.rel_err(torch.stack(list(out[i])), g["fwd/" + nm]) < 2e-4, nm
+    # (fp32 against fp32: the masked-out categories put log(eps) / sqrt(eps) = -1.8e5 into both arms' coupling operands)
+    assert abs(float(lt[0]) - float(g["loss/total"])) <= 1e-4 * abs(float(g["loss/total"]))
+    for k, v in grads.items():
+        assert G.rel_err(v, g["grad/" + k]) < 2e-4, k
+    oe = R.forward(sd, [x] * A, h, G.noise_of(g, "noise_eval/"), training=False, eval_flag=True, mask=mask)
+    for i, nm in names.items():
+        assert G.rel_err(torch.stack(list(oe[i])), g["eval/" + nm]) < 2e-4, nm

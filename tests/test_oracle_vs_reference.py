@@ -127,3 +127,49 @@ def test_checkpoints_round_trip_with_the_reference(tmp_path):
     t3.init_model(n_categories=C, state_dim=S, input_dim=D, fc_dim=H, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A)
     t3.load_model(ref_path)
     assert torch.equal(t3.model.state_dict()["fc1.0.weight"], m_ref.state_dict()["fc1.0.weight"])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-11), (torch.float32, 2e-4)])
+def test_masked_forward_equals_reference(dtype, tol):
+    """forward(mask=kept categories) -- the pruning-time forward, nn_model.py:332-335 -- train mode (with loss and
+    gradients) and eval mode, restatement against the live reference."""
+    warnings.simplefilter("ignore")
+    ref = RL.load_reference_nn_model()
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        cfg = (3, 33, 50, 10, 3, 8, 2, False, 0.0)
+        m, h = _mk(ref, cfg, dtype)
+        A, B, D = cfg[:3]
+        mask = [1, 2, 4, 7]
+        sd = R.init_state_dict(h, 99, dtype=dtype)
+        x = R.synthetic_batch(B, D, seed=5, dtype=dtype)
+        xs = x.expand(A, -1, -1)
+        noise = R.draw_noise(h, B, seed=11)
+        rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        m.train()
+        with RL.explicit_noise(m, noise):
+            out = m(xs, 1.0, 0.0, eval=False, mask=mask)
+        lo = m.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)
+        lo[0].backward()
+        out2, lt, grads = R.grads_autograd(sd, [x] * A, h, noise, mask=mask)
+        _, _, gman, _ = R.grads_manual(R.init_state_dict(h, 99, dtype=dtype), [x] * A, h, noise, mask=mask)
+        assert abs(float(lt[0]) - float(lo[0])) <= tol * abs(float(lo[0]))
+        for i in (0, 3, 4, 5, 6, 7, 8, 9):
+            for a in range(A):
+                assert rel(out2[i][a], out[i][a]) < max(tol, 1e-12), (i, a)
+        for a in range(A):
+            assert float(out2[4][a][:, [0, 3, 5, 6]].abs().max()) == 0.0        # masked-out categories: exactly zero
+        for k, p in m.named_parameters():
+            assert rel(grads[k], p.grad) < tol, k
+            assert rel(gman[k], p.grad) < tol, k
+        m.eval()
+        ne = R.draw_noise(h, B, seed=12, training=False, eval_flag=True)
+        with torch.no_grad(), RL.explicit_noise(m, ne):
+            oe = m(xs, 1.0, 0.0, eval=True, mask=mask)
+        oe2 = R.forward(sd, [x] * A, h, ne, training=False, eval_flag=True, mask=mask)
+        for i in (0, 3, 4, 5, 6, 7, 8, 9):
+            for a in range(A):
+                assert rel(oe2[i][a], oe[i][a]) < max(tol, 1e-12), (i, a)
+    finally:
+        torch.set_default_dtype(old)
