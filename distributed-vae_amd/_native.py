@@ -73,13 +73,13 @@ class AugTensors(C.Structure):
 
 N_EVENTS = 8
 N_TUNE = 24
-# mmvae_exec.tune indices (include/mmvae.h MMVAE_TUNE_*) and the environment switch that sets each one: the LIBRARY reads
+# mmvae_exec.tune indices (private: csrc/tune.h; public: MMVAE_TUNE_ENGINE / MMVAE_TUNE_MID_EVENT in include/mmvae.h) and the
+# environment switch that sets each one: the LIBRARY reads
 # no environment variables, this module translates them (experiments and A/B timing only; none is needed in production)
 TUNE_ENV = {
     "MMVAE_EVAL_CHAIN": (0, lambda v: int(int(v) == 0)), "MMVAE_DW11_AT": (1, int), "MMVAE_SIDE_SMALL": (2, int),
     "MMVAE_AUG_TILE": (3, int), "MMVAE_ABLATE_C": (4, int), "MMVAE_ABLATE": (5, int), "MMVAE_PADLDS": (6, int),
-    "MMVAE_FC1_V2": (7, int), "MMVAE_FC11_ZG": (8, lambda v: int(int(v) == 0)), "MMVAE_ABLATE_Z": (9, int),
-    "MMVAE_FC11_NSZ": (10, int), "MMVAE_GD10_V2": (11, int), "MMVAE_DW1_V2": (12, int), "MMVAE_DW11_V2": (13, int),
+    "MMVAE_FC11_ZG": (8, lambda v: int(int(v) == 0)),
     "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_ABLATE_B": (16, int),
     "MMVAE_BN_PARTIALS": (19, int), "MMVAE_PRESPLIT_ALL": (20, int), "MMVAE_CHAIN_FP32": (21, int),
     "MMVAE_REDUCE11_MAIN": (22, int), "MMVAE_FUSED_CHAIN": (23, int),

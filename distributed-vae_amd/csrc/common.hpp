@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mmvae.h"
+#include "tune.h"
 
 namespace mmvae {
 

@@ -1376,8 +1376,7 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
     const int padlds = c.tune(MMVAE_TUNE_PADLDS);   // occupancy experiments
     dim3 grid(cdiv(d.B, 128), KS, d.A);
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits);
-    const int v3off = c.tune(MMVAE_TUNE_FC1_V2);   // A/B timing
-    if (d.H == 100 && !v3off) {
+    if (d.H == 100) {
         if (use_mask)
             hipLaunchKernelGGL((k_fc1_fwd_v3<true>), grid, dim3(256), padlds, c.stream, x, xs, params, c.po.per_arm,
                                c.po.o[0], bits, cdiv(d.D, 32), c.ws + c.lay.fc1_slab, d.A, d.B, d.D, d.H, KS, ablate);
@@ -1433,14 +1432,11 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
         const int ntall = cdiv(d.D, 64);
         const int kgv = rup(d.H, 8) / 8;
-        const int ablz = c.tune(MMVAE_TUNE_ABLATE_Z);   // timing experiments
         {
             // one 512-thread workgroup per CU: split the gene range so that the grid fills the chip once
             const int nb = cdiv(d.B, 256);
             int nsz = max(1, min(min(256 / max(nb * d.A, 1), 16), ntall));
             while (nsz > 1 && (int64_t)nb * nsz > L.n11) --nsz;
-            const int nsz_env = c.tune(MMVAE_TUNE_FC11_NSZ);
-            if (nsz_env > 0 && (int64_t)nb * nsz_env <= L.n11) nsz = min(nsz_env, ntall);
             const size_t shm = (size_t)(2 * 64 * ldk + 16) * sizeof(float);
             dim3 grid(nb, nsz, d.A);
 #define FZT_ARGS c.ws + L.Dk[4], params, c.po.per_arm, c.po.o[26], c.po.o[27], x, xs, x_rec, c.ws + L.DZ11,        \
@@ -1452,14 +1448,6 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
             // without x_rec the kernel always writes dZ11 (workspace), wanted or not: one variant fewer
             if (kgv == 13 && d.H == 100) {
                 if (xr) FZT_LAUNCH(13, true, true, true, 0);
-                else if (ablz == 1) FZT_LAUNCH(13, true, true, false, 1);
-                else if (ablz == 2) FZT_LAUNCH(13, true, true, false, 2);
-                else if (ablz == 4) FZT_LAUNCH(13, true, true, false, 4);
-                else if (ablz == 6) FZT_LAUNCH(13, true, true, false, 6);
-                else if (ablz == 7) FZT_LAUNCH(13, true, true, false, 7);
-                else if (ablz == 8) FZT_LAUNCH(13, true, true, false, 8);
-                else if (ablz == 24) FZT_LAUNCH(13, true, true, false, 24);
-                else if (ablz == 16) FZT_LAUNCH(13, true, true, false, 16);
                 else FZT_LAUNCH(13, true, true, false, 0);
             } else if (kgv == 16 && d.H == 128) {
                 if (xr) FZT_LAUNCH(16, true, false, true, 0);
@@ -1474,8 +1462,7 @@ int launch_fc11_fast(const Ctx& c, const float* params, const float* x, int64_t 
         }
     }
     if (need_grad && (which & 2)) {
-        const int v2only = c.tune(MMVAE_TUNE_GD10_V2);   // A/B timing
-        if (d.H == 100 && !v2only)
+        if (d.H == 100)
             hipLaunchKernelGGL(k_gd10_v3, dim3(cdiv(d.B, 128), L.sp.ks_gd10, d.A), dim3(256), 0, c.stream, c.ws + L.DZ11,
                                params, c.po.per_arm, c.po.o[26], c.ws + L.GD10_slab, d.A, d.B, d.D, d.H, L.sp.ks_gd10);
         else
@@ -1505,8 +1492,7 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
     if (which & 1) {   // dW1[h][d] = sum_b dZ1[b][h] x~[b][d]   -> slab [KS][A][H][D]
         const int tiles_n = cdiv(d.D, 128);
         dim3 grid(cdiv(d.H, 128) * tiles_n, KS, d.A);
-        const int v2only = c.tune(MMVAE_TUNE_DW1_V2);   // A/B timing
-        if (d.H == 100 && !v2only) {
+        if (d.H == 100) {
             if (use_mask)
                 hipLaunchKernelGGL((k_tn_v3m<true>), grid, dim3(256), 0, c.stream, c.ws + L.DZ[1],
                                    (int64_t)d.B * d.H, d.H, d.H, x, xs, d.D, d.D, bits, wpr, c.ws + L.dw1_slab,
@@ -1531,8 +1517,7 @@ int launch_dw_big_fast(const Ctx& c, const float* x, int64_t xs, int which) {
         const int tiles_n = cdiv(d.H + 1, 128);
         const int KS11 = L.sp.ks_dw11;
         dim3 grid(cdiv(d.D, 128) * tiles_n, KS11, d.A);
-        const int v2o = c.tune(MMVAE_TUNE_DW11_V2);   // A/B timing
-        if (d.H == 100 && !v2o)
+        if (d.H == 100)
             hipLaunchKernelGGL(k_tn_v3n, grid, dim3(256), 0, c.stream, c.ws + L.DZ11, (int64_t)d.B * d.D,
                                d.D, d.D, c.ws + L.Dk[4], (int64_t)d.B * d.H, d.H, d.H, bits, wpr, c.ws + L.dw11_slab,
                                (int64_t)d.D * DW11_LD, (int64_t)d.A * d.D * DW11_LD, DW11_LD, d.B, KS11, tiles_n);

@@ -119,50 +119,21 @@ typedef struct mmvae_noise {
  *   split        split factors of the large GEMMs, 0 = automatic: 0 fc1 split-K, 1 fc11 column splits, 2 dW1 batch
  *                splits, 3 small-layer dW batch splits, 4 d(d10) gene splits, 5 dW11 batch splits.  They change the
  *                workspace layout: pass the same context to mmvae_workspace_bytes / mmvae_ws_offset.
- *   tune         experiment switches (A/B timing, ablations; MMVAE_TUNE_*), 0 = production behaviour.  The library
- *                reads no environment variables. */
+ *   tune         MMVAE_TUNE_ENGINE / MMVAE_TUNE_MID_EVENT below; the other entries are the implementation's experiment
+ *                switches (0 = production behaviour).  The library reads no environment variables. */
 #define MMVAE_N_EVENTS 8
 #define MMVAE_N_TUNE 24
-enum {
-    MMVAE_TUNE_EVAL_CHAIN_OFF = 0, /* eval mode: fc2..fc5 as four launches instead of one          */
-    MMVAE_TUNE_DW11_AT,            /* where dW11 forks: 0 start of backward, 1 after decoder chain, 2 after latent */
-    MMVAE_TUNE_SIDE_SMALL,         /* small-layer dW GEMMs on the side stream                         */
-    MMVAE_TUNE_AUG_TILE,           /* augmenter GEMM tile 11 12 21 22 (1 = 64, 2 = 128)              */
-    MMVAE_TUNE_ABLATE_C,           /* chain kernels: timing ablations / cycle stamps (results wrong) */
-    MMVAE_TUNE_ABLATE,             /* fc1 forward ablations                                           */
-    MMVAE_TUNE_PADLDS,             /* fc1 forward: extra dynamic LDS (occupancy experiments)          */
-    MMVAE_TUNE_FC1_V2,             /* previous kernel generations ...                                 */
-    MMVAE_TUNE_FC11_ZG_OFF,
-    MMVAE_TUNE_ABLATE_Z,
-    MMVAE_TUNE_FC11_NSZ,
-    MMVAE_TUNE_GD10_V2,
-    MMVAE_TUNE_DW1_V2,
-    MMVAE_TUNE_DW11_V2,
-    MMVAE_TUNE_ABLATE_L,           /* latent kernels: ablations                                       */
-    MMVAE_TUNE_LAT_FULLWAVE,       /* latent kernels: one wave per cell instead of the half-wave layout */
-    MMVAE_TUNE_ABLATE_B,           /* bf16 GEMM engine: 1 no MFMAs, 2 no global loads, 4 no LDS stores (results wrong)  */
-    MMVAE_TUNE_ENGINE,             /* not an experiment: the GEMM engine the caller is going to run (mmvae_hyper.gemm_bf16
-                                      & 0xFF; 0 = not stated).  The split factors of the workspace layout are chosen for the
-                                      workgroup shapes of that engine; any engine runs correctly on any layout */
-    MMVAE_TUNE_MID_EVENT,          /* not an experiment: != 0 and a side stream given -> mmvae_forward / mmvae_train_step record
-                                      ev[7] on the call's stream behind the first layer (fc1 + its epilogue), i.e. where the
-                                      step leaves its first throughput-bound kernel and enters the latency-bound encoder chain.
-                                      A caller that produces the NEXT batch on another stream (row gather, H2D copy) lets that
-                                      stream wait for it, so that the copy runs beside the chain instead of beside fc1 */
-    MMVAE_TUNE_BN_PARTIALS,        /* BatchNorm batch sums through per-workgroup partial arrays that every consumer recombines
-                                      (round 1's scheme) instead of the fixed-point atomic accumulators             */
-    MMVAE_TUNE_PRESPLIT_ALL,       /* fp32x3 engine: all slice planes through k_presplit launches (none written by the kernels
-                                      that produce the values)                                                       */
-    MMVAE_TUNE_CHAIN_FP32,         /* fp32x3 engine: the chain kernels' own GEMMs stay on the fp32 matrix instruction           */
-    MMVAE_TUNE_REDUCE11_MAIN,      /* fused Adam: reduce / update the fc11 tensors on the main stream with the rest instead of
-                                      behind their GEMM on the side stream                                              */
-    MMVAE_TUNE_FUSED_CHAIN,        /* training mode, fc2..fc5 and their backward as ONE launch per chain with an in-launch barrier per
-                                      BatchNorm (chain.hip k_enc_fwd_fused / k_enc_bwd_fused) instead of one launch per layer: 1 = on
-                                      (measured: the same step time at A = 2, slower at A = 3: DESIGN.md section 15); tests: 2 = on and
-                                      every third workgroup exits at once (the others pick its row blocks up), 3 = on even when
-                                      the grid exceeds the chip, 4 / 5 = forward / backward chain only */
-    MMVAE_TUNE_COUNT_
-};
+/* mmvae_exec.tune: 0 everywhere = production behaviour.  Two entries are part of the interface: */
+#define MMVAE_TUNE_ENGINE 17    /* the GEMM engine the caller is going to run (mmvae_hyper.gemm_bf16 & 0xFF; 0 = not stated).
+                                   The split factors of the workspace layout are chosen for the workgroup shapes of that
+                                   engine; any engine runs correctly on any layout */
+#define MMVAE_TUNE_MID_EVENT 18 /* != 0 and a side stream given -> mmvae_forward / mmvae_train_step record ev[7] on the call's
+                                   stream behind the first layer (fc1 + its epilogue), i.e. where the step leaves its first
+                                   throughput-bound kernel and enters the latency-bound encoder chain.  A caller that produces
+                                   the NEXT batch on another stream (row gather, H2D copy) lets that stream wait for it, so
+                                   that the copy runs beside the chain instead of beside fc1 */
+/* Every other index is an experiment switch of the implementation (A/B timing, ablations, test hooks), listed in the
+ * library's private header distributed-vae_amd/csrc/tune.h; callers leave them 0. */
 typedef struct mmvae_exec {
     void *side_stream;
     void *ev[MMVAE_N_EVENTS];
