@@ -176,6 +176,12 @@ def lib():
                "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus", "mmvae_aug_pack",
                "mmvae_augment", "mmvae_gather_rows"):
         getattr(L, fn).restype = C.c_int
+    L.mmvae_dp_unique_id.argtypes = [vp]
+    L.mmvae_dp_init.argtypes = [vp, i32, i32, C.POINTER(C.c_void_p)]
+    L.mmvae_allreduce_grads.argtypes = [vp, vp, i64, vp]
+    L.mmvae_dp_destroy.argtypes = [vp]
+    for fn in ("mmvae_dp_unique_id", "mmvae_dp_init", "mmvae_allreduce_grads", "mmvae_dp_destroy"):
+        getattr(L, fn).restype = C.c_int
     if L.mmvae_abi_version() != ABI_VERSION:
         raise NativeError("libmmvae_hip.so ABI version mismatch (rebuild: python distributed-vae_amd/build.py)")
     _lib = L

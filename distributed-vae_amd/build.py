@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmvae_hip.so")
-SOURCES = ["api.hip", "gemm_big.hip", "gemm_fast.hip", "gemm_bf16.hip", "chain.hip", "rowwise.hip", "consensus.hip", "augment.hip", "datapath.hip"]
+SOURCES = ["api.hip", "gemm_big.hip", "gemm_fast.hip", "gemm_bf16.hip", "chain.hip", "rowwise.hip", "consensus.hip", "augment.hip", "datapath.hip", "dp.hip"]
 HEADERS = ["common.hpp", "tune.h", os.path.join("..", "..", "include", "mmvae.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file); without it
 # hipcc parks loop-carried accumulators in AGPRs and copies all 64 of them out and back every K tile.
@@ -67,7 +67,7 @@ def build_native(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

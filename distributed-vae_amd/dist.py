@@ -64,6 +64,56 @@ def allreduce_mean_(buf: torch.Tensor):
     return buf
 
 
+class DirectComm:
+    """An RCCL communicator of this process for the library's own gradient all-reduce (``mmvae_allreduce_grads``,
+    include/mmvae.h): ONE stream-ordered ``ncclAllReduce(avg)`` on the stream the step runs on -- no torch NCCL stream, no
+    event round trip.  Rank 0 draws the RCCL unique id and the initialised ``torch.distributed`` group (any backend) carries
+    its 128 bytes to the other ranks; every rank must construct it (``ncclCommInitRank`` is collective)."""
+
+    def __init__(self, rank: int, world_size: int, device):
+        import ctypes as C
+        from . import _native as N
+        self.device = torch.device(device)
+        ids = [None]
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            N.check(N.lib().mmvae_dp_unique_id(buf), "mmvae_dp_unique_id")
+            ids = [bytes(buf)]
+        if world_size > 1:
+            dist.broadcast_object_list(ids, src=0)
+        self._comm = C.c_void_p()
+        raw = (C.c_uint8 * 128).from_buffer_copy(ids[0])
+        with torch.cuda.device(self.device):
+            N.check(N.lib().mmvae_dp_init(raw, int(rank), int(world_size), C.byref(self._comm)), "mmvae_dp_init")
+
+    def allreduce_mean_(self, buf: torch.Tensor):
+        from . import _native as N
+        assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+        N.check(N.lib().mmvae_allreduce_grads(self._comm, buf.data_ptr(), buf.numel(),
+                                              torch.cuda.current_stream(buf.device).cuda_stream), "mmvae_allreduce_grads")
+        return buf
+
+    def close(self):
+        from . import _native as N
+        if self._comm:
+            N.lib().mmvae_dp_destroy(self._comm)
+            self._comm = None
+
+
+_DIRECT = {}
+
+
+def direct_comm(device) -> "DirectComm":
+    """The process's DirectComm for ``device`` (created on first use: collective, every rank reaches it in its first
+    data-parallel step)."""
+    key = torch.device(device).index or 0
+    if key not in _DIRECT:
+        ws = dist.get_world_size() if dist.is_initialized() else 1
+        rk = dist.get_rank() if dist.is_initialized() else 0
+        _DIRECT[key] = DirectComm(rk, ws, device)
+    return _DIRECT[key]
+
+
 def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
     """One data-parallel step: fused forward + loss + backward, gradient all-reduce (average), Adam.
 
@@ -71,7 +121,9 @@ def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
     TWO: the fc11.weight / fc11.bias ranges of every arm (47 % of the buffer) are final as soon as their GEMM has finished
     on the side stream, so they are gathered into one staging buffer and all-reduced there, on a communication stream,
     beside the rest of backward; the remaining ranges follow as the second collective.  Off by default: no multi-GPU node
-    has been available to tune it on (round 2's form, 2 A collectives, cost 65 us per step on one rank)."""
+    has been available to tune it on (round 2's form, 2 A collectives, cost 65 us per step on one rank).
+    MMVAE_DP_DIRECT=1 (RCCL only): the single all-reduce is issued by the library itself (``mmvae_allreduce_grads``), on the
+    step's own stream."""
     import os
     from . import _native as N
     active = is_dist() or (rehearse and dist.is_available() and dist.is_initialized())   # rehearse: world size 1
@@ -105,6 +157,9 @@ def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
             work.wait()                      # the communication stream waits for its collective
             v[:, o26:].copy_(st[0])
         torch.cuda.current_stream(flat.device).wait_stream(comm)
+    elif active and os.environ.get("MMVAE_DP_DIRECT", "0") == "1" and dist.get_backend() == "nccl":
+        # the library's own RCCL all-reduce on the step's stream (opt-in: no multi-GPU node has run it yet)
+        direct_comm(flat.device).allreduce_mean_(flat)
     elif active and not is_dist():
         dist.all_reduce(flat, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
     else:

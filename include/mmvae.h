@@ -344,6 +344,23 @@ int mmvae_gather_rows(const float *data, int64_t ld, int64_t n_rows, const int64
 int mmvae_gather_rows_ex(const float *data, int64_t ld, int64_t n_rows, const int64_t *idx, int64_t n, int32_t D,
                          float *out, int32_t max_workgroups, void *stream);
 
+/* ---- data-parallel gradient exchange (SURVEY.md sections 8b / 8e) ------------------------------------------------------
+ * ONE RCCL all-reduce (average) of the flat fp32 gradient buffer per step, issued by the library on the stream the step
+ * runs on (stream-ordered behind mmvae_train_step(do_adam = 0), in front of mmvae_adam_step; no host synchronisation, no
+ * second stream).  Replaces the reference's FSDP gradient traffic (train.py:140-143; the bring-up of
+ * mmidas/_dist_utils.py:12-55 for this collective).  RCCL is resolved at run time (librccl.so.1): without it these entry
+ * points return MMVAE_E_UNSUPPORTED and everything else works.  One process per GPU:
+ *   rank 0:      mmvae_dp_unique_id(id)         and hands the 128 bytes to every rank (any channel: a file, a store, MPI)
+ *   every rank:  mmvae_dp_init(id, rank, world_size, &comm)      on its device (collective: returns when all have called)
+ *   per step:    mmvae_allreduce_grads(comm, grads, n, stream)   in place; every rank with the same n
+ *   at the end:  mmvae_dp_destroy(comm)
+ * The communicator is caller-owned; the library keeps nothing but the resolved RCCL entry points. */
+#define MMVAE_DP_ID_BYTES 128
+int mmvae_dp_unique_id(uint8_t id[MMVAE_DP_ID_BYTES]);
+int mmvae_dp_init(const uint8_t id[MMVAE_DP_ID_BYTES], int rank, int world_size, void **comm);
+int mmvae_allreduce_grads(void *comm, float *grads, int64_t n, void *stream);
+int mmvae_dp_destroy(void *comm);
+
 /* Writes the noise the Philox mode (nz->mode == 1) would use, in explicit-buffer form, so a test
  * can replay a Philox step through mode 0.  Any output pointer may be NULL. */
 int mmvae_dump_noise(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz,

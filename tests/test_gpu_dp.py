@@ -152,3 +152,25 @@ def test_train_dp_entry_runs_two_ranks_on_one_gpu(tmp_path):
     assert len(a["hist"]["losses"]) == 2 and np.isfinite(a["hist"]["losses"]).all()
     assert a["hist"]["losses"] == b["hist"]["losses"]        # all-reduced epoch means: the same number on every rank
     assert not torch.equal(a["bn"], b["bn"])                  # BatchNorm running statistics stay rank-local
+
+
+def test_library_allreduce_entry_on_one_rank():
+    """mmvae_dp_unique_id / mmvae_dp_init / mmvae_allreduce_grads / mmvae_dp_destroy (include/mmvae.h) on a one-rank
+    communicator -- all a one-GPU box can run (RCCL refuses two ranks on one device): the average over one rank is the
+    identity, the call is ordered on the stream it is given, and a destroyed communicator is refused."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd import dist as D
+    dev = torch.device("cuda", 0)
+    comm = D.DirectComm(0, 1, dev)
+    g = torch.randn(1 << 20, device=dev)
+    want = g.clone() * 3.0
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        g.mul_(3.0)                       # queued in front of the collective on the same stream
+        comm.allreduce_mean_(g)
+        out = g + 0.0
+    s.synchronize()
+    assert torch.equal(out, want)
+    comm.close()
+    comm.close()
