@@ -14,6 +14,7 @@
 // the next launch has to recombine (40 instead of 157 at B = 5000).
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mmvae {
 
@@ -981,18 +982,25 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
                     // split-K slabs of the producing GEMM: all (up to 16) requested before the first add -- a loop
                     // with a running sum waits for one memory latency per slab
                     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.nslab == 1) g = ldg4_t<V>(G, N, b0 + row, col, B, N);
-                    else for (int s0 = 0; s0 < a.nslab; s0 += 16) {
-                        float4 t[16];
+                    // (chunks of 4 for up to four slabs, of 16 beyond: clamped duplicates of the last slab cost a pass through
+                    // the vector-memory pipe each -- 16 loads issued for the benchmark's 3 slabs were 5 x the needed ones)
+                    auto add_slabs = [&](auto chunk) __attribute__((always_inline)) {
+                        constexpr int CHK = decltype(chunk)::value;
+                        for (int s0 = 0; s0 < a.nslab; s0 += CHK) {
+                            float4 t[CHK];
 #pragma unroll
-                        for (int sl = 0; sl < 16; ++sl)
-                            t[sl] = ldg4_t<V>(G + (int64_t)min(s0 + sl, a.nslab - 1) * a.slab_stride, N, b0 + row, col, B, N);
+                            for (int sl = 0; sl < CHK; ++sl)
+                                t[sl] = ldg4_t<V>(G + (int64_t)min(s0 + sl, a.nslab - 1) * a.slab_stride, N, b0 + row, col, B, N);
 #pragma unroll
-                        for (int sl = 0; sl < 16; ++sl) {
-                            const bool on = s0 + sl < a.nslab;
-                            g.x += on ? t[sl].x : 0.f; g.y += on ? t[sl].y : 0.f; g.z += on ? t[sl].z : 0.f; g.w += on ? t[sl].w : 0.f;
+                            for (int sl = 0; sl < CHK; ++sl) {
+                                const bool on = s0 + sl < a.nslab;
+                                g.x += on ? t[sl].x : 0.f; g.y += on ? t[sl].y : 0.f; g.z += on ? t[sl].z : 0.f; g.w += on ? t[sl].w : 0.f;
+                            }
                         }
-                    }
+                    };
+                    if (a.nslab == 1) g = ldg4_t<V>(G, N, b0 + row, col, B, N);
+                    else if (a.nslab <= 4) add_slabs(std::integral_constant<int, 4>{});
+                    else add_slabs(std::integral_constant<int, 16>{});
                     gq[j] = g;
                     avq[j] = ldg4_t<V>(act, N, b0 + row, col, B, N);
                     mmq[j] = ldg4_t<V>(mu, 0, 0, col, 1, N);

@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256) void k_fc1_fwd(const float* __restrict__ x, in
 // fc1 epilogue: R1 = relu(scale * sum_ks slab + b1), per-block column mean / M2 for BatchNorm.
 // grid (ceil(B/32), A), 256 threads: thread t -> float4 column group t & 31 (columns 4c..4c+3), rows
 // (t >> 5) + 8 i, i < 4.  All KS x 4 slab loads of a thread are independent float4 loads.
+template <int CH>   // slab loads in flight per row and thread: the smallest of 4 / 8 / 16 that covers KS (clamped duplicates of
+                    // the last slab cost a pass through the vector-memory pipe each: 16 issued for KS = 6 was 2.7 x the loads)
 __global__ __launch_bounds__(256) void k_fc1_epi(const float* __restrict__ slab, const float* __restrict__ params,
                                                  int64_t per_arm, int64_t b_off, float scale,
                                                  float* __restrict__ R1, float* __restrict__ part,
@@ -186,13 +188,13 @@ __global__ __launch_bounds__(256) void k_fc1_epi(const float* __restrict__ slab,
         const int rc = min(row, B - 1);
         // split-K slabs: sixteen requested before the first add (a running-sum loop waits for every load in turn)
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k0 = 0; k0 < KS; k0 += 16) {
-            float4 t[16];
+        for (int k0 = 0; k0 < KS; k0 += CH) {
+            float4 t[CH];
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
+            for (int k = 0; k < CH; ++k)
                 t[k] = *reinterpret_cast<const float4*>(slab + (((int64_t)min(k0 + k, KS - 1) * A + arm) * B + rc) * NP + c4 * 4);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < CH; ++k) {
                 const bool on = k0 + k < KS;
                 z.x += on ? t[k].x : 0.f; z.y += on ? t[k].y : 0.f; z.z += on ? t[k].z : 0.f; z.w += on ? t[k].w : 0.f;
             }
@@ -601,10 +603,18 @@ int launch_fc1_epi(const Ctx& c, const float* params) {
     const mmvae_dims& d = c.d;
     const int KS = c.lay.sp.ks_fc1;
     const float scale = (c.h.training && c.h.x_drop > 0.f) ? 1.f / (1.f - c.h.x_drop) : 1.f;
-    hipLaunchKernelGGL(k_fc1_epi, dim3(c.lay.nblk32, d.A), dim3(256), 0, c.stream, c.ws + c.lay.fc1_slab, params,
-                       c.po.per_arm, c.po.o[1], scale, c.ws + c.lay.R[0], c.ws + c.lay.bn_part[0],
-                       c.h.training && c.use_acc() ? reinterpret_cast<long long*>(c.ws + acc_set_off(c.lay, d.A, 0)) : nullptr,
-                       d.A, d.B, d.H, KS);
+    long long* acc = c.h.training && c.use_acc() ? reinterpret_cast<long long*>(c.ws + acc_set_off(c.lay, d.A, 0)) : nullptr;
+    const dim3 grid(c.lay.nblk32, d.A);
+    // the smallest slab-load chunk (4 / 8 / 16 in flight per row) that covers the split count
+    if (KS <= 4)
+        hipLaunchKernelGGL(k_fc1_epi<4>, grid, dim3(256), 0, c.stream, c.ws + c.lay.fc1_slab, params, c.po.per_arm, c.po.o[1], scale,
+                           c.ws + c.lay.R[0], c.ws + c.lay.bn_part[0], acc, d.A, d.B, d.H, KS);
+    else if (KS <= 8)
+        hipLaunchKernelGGL(k_fc1_epi<8>, grid, dim3(256), 0, c.stream, c.ws + c.lay.fc1_slab, params, c.po.per_arm, c.po.o[1], scale,
+                           c.ws + c.lay.R[0], c.ws + c.lay.bn_part[0], acc, d.A, d.B, d.H, KS);
+    else
+        hipLaunchKernelGGL(k_fc1_epi<16>, grid, dim3(256), 0, c.stream, c.ws + c.lay.fc1_slab, params, c.po.per_arm, c.po.o[1], scale,
+                           c.ws + c.lay.R[0], c.ws + c.lay.bn_part[0], acc, d.A, d.B, d.H, KS);
     HIP_LAUNCH_CHECK("k_fc1_epi");
     return 0;
 }

@@ -2,7 +2,7 @@
 # Collect this round's measurement artefacts ON the GPU box (run from the repo root through gpurun); writes
 # gpurun_out/<round>/..., which the builder then copies into profiles/.
 #   tools/collect_profiles.sh r02
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -14,6 +14,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_fp32 -- $BEN
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_mfma -- $BENCH --gemm-dtype fp32_mfma > $OUT/kstats_mfma.json 2> $OUT/kstats_mfma.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_bf16 -- $BENCH --gemm-dtype bf16 > $OUT/kstats_bf16.json 2> $OUT/kstats_bf16.err
 cp $(find $OUT/kstats_fp32 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
+# one step's kernel timeline (start offset, duration, queue): default launch sequence, and with the encoder chains as one launch each
+python3 $ROOT/tools/step_timeline.py $OUT/kstats_fp32 > $OUT/${R}_step_timeline.txt
+MMVAE_FUSED_CHAIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_fused -- $BENCH > $OUT/kstats_fused.json 2> $OUT/kstats_fused.err
+python3 $ROOT/tools/step_timeline.py $OUT/kstats_fused > $OUT/${R}_step_timeline_fused_chain.txt
+cp $(find $OUT/kstats_fused -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_fused_chain_kernel_stats.csv
 cp $(find $OUT/kstats_mfma -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_fp32mfma_kernel_stats.csv
 cp $(find $OUT/kstats_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_bf16_kernel_stats.csv
 # 2. PMC passes (own runs, counters only): HBM traffic, matrix-pipe utilisation
@@ -30,10 +35,10 @@ python3 tools/pmc_summary.py $OUT/pmcb_FETCH_SIZE $OUT/pmcb_WRITE_SIZE > $OUT/${
 python3 tools/pmc_summary.py $OUT/pmc_mfma1 $OUT/pmc_mfma2 > $OUT/${R}_pmc_mfma_summary.csv
 python3 - <<PY
 import hashlib, json
-srcs = ["distributed-vae_amd/csrc/gemm_fast.hip", "distributed-vae_amd/csrc/gemm_bf16.hip", "distributed-vae_amd/csrc/common.hpp"]
+srcs = ["distributed-vae_amd/csrc/gemm_fast.hip", "distributed-vae_amd/csrc/gemm_bf16.hip", "distributed-vae_amd/csrc/common.hpp", "distributed-vae_amd/csrc/chain.hip"]
 json.dump({"sources_sha256": {s: hashlib.sha256(open(s, "rb").read()).hexdigest() for s in srcs},
            "command": "tools/collect_profiles.sh $R"}, open("$OUT/${R}_pmc_meta.json", "w"), indent=1)
 PY
 # drop the bulky raw traces from what travels back (keep the summaries)
-rm -rf $OUT/kstats_fp32 $OUT/kstats_mfma $OUT/kstats_bf16 $OUT/pmc_* $OUT/pmcb_*
+rm -rf $OUT/kstats_fp32 $OUT/kstats_mfma $OUT/kstats_bf16 $OUT/kstats_fused $OUT/pmc_* $OUT/pmcb_*
 ls -la $OUT
