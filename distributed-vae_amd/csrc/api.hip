@@ -141,6 +141,17 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.nblk32 = cdiv(d.B, 32);
     L.nblk64 = cdiv(d.B, 64);
     L.nblkc = cdiv(d.B, CHAIN_ROWS);
+    {
+        // cells per workgroup of the forward chain launches.  Measured at A = 2, B = 5000 (round 3): 64 cells (158 workgroups)
+        // 0.693 ms per step, 48 (210) 0.692, 40 (250: one per CU) 0.695, 32 (314) 0.753 -- a chain launch is a latency chain of
+        // fixed costs (statistics read, weight planes, barriers, the exchange), not of per-row work, so smaller blocks on the idle
+        // CUs buy nothing.  MMVAE_TUNE_CHAIN_ROWS_FWD > 0 sets another block for experiments (accumulator form only).
+        int rows = CHAIN_ROWS;
+        if (ex && ex->tune[MMVAE_TUNE_CHAIN_ROWS_FWD] > 0 && !ex->tune[MMVAE_TUNE_BN_PARTIALS])
+            rows = max(8, min(CHAIN_ROWS, (ex->tune[MMVAE_TUNE_CHAIN_ROWS_FWD] / 8) * 8));
+        L.chain_rows_fwd = rows;
+        L.nblkf = cdiv(d.B, rows);
+    }
     L.nblkl = cdiv(d.B, LAT_ROWS);
     L.sp = default_splits(d, ex);
     int64_t off = 0;
@@ -162,7 +173,7 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.fc1_slab = take((int64_t)L.sp.ks_fc1 * A * B * NP);
     L.n11 = (L.nblk64 + 2) * (max(L.sp.ns_fc11, L.sp.ks_gd10) + 1) + cdiv(d.D, 64);
     L.fc11_part = take(A * (int64_t)L.n11 * 2 + 64);   // + diagnostic stamp counters
-    L.sync_arm_words = rup(4 * rup(L.nblkc, 32) + 2 * 4 * 32, 64);
+    L.sync_arm_words = rup(4 * rup(max(L.nblkc, L.nblkf), 32) + 2 * 4 * 32, 64);
     L.sync_fwd = take(A * (int64_t)L.sync_arm_words);
     L.acc = take((int64_t)ACC_NSETS * A * ACC_SET_FLOATS);   // behind fc11_part and sync_fwd: one zero fill at the start of a forward pass
     L.sync_bwd = take(A * (int64_t)L.sync_arm_words);       // directly behind the backward accumulator sets: one zero fill

@@ -60,6 +60,7 @@ struct ChainFwdArgs {
     int planes_rows;
     int64_t wpl_off;        // fp32x3 form (k_chain_fwd<true>): workspace offset of Layout::pl_small
     int B, ld, wrows;
+    int rows;               // cells per workgroup (<= CHAIN_ROWS, multiple of 8): Layout::chain_rows_fwd
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
     int64_t dbg_off;   // >= 0: workspace offset of a diagnostic stamp-counter block (bit 3 of ablate)
@@ -208,10 +209,11 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     unsigned* const Xp = reinterpret_cast<unsigned*>(Xs);
     unsigned* const Wp = reinterpret_cast<unsigned*>(Ws);
     const int xpl = CHAIN_ROWS * a.ld, wpl = a.wrows * a.ld;     // dwords per plane (X3)
-    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * CHAIN_ROWS;
+    const int arm = blockIdx.y, blk = blockIdx.x, b0 = blk * a.rows;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rt = wv >> 2, ct = wv & 3;
     const int B = a.B, ld = a.ld;
-    const int nvalid = min(CHAIN_ROWS, B - b0);
+    const int nvalid = min(a.rows, B - b0);
+    const int Rlim = b0 + nvalid;            // rows of x beyond the block read as zero (the tile has CHAIN_ROWS rows)
     const float* P = params + (int64_t)arm * a.per_arm;
     const bool stamps = (a.ablate & 8) != 0 && a.dbg_off >= 0;
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
     float4 xq[4];
     if (x_early) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xq[j] = ldg4_t<true>(X, a.K0, b0 + (tid >> 3), ((tid & 7) + 8 * j) * 4, B, a.K0);
+        for (int j = 0; j < 4; ++j) xq[j] = ldg4_t<true>(X, a.K0, b0 + (tid >> 3), ((tid & 7) + 8 * j) * 4, Rlim, a.K0);
     }
     // ---- statistics of the input's BatchNorm: recombined from the producer's partials (training) or
     //      the running buffers' values left in the workspace (eval); zero beyond K0
@@ -307,13 +309,13 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
             for (int cb = 0; cb < c4n; cb += 32) {
                 float4 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (V && x_early) ? xq[j] : ldg4_t<V>(X, a.K0, b0 + row, (cb + part + 8 * j) * 4, B, a.K0);
+                for (int j = 0; j < 4; ++j) v[j] = (V && x_early) ? xq[j] : ldg4_t<V>(X, a.K0, b0 + row, (cb + part + 8 * j) * 4, Rlim, a.K0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = cb + part + 8 * j;
                     float4 o = v[j];
                     if (bn) {   // padded columns: (0 - 0) * 0 = 0; rows past the batch must stay zero
-                        const bool rok = b0 + row < B;
+                        const bool rok = b0 + row < Rlim;
                         const int cc = min(c, 31) * 4;   // BatchNorm widths are <= 128
                         const float4 m4 = *reinterpret_cast<const float4*>(&mean_s[cc]);
                         const float4 r4 = *reinterpret_cast<const float4*>(&rstd_s[cc]);
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         const int N = a.L[a.nlayers - 1].N;
         const int64_t plane = (int64_t)a.planes_rows * 128;
         unsigned short* pl = reinterpret_cast<unsigned short*>(ws + a.planes_off) + (int64_t)arm * 3 * plane;
-        const int rows_here = blk == (int)gridDim.x - 1 ? a.planes_rows - b0 : CHAIN_ROWS;
+        const int rows_here = blk == (int)gridDim.x - 1 ? a.planes_rows - b0 : a.rows;
         for (int i = tid; i < rows_here * 64; i += CH_NT) {
             const int r = i >> 6, c = (i & 63) * 2;
             unsigned w[3] = {0u, 0u, 0u};
@@ -532,6 +534,7 @@ struct EncFusedArgs {
     int64_t wpl_off;
     float bn_eps, bn_momentum;
     int B, H, ld, wrows, nblk;
+    int rows;                       // cells per row block (Layout::chain_rows_fwd, as the per-layer launches)
     int64_t per_arm;
     int skip_mod;                   // tests only: workgroups with blockIdx.x % skip_mod == 1 exit at once, as if they never became resident
     int64_t dbg_off;                // >= 0: diagnostic stamp counters (MMVAE_TUNE_ABLATE_C bit 3), int64 [16] in the workspace
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(CH_NT) void k_enc_fwd_fused(const EncFusedArgs a_in
         for (int j = 0; j < 4; ++j) {
             const int col = (part + 8 * j) * 4;
             const bool ok = col < K;
-            xq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? ((my * CHAIN_ROWS + srow) * K + col) * 4 : -16, 0, 0));
+            xq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && srow < a.rows) ? ((my * a.rows + srow) * K + col) * 4 : -16, 0, 0));
         }
     }
     float vals[16];
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(CH_NT) void k_enc_fwd_fused(const EncFusedArgs a_in
             break;
         }
         // ================================ item (l, b) ================================
-        const int N = a.N[l], b0 = b * CHAIN_ROWS, nvalid = min(CHAIN_ROWS, B - b0);
+        const int N = a.N[l], b0 = b * a.rows, nvalid = min(a.rows, B - b0);
         const int col = ct * 32 + (lane & 31);
         // the input rows of a picked-up block come from global memory (stored write-through by whoever computed them)
         if (!fast && !(l == 0 && xq_block == b)) {
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(CH_NT) void k_enc_fwd_fused(const EncFusedArgs a_in
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = (part + 8 * j) * 4;
-                const int off = c < K ? ((b0 + srow) * K + c) * 4 : -16;
+                const int off = (c < K && srow < a.rows) ? ((b0 + srow) * K + c) * 4 : -16;
                 xq[j] = l > 0 ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 16))
                               : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
             }
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(CH_NT) void k_enc_fwd_fused(const EncFusedArgs a_in
                 }
             }
         } else {
-            const bool rok = b0 + srow < B;
+            const bool rok = srow < nvalid;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = part + 8 * j;
@@ -1574,7 +1577,8 @@ static size_t chain_smem(int ld, int wrows) { return (size_t)(CHAIN_ROWS * ld + 
 static int x3_ld(int maxdim) { return rup(maxdim, 16) / 2 + 4; }
 static size_t chain_smem_x3(int ld, int wrows) { return (size_t)(3 * CHAIN_ROWS * ld + 3 * wrows * ld + 256) * sizeof(float); }
 static int launch_fwd(const Ctx& c, ChainFwdArgs& a, int maxdim, const float* params, float* bn_running, int64_t* nbt, const char* what) {
-    const dim3 grid(c.lay.nblkc, c.d.A);
+    a.rows = c.lay.chain_rows_fwd;
+    const dim3 grid(c.lay.nblkf, c.d.A);
     if (c.small_planes && chain_x3_ok(c) && maxdim <= 128) {
         a.ld = x3_ld(maxdim);
         a.wrows = 128;
@@ -1622,8 +1626,8 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     // buffers); eval: launch_bn_eval_stats has put the running statistics into the workspace
     // BN1's partials come from the fc1 epilogue (32-row blocks), the others from the previous chain launch
     a.bn_part_off = c.h.training ? L.bn_part[i - 1] : -1;
-    a.part_n = (layer == 2) ? L.nblk32 : L.nblkc;
-    a.part_rows = (layer == 2) ? 32 : CHAIN_ROWS;
+    a.part_n = (layer == 2) ? L.nblk32 : L.nblkf;      // (the partial-array form keeps chain_rows_fwd == CHAIN_ROWS)
+    a.part_rows = (layer == 2) ? 32 : L.chain_rows_fwd;
     a.run_mean_off = c.po.bn_mean[i - 1];
     a.run_var_off = c.po.bn_var[i - 1];
     a.run_arm_stride = c.po.bn_per_arm;
@@ -1649,7 +1653,7 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
 // the head of a forward pass zeroes; a stage replayed on its own zeroes them here.
 bool enc_fused_ok(const Ctx& c) {
     return c.h.training && c.use_acc() && c.small_planes && chain_x3_ok(c) && c.d.H <= 128 && (c.d.H & 3) == 0 &&
-           c.tune(MMVAE_TUNE_FUSED_CHAIN) != 0 && (c.lay.nblkc * c.d.A <= 256 || c.tune(MMVAE_TUNE_FUSED_CHAIN) == 3) &&
+           c.tune(MMVAE_TUNE_FUSED_CHAIN) != 0 && (max(c.lay.nblkc, c.lay.nblkf) * c.d.A <= 256 || c.tune(MMVAE_TUNE_FUSED_CHAIN) == 3) &&
            c.tune(MMVAE_TUNE_FUSED_CHAIN) != 5;
 }
 int launch_chain_fwd_enc_fused(const Ctx& c, const float* params, float* bn_running, int64_t* nbt) {
@@ -1669,12 +1673,12 @@ int launch_chain_fwd_enc_fused(const Ctx& c, const float* params, float* bn_runn
     for (int l = 0; l <= ENC_NL; ++l) { a.r_off[l] = L.R[l]; a.acc_off[l] = acc_set_off(L, d.A, l); }
     a.run_arm_stride = c.po.bn_per_arm;
     a.sync_off = L.sync_fwd;
-    a.nblk_pad = rup(L.nblkc, 32);
+    a.nblk_pad = rup(L.nblkf, 32);
     a.sync_arm_words = L.sync_arm_words;
     a.wpl_off = L.pl_small;
     a.bn_eps = c.h.eps;
     a.bn_momentum = c.h.bn_momentum;
-    a.B = d.B; a.H = d.H; a.nblk = L.nblkc;
+    a.B = d.B; a.H = d.H; a.nblk = L.nblkf; a.rows = L.chain_rows_fwd;
     a.ld = x3_ld(max(d.H, d.L));
     a.wrows = 128;
     a.per_arm = c.po.per_arm;
@@ -1685,7 +1689,7 @@ int launch_chain_fwd_enc_fused(const Ctx& c, const float* params, float* bn_runn
         if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
     }
     const size_t shm = (size_t)(3 * CHAIN_ROWS * a.ld + 3 * a.wrows * a.ld + 256 + CH_RT * 2 * 128 + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_enc_fwd_fused, dim3(L.nblkc, d.A), dim3(CH_NT), shm, c.stream, a, params, c.ws, bn_running, nbt);
+    hipLaunchKernelGGL(k_enc_fwd_fused, dim3(L.nblkf, d.A), dim3(CH_NT), shm, c.stream, a, params, c.ws, bn_running, nbt);
     HIP_LAUNCH_CHECK("k_enc_fwd_fused");
     return 0;
 }

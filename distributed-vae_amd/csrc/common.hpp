@@ -43,6 +43,9 @@ struct Layout {
     // forward, saved for backward
     int64_t R[5];                  // R1..R4 [A,B,H], R5 [A,B,L]
     int nblkc;                       // ceil(B / CHAIN_ROWS)
+    // cells per workgroup of the FORWARD chain launches (CHAIN_ROWS unless MMVAE_TUNE_CHAIN_ROWS_FWD asks for a smaller block:
+    // measured, no gain) and their count
+    int chain_rows_fwd, nblkf;
     int nblkl;                       // ceil(B / LAT_ROWS)
     int64_t bn_mean[5], bn_rstd[5];  // [A,W]
     int64_t bn_part[5];            // [A][nblk32][2][W]   (block mean, block M2)

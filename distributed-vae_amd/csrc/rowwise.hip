@@ -1554,7 +1554,7 @@ static LatArgs make_lat_args(const Ctx& c) {
     a.T = L.T; a.c_mean = L.c_mean; a.c_iv = L.c_iv;
     a.am1 = (float)(d.A > 1 ? d.A - 1 : 1); a.beta = c.h.beta; a.lam = c.h.lam;
     a.bn_part5 = c.h.training ? L.bn_part[4] : -1;
-    a.bn5_n = L.nblkc;
+    a.bn5_n = L.nblkf;   // (partial-array form: chain_rows_fwd == CHAIN_ROWS)
     a.acc_bn5 = (c.h.training && c.use_acc()) ? acc_set_off(L, d.A, 4) : -1;
     a.acc_bnb5 = c.use_acc() ? acc_set_off(L, d.A, ACC_BWD + 4) : -1;
     a.acc_c = (c.h.training && c.use_acc()) ? acc_set_off(L, d.A, ACC_C) : -1;

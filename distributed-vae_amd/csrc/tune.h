@@ -11,7 +11,9 @@ enum {
     MMVAE_TUNE_ABLATE_C = 4,       // chain kernels: timing ablations / cycle stamps (bit 3: stamps; results wrong with bits 0..2)
     MMVAE_TUNE_ABLATE = 5,         // fc1 forward ablations (fp32 matrix-instruction kernels)
     MMVAE_TUNE_PADLDS = 6,         // fc1 forward: extra dynamic LDS (occupancy experiments)
-    // 7 .. 13: removed in round 3 (forcing the general-width kernels at fc_dim 100, fc11 grid shape, fc11 ablations)
+    MMVAE_TUNE_CHAIN_ROWS_FWD = 7, // cells per workgroup of the forward chain launches: 0 = 64 (as the backward chains), > 0 = this
+                                   // many (multiple of 8, <= 64; measured: no gain from smaller blocks, api.hip make_layout)
+    // 9 .. 13: removed in round 3 (forcing the general-width kernels at fc_dim 100, fc11 grid shape, fc11 ablations)
     MMVAE_TUNE_FC11_ZG_OFF = 8,    // fc11 forward, loss and d(d10) as separate launches instead of the fused kernel
     MMVAE_TUNE_ABLATE_L = 14,      // latent kernels: ablations / stamps
     MMVAE_TUNE_LAT_FULLWAVE = 15,  // latent kernels: one wave per cell instead of the half-wave layout
