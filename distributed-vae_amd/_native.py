@@ -154,6 +154,9 @@ def lib():
     L.mmvae_adam_step.argtypes = [i64, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
     L.mmvae_train_step.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp,
                                    C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, ex, vp]
+    L.mmvae_train_step_rows.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, i64, vp, vp,
+                                        C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, ex, vp]
+    L.mmvae_train_step_rows.restype = C.c_int
     L.mmvae_debug_stage.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), i32, vp, vp, i64, vp,
                                     C.c_size_t, vp, ex, vp]
     L.mmvae_dump_noise.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, vp]
@@ -388,6 +391,18 @@ class Engine:
                                      _ptr(grads), _ptr(self.loss_buf), int(do_adam), _ptr(exp_avg), _ptr(exp_avg_sq),
                                      int(step), lr, b1, b2, adam_eps, wd, int(decoupled), self._x(), self._s()),
               "mmvae_train_step")
+        return self.loss_buf
+
+    def train_step_rows(self, hyper, noise, params, bn_running, nbt, data, rows, grads, do_adam, exp_avg,
+                        exp_avg_sq, step, lr, b1=0.9, b2=0.999, adam_eps=1e-8, wd=0.0, decoupled=False):
+        """The fused step on a batch that is never materialised: cell b = row rows[b] of the resident matrix ``data``
+        (mmvae_train_step_rows).  Raises NotImplementedError where the library does not offer it (gather then)."""
+        assert data.dim() == 2 and data.stride(1) == 1 and rows.dtype == torch.int64 and rows.numel() == self.dims.B
+        check(lib().mmvae_train_step_rows(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params),
+                                          _ptr(bn_running), _ptr(nbt), _ptr(data), int(data.stride(0)), int(data.shape[0]),
+                                          _ptr(rows), _ptr(self.ws), self.ws_bytes, _ptr(grads), _ptr(self.loss_buf),
+                                          int(do_adam), _ptr(exp_avg), _ptr(exp_avg_sq), int(step), lr, b1, b2, adam_eps, wd,
+                                          int(decoupled), self._x(), self._s()), "mmvae_train_step_rows")
         return self.loss_buf
 
     def eval_classify(self, hyper: Hyper, params, bn_running, x, x_arm_stride, labels, counts=None):

@@ -196,6 +196,17 @@ class cpl_mixVAE:
         self.optimizer.step()
         return buf
 
+    def _step_rows(self, data: torch.Tensor, rows: torch.Tensor):
+        """``_step`` on the batch ``data[rows]`` read in place (``mixVAE_model.fused_train_step_rows``)."""
+        if D.is_dist():
+            return D.dp_train_step(self.model, None, self.temp, self.optimizer, rows=(data, rows))
+        if isinstance(self.optimizer, FusedAdam) and self.optimizer.model is self.model:
+            return self.model.fused_train_step_rows(data, rows, self.temp, self.optimizer, do_adam=True)
+        buf = self.model.fused_train_step_rows(data, rows, self.temp, None, do_adam=False)
+        self.model.bind_grads()
+        self.optimizer.step()
+        return buf
+
     def train_step(self, x: torch.Tensor):
         """One batch of cpl_mixvae.py:416-463 (x -> device, x.expand over arms, [augmenter,] zero_grad, forward,
         loss, backward, optimizer step).  Returns the device loss vector; no host synchronisation."""
@@ -219,6 +230,29 @@ class cpl_mixVAE:
         def first(b):
             return b[0] if isinstance(b, (tuple, list)) else b
 
+        # A device-resident loader without an augmenter in front of the step: the batch is never assembled -- the step reads the
+        # resident matrix through the epoch's row indices (mmvae_train_step_rows: fc1, the fused fc11 kernel and dW1 take a
+        # row map), so a shuffled epoch costs what fixed batches do (the 100 MB row gather per step, and the hook that hid it
+        # beside the encoder chain, are gone from this path).  Where the library does not offer it (other GEMM engines,
+        # matrices beyond 4 GB) the first step says so and the epoch falls back to gathered batches.
+        if (self.netA is None and self.device.type == "cuda" and hasattr(loader, "iter_rows")
+                and getattr(loader, "data", None) is not None and os.environ.get("MMVAE_ROWS", "1") != "0"
+                and getattr(self, "_rows_ok", True)):
+            it = loader.iter_rows()
+            first_rows = next(it, None)
+            if first_rows is None:
+                return
+            try:
+                buf = self._step_rows(loader.data, first_rows)
+            except NotImplementedError:
+                self._rows_ok = False
+                if hasattr(loader, "_auto_epoch") and loader._auto_epoch is not None:
+                    loader._auto_epoch -= 1          # the abandoned iterator had taken this epoch's permutation
+            else:
+                yield buf
+                for rows in it:
+                    yield self._step_rows(loader.data, rows)
+                return
         if self.device.type != "cuda" or not self.pipeline:
             for b in loader:
                 yield self.train_step(first(b))
@@ -277,7 +311,7 @@ class cpl_mixVAE:
         thin = use_hook and hasattr(loader, "gather_workgroups")
         prev_wg = getattr(loader, "gather_workgroups", 0)
         if thin:
-            loader.gather_workgroups = 512                      # beside the step: thinner and 10 us longer, 7 us cheaper per step
+            loader.gather_workgroups = int(os.environ.get("MMVAE_GATHER_WG", "512"))   # beside the step: thinner and 10 us longer, 7 us cheaper per step
         try:
             while cur is not None:
                 # ring buffers (loader batches, augmenter outputs) are reused every few batches: the side stream may only

@@ -201,6 +201,7 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
         L.pl_d10 = take(A * 3 * Br * 128 / 2);
         L.pl_small = take(A * (int64_t)PL_SMALL_SLOTS * 3 * 128 * 128 / 2);
     }
+    L.rowmap = take(B);
     L.loss_scratch = take(4096);
     L.total = off;
     return L;
@@ -581,13 +582,10 @@ int mmvae_adam_step(int64_t n, float* params, const float* grads, float* exp_avg
                        reinterpret_cast<hipStream_t>(stream));
 }
 
-int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, float* params,
-                     float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes,
-                     float* grads, float* loss_out, int do_adam, float* exp_avg, float* exp_avg_sq, int64_t step,
-                     float lr, float beta1, float beta2, float adam_eps, float weight_decay, int decoupled,
-                     mmvae_exec* ex, void* stream) {
-    Ctx c;
-    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
+static int train_step_impl(Ctx& c, const mmvae_hyper* h, const mmvae_noise* nz, float* params,
+                           float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride,
+                           float* grads, float* loss_out, int do_adam, float* exp_avg, float* exp_avg_sq, int64_t step,
+                           float lr, float beta1, float beta2, float adam_eps, float weight_decay, int decoupled) {
     if (!params || !x || !grads || !loss_out) { set_error("null params / x / grads / loss_out"); return MMVAE_E_BADARG; }
     if (int rc = check_noise(c, nz)) return rc;
     if (!h->training) { set_error("train_step requires training mode"); return MMVAE_E_UNSUPPORTED; }
@@ -609,6 +607,44 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
         return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, &ah, loss_on_side, loss_on_side ? loss_out : nullptr);
     }
     return do_backward(c, nz, params, x, x_arm_stride, 1.f, grads, nullptr, loss_on_side, loss_on_side ? loss_out : nullptr);
+}
+
+int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, float* params,
+                     float* bn_running, int64_t* nbt, const float* x, int64_t x_arm_stride, void* ws, size_t ws_bytes,
+                     float* grads, float* loss_out, int do_adam, float* exp_avg, float* exp_avg_sq, int64_t step,
+                     float lr, float beta1, float beta2, float adam_eps, float weight_decay, int decoupled,
+                     mmvae_exec* ex, void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
+    return train_step_impl(c, h, nz, params, bn_running, nbt, x, x_arm_stride, grads, loss_out, do_adam, exp_avg, exp_avg_sq, step,
+                           lr, beta1, beta2, adam_eps, weight_decay, decoupled);
+}
+
+int mmvae_train_step_rows(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, float* params,
+                          float* bn_running, int64_t* nbt, const float* data, int64_t ld, int64_t n_rows, const int64_t* rows,
+                          void* ws, size_t ws_bytes, float* grads, float* loss_out, int do_adam, float* exp_avg,
+                          float* exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float adam_eps,
+                          float weight_decay, int decoupled, mmvae_exec* ex, void* stream) {
+    Ctx c;
+    if (int rc = make_ctx(c, d, h, ws, ws_bytes, ex, stream)) return rc;
+    if (!data || !rows || n_rows < 1 || ld < d->D) { set_error("train_step_rows: null data / rows, n_rows < 1 or ld < D"); return MMVAE_E_BADARG; }
+    // what the row-indexed kernels take: the fp32x3 engine's fused step (its head launch builds the row map), 16-byte rows,
+    // a matrix within reach of 32-bit byte offsets.  Everything else: gather the batch (mmvae_gather_rows) and call
+    // mmvae_train_step.
+    if ((ld & 3) || (reinterpret_cast<uintptr_t>(data) & 15) || n_rows * ld >= ((int64_t)1 << 30)) {
+        set_error("train_step_rows: needs ld %% 4 == 0, 16-byte aligned data and n_rows * ld < 2^30 floats");
+        return MMVAE_E_UNSUPPORTED;
+    }
+    if (!h->training || !(h->x_drop > 0.f) || !split3_gemms(c) || !prologue_merged(c) || !fast_path_ok(c, params, data, 0) ||
+        d->H + 1 > 112 || (int64_t)cdiv(d->B, 128) * c.lay.sp.ks_gd10 > c.lay.n11 || c.tune(MMVAE_TUNE_FC11_ZG_OFF)) {
+        set_error("train_step_rows: only the fp32x3 engine's fused training step reads the batch through a row map");
+        return MMVAE_E_UNSUPPORTED;
+    }
+    c.x_rows = rows;
+    c.x_ld = ld;
+    c.x_nrows = n_rows;
+    return train_step_impl(c, h, nz, params, bn_running, nbt, data, 0, grads, loss_out, do_adam, exp_avg, exp_avg_sq, step,
+                           lr, beta1, beta2, adam_eps, weight_decay, decoupled);
 }
 
 int mmvae_eval_classify(const mmvae_dims* d, const mmvae_hyper* h, const float* params, const float* bn_running,

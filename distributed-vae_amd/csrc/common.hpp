@@ -87,6 +87,7 @@ struct Layout {
     // zeroes), sync_bwd directly behind acc (inside the range the first kernel of a backward pass zeroes).
     int64_t sync_fwd, sync_bwd;
     int sync_arm_words;
+    int64_t rowmap;                // uint32 [B]: element offsets of the batch's rows in the resident matrix (mmvae_train_step_rows)
     int64_t loss_scratch;          // small
     int64_t total;
 };
@@ -739,6 +740,11 @@ struct Ctx {
     int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, ACC_T) - lay.fc11_part; }
     int64_t bwd_zero_floats() const { return lay.sync_bwd + (int64_t)d.A * lay.sync_arm_words - acc_set_off(lay, d.A, ACC_BWD); }
     mutable bool bwd_zeroed = false;   // set by the launcher of the first kernel of a backward pass (it zeroes that range)
+    // mmvae_train_step_rows: the batch is rows x_rows[0 .. B) (device, int64) of the resident matrix [x_nrows][x_ld] that the
+    // call's `x` points at; the head launch of the step turns them into the row map (Layout::rowmap) and sets rowmap_ready
+    const int64_t* x_rows = nullptr;
+    int64_t x_ld = 0, x_nrows = 0;
+    mutable bool rowmap_ready = false;
 };
 // events of mmvae_exec.ev by role
 enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE /* MMVAE_TUNE_MID_EVENT: behind fc1 */ };

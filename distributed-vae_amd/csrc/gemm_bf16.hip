@@ -103,6 +103,12 @@ struct Operand {
     const unsigned short* pl;
     int64_t pl_plane, pl_arm;    // elements per plane / per arm
     int pl_ld;                   // row pitch (elements)
+    // row indirection (the batch is never materialised: mmvae_train_step_rows): logical row / k index i of the operand lies
+    // at ptr[rowmap[i] .. + ld) instead of ptr[i * ld ..); rowmap: uint32 [map_n] element offsets, nrec: floats addressable
+    // from ptr (< 2^30).  The keep-mask words stay indexed by the logical index.
+    const unsigned* rowmap;
+    int64_t nrec;
+    int map_n;
 };
 
 // One K tile of an operand in flight: rows [r0, r0 + 128) x k [k0, k0 + KT).  `load` only REQUESTS the data (NQ
@@ -121,6 +127,7 @@ struct TileRegsT {
 // matrix; what must read as zero is selected at the LDS store.  Every operand has ld % 4 == 0 and < 4 GB per arm.
 struct OperandDev {
     __amdgpu_buffer_rsrc_t rs, rb;   // matrix, mask words
+    __amdgpu_buffer_rsrc_t rm;       // row map (row indirection; see Operand::rowmap)
     int ld, rows, K, wpr, ones_row;
     bool bits;
     float4 bn_sub, bn_mul;           // BN = true (k_x3_small): this thread's four rows read (v - bn_sub) * bn_mul
@@ -129,7 +136,9 @@ template <bool KMINOR>
 __device__ __forceinline__ OperandDev make_operand_dev(const Operand& o) {
     OperandDev d;
     const int64_t n = KMINOR ? (int64_t)o.K * o.ld : (int64_t)o.rows * o.ld;
-    d.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.ptr), 0, (int)(n * 4), 0x00020000);
+    d.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.ptr), 0, (int)((o.rowmap ? o.nrec : n) * 4), 0x00020000);
+    d.rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(o.rowmap ? o.rowmap : reinterpret_cast<const unsigned*>(o.ptr)), 0,
+                                             (int)((o.rowmap ? o.map_n : 1) * 4), 0x00020000);
     d.bits = o.bits != nullptr;
     const int64_t nb = (KMINOR ? (int64_t)o.K : (int64_t)o.rows) * o.wpr;
     d.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(d.bits ? o.bits : reinterpret_cast<const uint32_t*>(o.ptr)), 0,
@@ -169,6 +178,47 @@ __device__ __forceinline__ void quad_load(TileRegsT<BITS, Eng<NP>::NQ>& t, const
     }
     t.v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 4, 0, 0));
     if constexpr (BITS) t.wd[q] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
+}
+
+// The same request through a row map (Operand::rowmap).  ro[q]: the element offset of piece q's memory row, i.e. of the logical
+// row r0 + (tid >> 3) + 32 p (KMAJOR: the same for every K tile, requested once by ro_init) or of k (KMINOR: requested one
+// stage ahead -- the piece of tile k0 consumes ro[q] and immediately requests the entry of tile k0 + KSTEP, so the map never
+// puts a second memory round trip in front of the operand's load).
+template <bool KMINOR, int NP, int KSTEP>
+__device__ __forceinline__ void quad_load_idx(TileRegsT<true, Eng<NP>::NQ>& t, const OperandDev& o, int r0, int k0, int kend, int q,
+                                              unsigned (&ro)[Eng<NP>::NQ]) {
+    const int tid = threadIdx.x & 255;
+    int p, h;
+    piece_ph<KMINOR, NP>(q, p, h);
+    int off, woff;
+    if (!KMINOR) {
+        const int row = r0 + (tid >> 3) + 32 * p;
+        const int rc = min(row, o.rows - 1);
+        const int k = k0 + ((tid & 7) + 8 * h) * 4;
+        const bool ok = row < o.rows && k + 3 < kend && k + 3 < o.K;
+        off = (int)ro[q] + (ok ? k : 0);
+        woff = rc * o.wpr + ((ok ? k : 0) >> 5);
+    } else {
+        const int k = k0 + 2 * ((tid >> 5) + 8 * p) + h;
+        const int kc = min(k, o.K - 1);
+        const int row = r0 + (tid & 31) * 4;
+        off = (int)ro[q] + (row < o.ld ? row : 0);
+        woff = kc * o.wpr + (min(row, o.rows - 1) >> 5);
+        ro[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(o.rm, min(k + KSTEP, o.K - 1) * 4, 0, 0);
+    }
+    t.v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 4, 0, 0));
+    t.wd[q] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
+}
+template <bool KMINOR, int NP>
+__device__ __forceinline__ void ro_init(unsigned (&ro)[Eng<NP>::NQ], const OperandDev& o, int r0, int kfirst) {
+    const int tid = threadIdx.x & 255;
+#pragma unroll
+    for (int q = 0; q < Eng<NP>::NQ; ++q) {
+        int p, h;
+        piece_ph<KMINOR, NP>(q, p, h);
+        const int i = KMINOR ? min(kfirst + 2 * ((tid >> 5) + 8 * p) + h, o.K - 1) : min(r0 + (tid >> 3) + 32 * p, o.rows - 1);
+        ro[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(o.rm, i * 4, 0, 0);
+    }
 }
 
 template <bool KMINOR, bool BITS = true, int NP = 1, bool BN = false>
@@ -306,10 +356,21 @@ struct SplitJob {
 // The head of a training step as one launch: besides the split jobs, the first xb.blocks blocks of every z-slice make the
 // dropout keep-mask (k_make_xbits' work) and the whole grid zeroes the step's loss partial slots and forward accumulator
 // sets -- one launch boundary and one tail less on the critical path.
-struct XbitsJob { NoiseDev nz; int A, B, D, wpr; uint32_t* bits; int blocks; float* zero_p; int zero_n4; };
+struct XbitsJob {
+    NoiseDev nz; int A, B, D, wpr; uint32_t* bits; int blocks; float* zero_p; int zero_n4;
+    // mmvae_train_step_rows: the row map of the batch, map[b] = rows[b] * ld (element offset of cell b's row in the resident
+    // matrix; indices outside [0, n_rows) are clamped as mmvae_gather_rows does) -- null: the batch is materialised
+    const int64_t* rows; unsigned* map; int64_t rows_ld, n_rows;
+};
 struct SplitJobs { SplitJob j[24]; int first[25]; int n; XbitsJob xb; };   // job i owns blocks [first[i], first[i + 1]) of grid.x (behind xb.blocks)
 __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
     if (js.xb.zero_n4 > 0) grid_zero(js.xb.zero_p, js.xb.zero_n4);
+    if (js.xb.rows && blockIdx.z == 0) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < js.xb.B; i += gridDim.x * 256) {
+            const int64_t r = js.xb.rows[i];
+            js.xb.map[i] = (unsigned)((r < 0 ? 0 : (r >= js.xb.n_rows ? js.xb.n_rows - 1 : r)) * js.xb.rows_ld);
+        }
+    }
     if ((int)blockIdx.x < js.xb.blocks) {
         make_xbits_range(js.xb.nz, js.xb.A, js.xb.B, js.xb.D, js.xb.wpr, js.xb.bits,
                          ((int64_t)blockIdx.z * js.xb.blocks + blockIdx.x) * 256 + threadIdx.x, (int64_t)gridDim.z * js.xb.blocks * 256);
@@ -370,6 +431,8 @@ struct Fc11Out {       // z tile -> + bias, dZ11, loss partials (nn_model.py:286
     float* part;       // this arm's loss partial slots [n11][2]
     float coef;
     int B, D;
+    const unsigned* xmap;   // row indirection (k_x3_fc11g): cell b's row of x lies at x[xmap[b] ..), x_nrec floats addressable; null: x[b * D ..)
+    int64_t x_nrec;
 };
 
 struct AffineOut {     // C tile -> out[m][n] = act(C * scale[n] + shift[n]) (the augmenter's Linear + folded BatchNorm + ReLU);
@@ -559,7 +622,8 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
 // accumulators are added to group 0's through LDS before the epilogue.  For GEMMs with fewer tiles than CUs (the augmenter's
 // 500- and 1000-wide trunk layers at M = 5000: 40 to 160 tiles): twice the workgroups, half the K loop each.  With SPL the B
 // operand comes from planes, copied by each group for its own K tiles.
-template <bool AMINOR, bool BMINOR, int EPI = 0, int SHARE = 0, bool SPL = false>
+// IDX: 1 / 2 = the A / B operand is read through its row map (Operand::rowmap: x of a batch that is never materialised)
+template <bool AMINOR, bool BMINOR, int EPI = 0, int SHARE = 0, bool SPL = false, int IDX = 0>
 __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     typedef Eng<3> E;
     constexpr int KTv = E::KT;
@@ -598,8 +662,10 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     const int kfirst = SHARE == 3 ? kb + grp * KTv : kb;
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegsT<true, E::NQ> ta, tb;
+    unsigned ro[E::NQ] = {};           // IDX: element offsets of the indexed operand's memory rows (see quad_load_idx)
     PlaneRegs ps;
     constexpr bool APL = SPL && SHARE == 1, BPL = SPL && (SHARE == 2 || SHARE == 3);
+    static_assert(IDX == 0 || SHARE != 3, "row indirection: not with the K-alternating form");
     const PlaneDev dp = make_plane_dev(SHARE == 1 ? g.a : g.b, arm);
     const bool do_a = SHARE != 1 || grp == 0, do_b = SHARE != 2 || grp == 0;   // which operands this group stages
     // one piece of each operand in turn; a piece's registers request the next tile as soon as they have been written out
@@ -615,7 +681,10 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             } else if (i < E::NQ) {
                 if (do_a) {
                     quad_store<AMINOR, true, 3>(Ad, ta, oa, m0, kst, ke, i);
-                    if constexpr (LOAD) quad_load<AMINOR, true, 3>(ta, oa, m0, kld, ke, i);
+                    if constexpr (LOAD) {
+                        if constexpr (IDX == 1) quad_load_idx<AMINOR, 3, KTv>(ta, oa, m0, kld, ke, i, ro);
+                        else quad_load<AMINOR, true, 3>(ta, oa, m0, kld, ke, i);
+                    }
                 }
             }
             if constexpr (BPL) {
@@ -626,7 +695,10 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             } else if (i < E::NQ) {
                 if (do_b) {
                     quad_store<BMINOR, true, 3>(Bd, tb, ob, n0, kst, ke, i);
-                    if constexpr (LOAD) quad_load<BMINOR, true, 3>(tb, ob, n0, kld, ke, i);
+                    if constexpr (LOAD) {
+                        if constexpr (IDX == 2) quad_load_idx<BMINOR, 3, KTv>(tb, ob, n0, kld, ke, i, ro);
+                        else quad_load<BMINOR, true, 3>(tb, ob, n0, kld, ke, i);
+                    }
                 }
             }
         }
@@ -637,13 +709,25 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) plane_load<AMINOR>(ps, dp, m0, kfirst, i);
             }
-        } else if (do_a) tile_load<AMINOR, true, 3>(ta, oa, m0, kfirst, ke);
+        } else if (do_a) {
+            if constexpr (IDX == 1) {
+                ro_init<AMINOR, 3>(ro, oa, m0, kfirst);
+#pragma unroll
+                for (int q = 0; q < E::NQ; ++q) quad_load_idx<AMINOR, 3, KTv>(ta, oa, m0, kfirst, ke, q, ro);
+            } else tile_load<AMINOR, true, 3>(ta, oa, m0, kfirst, ke);
+        }
         if constexpr (BPL) {
             if (do_b) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) plane_load<BMINOR>(ps, dp, n0, kfirst, i);
             }
-        } else if (do_b) tile_load<BMINOR, true, 3>(tb, ob, n0, kfirst, ke);
+        } else if (do_b) {
+            if constexpr (IDX == 2) {
+                ro_init<BMINOR, 3>(ro, ob, n0, kfirst);
+#pragma unroll
+                for (int q = 0; q < E::NQ; ++q) quad_load_idx<BMINOR, 3, KTv>(tb, ob, n0, kfirst, ke, q, ro);
+            } else tile_load<BMINOR, true, 3>(tb, ob, n0, kfirst, ke);
+        }
     }
 #ifdef X3_STAMPS
     long long t_st = 0, t_mf = 0, t_bar = 0, t_ld = 0, t0 = __builtin_amdgcn_s_memtime(), t_begin = t0;
@@ -1039,9 +1123,10 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     const int cell = c0 + 32 * wv + l31;
     const float* xa = g.fo.x + (int64_t)arm * g.fo_x_arm;
     float* dza = g.fo.dz + (int64_t)arm * g.fo_arm;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa), 0, (int)((int64_t)B * D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xa), 0, (int)((g.fo.xmap ? g.fo.x_nrec : (int64_t)B * D) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(dza, 0, (int)((int64_t)B * D * 4), 0x00020000);
-    const int rowoff = min(cell, B - 1) * D;          // B * D < 2^30 (fast-path condition)
+    // this lane's cell: its row of x (through the row map when the batch is not materialised) and of dZ11
+    const int rowoff = g.fo.xmap ? (int)g.fo.xmap[min(cell, B - 1)] : min(cell, B - 1) * D;          // B * D < 2^30 (fast-path condition)
     const bool cell_ok = cell < B;
 
     // LDS-DMA of W11 tile t into buffer (t - t0) % 3: 3 slices x 64 rows x 16 sixteen-byte blocks = 48 wave instructions of
@@ -1427,8 +1512,8 @@ __global__ __launch_bounds__(512, 1) void k_x3_small(const TnDescs descs, int nd
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers (same workspace layouts and split factors as the fp32 fast path)
 // ---------------------------------------------------------------------------------------------------------------
-static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1, nullptr, 0, 0, 0}; }
-static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1, nullptr, 0, 0, 0}; }
+static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1, nullptr, 0, 0, 0, nullptr, 0, 0}; }
+static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1, nullptr, 0, 0, 0, nullptr, 0, 0}; }
 
 // Slice planes of the four small operands (fp32x3 engine).  They are written by launch_x3_planes at fixed points of the
 // step -- W1 and [W11 | b11] at the start of the forward pass, [d10 | 1] behind the decoder chain, dZ1 behind the encoder's
@@ -1487,6 +1572,11 @@ int launch_x3_planes(const Ctx& c, const float* params, int which, const mmvae_n
         xb.zero_p = c.ws + c.lay.fc11_part;
         xb.zero_n4 = (int)(c.fwd_zero_floats() / 4);
         c.fwd_zeroed = true;
+        if (c.x_rows) {
+            xb.rows = c.x_rows; xb.map = reinterpret_cast<unsigned*>(c.ws + c.lay.rowmap);
+            xb.rows_ld = c.x_ld; xb.n_rows = c.x_nrows;
+            c.rowmap_ready = true;
+        }
     }
     if (!x3) which &= 9;   // bf16 configuration: only the chain kernels take planes
     const mmvae_dims& d = c.d;
@@ -1529,7 +1619,12 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
     g.M = d.B; g.N = d.H; g.K = d.D; g.KS = c.lay.sp.ks_fc1; g.A = d.A;
     g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
     g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
-    if (split3_gemms(c)) {   // (fc_dim <= 124: one tile wide, the two tiles of a block share the W1 tile)
+    if (c.x_rows) {   // the batch as rows of the resident matrix (mmvae_train_step_rows): x is read through the row map
+        if (!split3_gemms(c) || !c.rowmap_ready) { set_error("row-indexed batches need the fp32x3 engine's fused step"); return MMVAE_E_UNSUPPORTED; }
+        g.a.rowmap = reinterpret_cast<const unsigned*>(c.ws + c.lay.rowmap); g.a.nrec = c.x_nrows * c.x_ld; g.a.map_n = d.B;
+        use_planes(c, g.b, PL_W1);
+        hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true, 1>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+    } else if (split3_gemms(c)) {   // (fc_dim <= 124: one tile wide, the two tiles of a block share the W1 tile)
         use_planes(c, g.b, PL_W1);
         hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
     } else
@@ -1556,7 +1651,12 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         use_planes(c, g.a, PL_D10);
         g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.A = d.A; g.n11 = L.n11;
         g.fo = Fc11Out{params + c.po.o[27], x, c.ws + L.DZ11, nullptr, c.ws + L.fc11_part,
-                       (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D};
+                       (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D, nullptr, 0};
+        if (c.x_rows) {
+            if (!c.rowmap_ready) { set_error("row-indexed batches need the fp32x3 engine's fused step"); return MMVAE_E_UNSUPPORTED; }
+            g.fo.xmap = reinterpret_cast<const unsigned*>(c.ws + L.rowmap);
+            g.fo.x_nrec = c.x_nrows * c.x_ld;
+        }
         g.fo_arm = (int64_t)d.B * d.D;
         g.fo_x_arm = xs;
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
@@ -1577,7 +1677,8 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.bias_arm = c.po.per_arm;
         g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.A = d.A; g.n11 = L.n11;
         g.fo = Fc11Out{params + c.po.o[27], x, c.ws + L.DZ11, x_rec, c.ws + L.fc11_part,
-                       (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D};
+                       (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D, nullptr, 0};
+        if (c.x_rows) { set_error("row-indexed batches need the fp32x3 engine's fused step"); return MMVAE_E_UNSUPPORTED; }
         g.fo_arm = (int64_t)d.B * d.D;
         g.fo_x_arm = xs;
         if (fused) {   // train step: d(d10) comes out of the same launch (which & 2 is then a no-op)
@@ -1621,7 +1722,12 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.M = d.H; g.N = d.D; g.K = d.B; g.KS = L.sp.ks_dw; g.A = d.A;
         g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
         g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
-        if (split3_gemms(c)) {   // one tile high: the two tiles of a block share the dZ1 tile
+        if (c.x_rows) {
+            if (!split3_gemms(c) || !c.rowmap_ready) { set_error("row-indexed batches need the fp32x3 engine's fused step"); return MMVAE_E_UNSUPPORTED; }
+            g.b.rowmap = reinterpret_cast<const unsigned*>(c.ws + L.rowmap); g.b.nrec = c.x_nrows * c.x_ld; g.b.map_n = d.B;
+            use_planes(c, g.a, PL_DZ1);
+            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true, 2>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+        } else if (split3_gemms(c)) {   // one tile high: the two tiles of a block share the dZ1 tile
             use_planes(c, g.a, PL_DZ1);
             hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
         } else

@@ -114,7 +114,7 @@ def direct_comm(device) -> "DirectComm":
     return _DIRECT[key]
 
 
-def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
+def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False, rows=None):
     """One data-parallel step: fused forward + loss + backward, gradient all-reduce (average), Adam.
 
     Default: ONE all-reduce of the whole flat buffer when backward is done.  MMVAE_DP_OVERLAP=1 (RCCL only) splits it in
@@ -128,10 +128,13 @@ def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False):
     from . import _native as N
     active = is_dist() or (rehearse and dist.is_available() and dist.is_initialized())   # rehearse: world size 1
     overlap = (active and dist.get_backend() == "nccl" and os.environ.get("MMVAE_DP_OVERLAP", "0") == "1")
-    B = xs.shape[-2]
+    B = xs.shape[-2] if rows is None else int(rows[1].numel())
     eng = model._ensure(B)
     eng.enable_early_grad_event(overlap)
-    buf = model.fused_train_step(xs, temp, optimizer, do_adam=False)
+    if rows is not None:      # (data, row indices): the batch is read through a row map, never materialised
+        buf = model.fused_train_step_rows(rows[0], rows[1], temp, optimizer, do_adam=False)
+    else:
+        buf = model.fused_train_step(xs, temp, optimizer, do_adam=False)
     flat = model.flat_grad()
     if overlap and eng.early_event is not None and eng.early_recorded():
         # TWO collectives (round 2 issued 2 A): the fc11 ranges of all arms are gathered into one contiguous staging buffer

@@ -418,6 +418,39 @@ class mixVAE_model(nn.Module):
                               None, None, 1, 0.0)
 
 
+    def fused_train_step_rows(self, data, rows, temp, opt=None, do_adam=True):
+        """``fused_train_step`` on the batch ``data[rows]`` without materialising it (``x.expand`` over the arms): the step
+        reads the cells x genes matrix through a row map (mmvae_train_step_rows; bit-identical to gather + step).  Raises
+        ``NotImplementedError`` where the library does not offer it -- engines other than fp32x3, no input dropout, a
+        matrix beyond 4 GB --: gather the batch and call ``fused_train_step`` then."""
+        if data.device.type != "cuda" or data.dtype != torch.float32 or data.shape[1] != self.input_dim:
+            raise N.NativeError("fused_train_step_rows needs the float32 cells x genes matrix on the GPU")
+        rows = rows.to(device=data.device, dtype=torch.int64).contiguous()
+        eng = self._ensure(int(rows.numel()))
+        hyper = self._hyper(temp, False)
+        noise = self._next_noise()
+        try:
+            if do_adam:
+                opt._bind(self)
+                g = opt.param_groups[0]
+                buf = eng.train_step_rows(hyper, noise, self._flat, self._bn_flat, self._nbt, data, rows, self._flat_grad, True,
+                                          opt.exp_avg, opt.exp_avg_sq, opt.step_count + 1, g["lr"], g["betas"][0],
+                                          g["betas"][1], g["eps"], g["weight_decay"], opt.decoupled)
+                opt.step_count += 1
+            else:
+                buf = eng.train_step_rows(hyper, noise, self._flat, self._bn_flat, self._nbt, data, rows, self._flat_grad, False,
+                                          None, None, 1, 0.0)
+        except NotImplementedError:
+            if self._explicit_noise is None:
+                self._noise_offset -= 1            # the refused call consumed nothing
+            elif isinstance(self._explicit_noise, list):
+                self._explicit_noise.insert(0, self._noise_keep)
+            raise
+        self._step_id += 1
+        self._ctx = None
+        return buf
+
+
 def mk_vae(C, state_dim, input_dim, device, eps=1e-8, fc_dim=100, latent_dim=10, x_drop=0.5, s_drop=0.2, lr=0.001,
            lam=1, lam_pc=1, A=2, tau=0.005, beta=1.0, hard=False, variational=True, ref_prior=False, momentum=0.01,
            mode="MSE") -> nn.Module:

@@ -183,6 +183,17 @@ class DeviceLoader:
         for i in range(0, n, int(rows)):
             yield N.gather_rows(self.data, self.index[i:i + int(rows)])
 
+    def iter_rows(self):
+        """One epoch as ROW INDICES instead of gathered batches: yields int64 device tensors ``rows`` (the batch is
+        ``self.data[rows]``), same order, sharding, ``drop_last`` and epoch bookkeeping as ``__iter__``.  For consumers that
+        read the resident matrix through the indices (``mixVAE_model.fused_train_step_rows``): nothing is copied."""
+        order = self._upload(self.epoch_order()) if self.host_order else self.epoch_order_device()
+        if self._auto_epoch is not None:
+            self._auto_epoch += 1
+        rows = self.index[order]
+        for i in range(len(self)):
+            yield rows[i * self.batch_size:(i + 1) * self.batch_size]
+
     def __iter__(self):
         order = self._upload(self.epoch_order()) if self.host_order else self.epoch_order_device()
         if self._auto_epoch is not None:

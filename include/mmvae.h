@@ -272,6 +272,22 @@ int mmvae_train_step(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
                      float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2,
                      float adam_eps, float weight_decay, int decoupled, mmvae_exec *ex, void *stream);
 
+/* mmvae_train_step on a batch that is never materialised: cell b of the batch is row rows[b] of the resident cells x genes
+ * matrix `data` ([n_rows, ld] fp32, ld >= D; rows: int64 [B] on the device, indices outside [0, n_rows) are clamped as
+ * mmvae_gather_rows does), shared by all arms (x.expand).  Replaces the batch assembly of the reference's DataLoader
+ * (mmidas/utils/dataloader.py:114-132: shuffled index batches collated into a fresh tensor, pinned, copied to the device) AND
+ * the per-step row gather of mmvae_gather_rows: fc1, the fused fc11 kernel and dW1 read x through a row map (B 32-bit
+ * offsets the step's head launch derives from `rows`), so a shuffled batch costs what a resident one does.  Bit-identical to
+ * mmvae_gather_rows + mmvae_train_step.  Offered where it is built -- the fp32x3 engine's fused training step (gemm_bf16 & 0xFF
+ * == 2, fc_dim <= 111, x_drop > 0), ld % 4 == 0, 16-byte aligned data, n_rows * ld < 2^30 floats --; otherwise
+ * MMVAE_E_UNSUPPORTED: gather the batch and call mmvae_train_step. */
+int mmvae_train_step_rows(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz, float *params,
+                          float *bn_running, int64_t *num_batches_tracked, const float *data, int64_t ld,
+                          int64_t n_rows, const int64_t *rows, void *ws, size_t ws_bytes, float *grads,
+                          float *loss_out, int do_adam, float *exp_avg, float *exp_avg_sq, int64_t step, float lr,
+                          float beta1, float beta2, float adam_eps, float weight_decay, int decoupled,
+                          mmvae_exec *ex, void *stream);
+
 /* ---- evaluation labels and between-arm consensus ----------------
  * Replaces the per-epoch host loop of mmidas/cpl_mixvae.py:563-657: eval-mode forward of every batch,
  * `classify` = argmax of c (mmidas/_utils.py:79-80), `compute_confmat` per arm pair (:84-95),

@@ -102,3 +102,84 @@ def test_trainer_epoch_from_device_loaders():
     hist = t.train(tr, te, n_epoch=2)
     assert len(hist["losses"]) == 2 and np.isfinite(hist["losses"]).all()
     assert np.isfinite(hist["validation_loss"]).all() and 0.0 <= hist["consensus_train"][-1] <= 1.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# The batch as rows of the resident matrix (mmvae_train_step_rows): never materialised, bit-identical to gather + step
+# ---------------------------------------------------------------------------------------------------
+def _rows_case(A, B, D, H, n_rows, seed):
+    from oracle import restatement as R
+    from tests import gpu_util as U
+    from distributed_vae_amd.cpl_mixvae import FusedAdam
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=12, state_dim=2, lowD_dim=6, n_arm=A)
+    sd = R.init_state_dict(h, seed)
+    data = R.synthetic_batch(n_rows, D, seed=seed + 1).to(U.DEV)
+    g = torch.Generator().manual_seed(seed + 2)
+    rows = torch.randint(0, n_rows, (B,), generator=g)
+    rows[:3] = torch.tensor([n_rows - 1, 0, n_rows - 1])           # repeated rows, both ends
+    res = []
+    for indexed in (False, True):
+        m = U.build_model(h, sd)
+        m.train()
+        opt = FusedAdam(m, lr=1e-3)
+        bufs = []
+        for s in range(2):
+            m.set_explicit_noise(U.noise_to_device(R.draw_noise(h, B, seed=seed + 10 + s)))
+            r = torch.roll(rows, s).to(U.DEV)
+            if indexed:
+                bufs.append(m.fused_train_step_rows(data, r, 1.0, opt, do_adam=True).clone())
+            else:
+                x = data[r].contiguous()
+                bufs.append(m.fused_train_step(x.expand(A, -1, -1), 1.0, opt, do_adam=True).clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(bufs).cpu(), m.flat_parameters().detach().cpu().clone(), m._flat_grad.detach().cpu().clone(),
+                    m._bn_flat.detach().cpu().clone(), opt.step_count))
+    return res
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 520, 100, 1000), (3, 257, 1000, 64, 700), (2, 1100, 2600, 100, 4000)])
+def test_row_indexed_step_is_bit_identical_to_gather_then_step(shape):
+    A, B, D, H, n_rows = shape
+    a, b = _rows_case(A, B, D, H, n_rows, 31)
+    assert a[4] == b[4] == 2
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u.view(torch.int32), v.view(torch.int32))
+    assert bool(torch.isfinite(a[0]).all())
+
+
+def test_row_indexed_step_is_refused_where_it_is_not_built():
+    from oracle import restatement as R
+    from tests import gpu_util as U
+    h = R.Hyper(input_dim=256, fc_dim=32, n_categories=12, state_dim=2, lowD_dim=6, n_arm=2)
+    m = U.build_model(h, R.init_state_dict(h, 1))
+    m.train()
+    m.gemm_dtype = "fp32_mfma"
+    data = R.synthetic_batch(500, 256, seed=2).to(U.DEV)
+    rows = torch.arange(96, device=U.DEV)
+    off0 = m._noise_offset
+    with pytest.raises(NotImplementedError):
+        m.fused_train_step_rows(data, rows, 1.0, None, do_adam=False)
+    assert m._noise_offset == off0                                  # the refused call consumed no noise
+    m.fused_train_step(data[rows].expand(2, -1, -1), 1.0, None, do_adam=False)   # the gathered batch runs
+
+
+def test_shuffled_epoch_through_row_indices_equals_gathered_batches(monkeypatch):
+    """The trainer's epoch on a DeviceLoader: row-indexed steps (default) against gathered batches (MMVAE_ROWS=0) -- the same
+    permutation, the same Philox noise offsets, bit-identical parameters and epoch history."""
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    from distributed_vae_amd.utils.dataloader import DeviceLoader
+    from oracle import restatement as R
+    from tests import gpu_util as U
+    data = R.synthetic_batch(1300, 520, seed=9).to(U.DEV)
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MMVAE_ROWS", mode)
+        torch.manual_seed(77)
+        t = cpl_mixVAE(saving_folder="", device=U.DEV, save_flag=False)
+        t.init_model(n_categories=12, state_dim=2, input_dim=520, fc_dim=100, lowD_dim=6, x_drop=0.5, s_drop=0.0, n_arm=2)
+        ld = DeviceLoader(data, torch.arange(1300), 256, True, True, seed=5)
+        hist = t.train(ld, None, n_epoch=2, good_enuf_consensus=2.0)
+        torch.cuda.synchronize()
+        out.append((t.model.flat_parameters().detach().cpu().clone(), hist["losses"], getattr(t, "_rows_ok", True)))
+    assert out[0][2] is True                                         # the row-indexed path was taken, not refused
+    assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
