@@ -635,9 +635,10 @@ int mmvae_train_step_rows(const mmvae_dims* d, const mmvae_hyper* h, const mmvae
         set_error("train_step_rows: needs ld %% 4 == 0, 16-byte aligned data and n_rows * ld < 2^30 floats");
         return MMVAE_E_UNSUPPORTED;
     }
-    if (!h->training || !(h->x_drop > 0.f) || !split3_gemms(c) || !prologue_merged(c) || !fast_path_ok(c, params, data, 0) ||
-        d->H + 1 > 112 || (int64_t)cdiv(d->B, 128) * c.lay.sp.ks_gd10 > c.lay.n11 || c.tune(MMVAE_TUNE_FC11_ZG_OFF)) {
-        set_error("train_step_rows: only the fp32x3 engine's fused training step reads the batch through a row map");
+    const bool x3 = split3_gemms(c) && d->H + 1 <= 112, b16 = (h->gemm_bf16 & 0xFF) == 1 && bf16_gemms(c);
+    if (!h->training || !(h->x_drop > 0.f) || !(x3 || b16) || !prologue_merged(c) || !fast_path_ok(c, params, data, 0) ||
+        (int64_t)cdiv(d->B, 128) * c.lay.sp.ks_gd10 > c.lay.n11 || c.tune(MMVAE_TUNE_FC11_ZG_OFF) || ((h->gemm_bf16 >> 8) & 15)) {
+        set_error("train_step_rows: only the fused training step of the fp32x3 / bf16 engines reads the batch through a row map");
         return MMVAE_E_UNSUPPORTED;
     }
     c.x_rows = rows;

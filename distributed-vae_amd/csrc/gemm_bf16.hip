@@ -544,7 +544,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // C tile -> slab.  grid (tiles_m * tiles_n, KS, A): block (m tile, n tile) x k range ks x arm.  Tile t + 1 is written to
 // the second LDS buffer while tile t is multiplied (one barrier per K tile); a piece's registers request tile t + 2 as
 // soon as they have been written out for tile t + 1.
-template <bool AMINOR, bool BMINOR, int EPI = 0>
+template <bool AMINOR, bool BMINOR, int EPI = 0, int IDX = 0>   // IDX: 1 / 2 = the A / B operand through its row map (see k_x3_gemm)
 __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const GemmArgs g = g_in;
     __shared__ __attribute__((aligned(16))) unsigned As[2][BT * LDB];   // two K tiles in LDS: tile t is multiplied while tile
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegsT<true> ta, tb;
+    unsigned ro[Eng<1>::NQ] = {};
     // Software pipeline at the granularity of one 16-byte piece: a piece of tile t + 1 is rounded and written to LDS
     // and the SAME registers immediately request the piece of tile t + 2, so sixteen loads per thread are in flight
     // all the time and every load has a whole iteration (the other fifteen pieces, the MFMAs, the barrier) to land.
@@ -577,14 +578,28 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
         for (int q = 0; q < 8; ++q) {
             // (no run-time condition around a load: hipcc then waits for every load separately)
             quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
-            if constexpr (LOAD) quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
+            if constexpr (LOAD) {
+                if constexpr (IDX == 1) quad_load_idx<AMINOR, 1, KT>(ta, oa, m0, kld, ke, q, ro);
+                else quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
+            }
             quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
-            if constexpr (LOAD) quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
+            if constexpr (LOAD) {
+                if constexpr (IDX == 2) quad_load_idx<BMINOR, 1, KT>(tb, ob, n0, kld, ke, q, ro);
+                else quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
+            }
         }
     };
     if (kb < ke) {
-        tile_load<AMINOR>(ta, oa, m0, kb, ke);
-        tile_load<BMINOR>(tb, ob, n0, kb, ke);
+        if constexpr (IDX == 1) {
+            ro_init<AMINOR, 1>(ro, oa, m0, kb);
+#pragma unroll
+            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<AMINOR, 1, KT>(ta, oa, m0, kb, ke, q, ro);
+        } else tile_load<AMINOR>(ta, oa, m0, kb, ke);
+        if constexpr (IDX == 2) {
+            ro_init<BMINOR, 1>(ro, ob, n0, kb);
+#pragma unroll
+            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<BMINOR, 1, KT>(tb, ob, n0, kb, ke, q, ro);
+        } else tile_load<BMINOR>(tb, ob, n0, kb, ke);
     }
     if (kb < ke) {
         if (kb + KT < ke) stage(As[0], Bs[0], kb, kb + KT, VecTag{});
@@ -960,7 +975,7 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
     float se = 0.f;
     int mism = 0;
     const int cell = c0 + 32 * wv + l31;
-    const int64_t rowoff = (int64_t)min(cell, B - 1) * D;
+    const int64_t rowoff = g.fo.xmap ? (int64_t)g.fo.xmap[min(cell, B - 1)] : (int64_t)min(cell, B - 1) * D;   // (row map: the batch is rows of the resident matrix)
     const unsigned short* Wk16[2] = {reinterpret_cast<const unsigned short*>(Ws[0]), reinterpret_cast<const unsigned short*>(Ws[1])};
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
@@ -1620,10 +1635,13 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
     g.so = SlabOut{c.ws + c.lay.fc1_slab, (int64_t)d.A * d.B * NP, (int64_t)d.B * NP, NP, d.B, d.H};
     g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
     if (c.x_rows) {   // the batch as rows of the resident matrix (mmvae_train_step_rows): x is read through the row map
-        if (!split3_gemms(c) || !c.rowmap_ready) { set_error("row-indexed batches need the fp32x3 engine's fused step"); return MMVAE_E_UNSUPPORTED; }
+        if (!c.rowmap_ready) { set_error("row-indexed batches need the fused step's head launch"); return MMVAE_E_UNSUPPORTED; }
         g.a.rowmap = reinterpret_cast<const unsigned*>(c.ws + c.lay.rowmap); g.a.nrec = c.x_nrows * c.x_ld; g.a.map_n = d.B;
-        use_planes(c, g.b, PL_W1);
-        hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true, 1>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+        if (split3_gemms(c)) {
+            use_planes(c, g.b, PL_W1);
+            hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true, 1>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+        } else
+            hipLaunchKernelGGL((k_bf16_gemm<false, false, 0, 1>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
     } else if (split3_gemms(c)) {   // (fc_dim <= 124: one tile wide, the two tiles of a block share the W1 tile)
         use_planes(c, g.b, PL_W1);
         hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
@@ -1678,7 +1696,11 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.M = d.B; g.N = d.D; g.K = d.H; g.KS = NS; g.A = d.A; g.n11 = L.n11;
         g.fo = Fc11Out{params + c.po.o[27], x, c.ws + L.DZ11, x_rec, c.ws + L.fc11_part,
                        (float)(d.A > 1 ? d.A - 1 : 1) / (float)d.B, d.B, d.D, nullptr, 0};
-        if (c.x_rows) { set_error("row-indexed batches need the fp32x3 engine's fused step"); return MMVAE_E_UNSUPPORTED; }
+        if (c.x_rows) {
+            if (!fused || !c.rowmap_ready) { set_error("row-indexed batches need the fused fc11 kernel of a training step"); return MMVAE_E_UNSUPPORTED; }
+            g.fo.xmap = reinterpret_cast<const unsigned*>(c.ws + L.rowmap);
+            g.fo.x_nrec = c.x_nrows * c.x_ld;
+        }
         g.fo_arm = (int64_t)d.B * d.D;
         g.fo_x_arm = xs;
         if (fused) {   // train step: d(d10) comes out of the same launch (which & 2 is then a no-op)
@@ -1723,10 +1745,13 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
         g.so = SlabOut{c.ws + L.dw1_slab, (int64_t)d.A * d.H * d.D, (int64_t)d.H * d.D, d.D, d.H, d.D};
         if (c.x_rows) {
-            if (!split3_gemms(c) || !c.rowmap_ready) { set_error("row-indexed batches need the fp32x3 engine's fused step"); return MMVAE_E_UNSUPPORTED; }
+            if (!c.rowmap_ready) { set_error("row-indexed batches need the fused step's head launch"); return MMVAE_E_UNSUPPORTED; }
             g.b.rowmap = reinterpret_cast<const unsigned*>(c.ws + L.rowmap); g.b.nrec = c.x_nrows * c.x_ld; g.b.map_n = d.B;
-            use_planes(c, g.a, PL_DZ1);
-            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true, 2>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+            if (split3_gemms(c)) {
+                use_planes(c, g.a, PL_DZ1);
+                hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true, 2>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+            } else
+                hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 2>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         } else if (split3_gemms(c)) {   // one tile high: the two tiles of a block share the dZ1 tile
             use_planes(c, g.a, PL_DZ1);
             hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);

@@ -278,8 +278,8 @@ int mmvae_train_step(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
  * (mmidas/utils/dataloader.py:114-132: shuffled index batches collated into a fresh tensor, pinned, copied to the device) AND
  * the per-step row gather of mmvae_gather_rows: fc1, the fused fc11 kernel and dW1 read x through a row map (B 32-bit
  * offsets the step's head launch derives from `rows`), so a shuffled batch costs what a resident one does.  Bit-identical to
- * mmvae_gather_rows + mmvae_train_step.  Offered where it is built -- the fp32x3 engine's fused training step (gemm_bf16 & 0xFF
- * == 2, fc_dim <= 111, x_drop > 0), ld % 4 == 0, 16-byte aligned data, n_rows * ld < 2^30 floats --; otherwise
+ * mmvae_gather_rows + mmvae_train_step.  Offered where it is built -- the fused training step of the fp32x3 and bf16 engines
+ * (gemm_bf16 & 0xFF == 2 with fc_dim <= 111, or == 1; x_drop > 0), ld % 4 == 0, 16-byte aligned data, n_rows * ld < 2^30 floats --; otherwise
  * MMVAE_E_UNSUPPORTED: gather the batch and call mmvae_train_step. */
 int mmvae_train_step_rows(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz, float *params,
                           float *bn_running, int64_t *num_batches_tracked, const float *data, int64_t ld,

@@ -107,7 +107,7 @@ def test_trainer_epoch_from_device_loaders():
 # ---------------------------------------------------------------------------------------------------
 # The batch as rows of the resident matrix (mmvae_train_step_rows): never materialised, bit-identical to gather + step
 # ---------------------------------------------------------------------------------------------------
-def _rows_case(A, B, D, H, n_rows, seed):
+def _rows_case(A, B, D, H, n_rows, seed, dtype="fp32"):
     from oracle import restatement as R
     from tests import gpu_util as U
     from distributed_vae_amd.cpl_mixvae import FusedAdam
@@ -121,6 +121,7 @@ def _rows_case(A, B, D, H, n_rows, seed):
     for indexed in (False, True):
         m = U.build_model(h, sd)
         m.train()
+        m.gemm_dtype = dtype
         opt = FusedAdam(m, lr=1e-3)
         bufs = []
         for s in range(2):
@@ -145,6 +146,12 @@ def test_row_indexed_step_is_bit_identical_to_gather_then_step(shape):
     for u, v in zip(a[:4], b[:4]):
         assert torch.equal(u.view(torch.int32), v.view(torch.int32))
     assert bool(torch.isfinite(a[0]).all())
+
+
+def test_row_indexed_step_on_the_bf16_engine():
+    a, b = _rows_case(2, 300, 520, 100, 1000, 33, dtype="bf16")
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u.view(torch.int32), v.view(torch.int32))
 
 
 def test_row_indexed_step_is_refused_where_it_is_not_built():
