@@ -510,25 +510,37 @@ def data_path(data, A, B, D):
     res = {"kernel": "k_gather_rows", "us_per_batch": ms * 1e3, "algorithmic_GBs": by / ms / 1e6,
            "frac_of_hbm_peak": by / ms / 1e6 / PEAK_HBM_GBS, "bytes_per_batch": by,
            "note": "a host-resident batch would cost B*D*4 bytes over PCIe (~1.6 ms at 63 GB/s) per step instead"}
-    # a shuffled epoch from the device-resident loader through the trainer: the gather of batch i+1 on the side stream
-    # beside step i (pipelined) against gather-then-step
+    # a shuffled epoch from the device-resident loader through the trainer: row-indexed steps (mmvae_train_step_rows: the
+    # batch is never assembled; the default), and for comparison gathered batches (MMVAE_ROWS=0): the gather of batch i+1 on
+    # a side stream beside step i, and gather-then-step
     from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
     from distributed_vae_amd.utils.dataloader import DeviceLoader
     tr = cpl_mixVAE(saving_folder="", device=data.device, save_flag=False)
     tr.init_model(n_categories=92, state_dim=2, input_dim=D, fc_dim=100, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A)
     ld = DeviceLoader(data, torch.arange(data.shape[0]), B, True, True, seed=546)
-    for pipe in (False, True):
-        tr.pipeline = pipe
-        for _ in tr.epoch_steps(ld):
-            pass
-        e0.record()
-        n = 0
-        for _ in range(3):
-            for _b in tr.epoch_steps(ld):
-                n += 1
-        e1.record()
-        e1.synchronize()
-        res["shuffled_epoch_ms_per_step_pipelined" if pipe else "shuffled_epoch_ms_per_step_back_to_back"] = e0.elapsed_time(e1) / n
+    prev = os.environ.get("MMVAE_ROWS")
+    try:
+        for key, rows, pipe in (("shuffled_epoch_ms_per_step", "1", True),
+                                ("shuffled_epoch_ms_per_step_gathered_pipelined", "0", True),
+                                ("shuffled_epoch_ms_per_step_gathered_back_to_back", "0", False)):
+            os.environ["MMVAE_ROWS"] = rows
+            tr.pipeline = pipe
+            for _ in tr.epoch_steps(ld):
+                pass
+            e0.record()
+            n = 0
+            for _ in range(3):
+                for _b in tr.epoch_steps(ld):
+                    n += 1
+            e1.record()
+            e1.synchronize()
+            res[key] = e0.elapsed_time(e1) / n
+        res["row_indexed_steps"] = bool(getattr(tr, "_rows_ok", True))
+    finally:
+        if prev is None:
+            os.environ.pop("MMVAE_ROWS", None)
+        else:
+            os.environ["MMVAE_ROWS"] = prev
     return res
 
 

@@ -14,7 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MMVAE_LIB") or os.path.join(HERE, "libmmvae_hip.so")   # env override: A/B timing of builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 N_PARAM_TENSORS = 28
 N_BN = 6
 MAX_ARMS = 8
@@ -73,7 +73,7 @@ class AugTensors(C.Structure):
 
 N_EVENTS = 8
 N_TUNE = 24
-# mmvae_exec.tune indices (private: csrc/tune.h; public: MMVAE_TUNE_ENGINE / MMVAE_TUNE_MID_EVENT in include/mmvae.h) and the
+# mmvae_exec.tune indices (private: csrc/tune.h; public: MMVAE_TUNE_ENGINE in include/mmvae.h) and the
 # environment switch that sets each one: the LIBRARY reads
 # no environment variables, this module translates them (experiments and A/B timing only; none is needed in production)
 TUNE_ENV = {
@@ -85,18 +85,13 @@ TUNE_ENV = {
     "MMVAE_REDUCE11_MAIN": (22, int), "MMVAE_FUSED_CHAIN": (23, int),
 }
 TUNE_ENGINE = 17    # MMVAE_TUNE_ENGINE: the GEMM engine the caller runs (the layout's split factors are chosen for it)
-TUNE_MID_EVENT = 18  # MMVAE_TUNE_MID_EVENT: record ev[7] behind fc1 (see Engine.mid_event)
-
-
-AT_MID_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)    # mmvae_exec.at_mid(user, stream)
 
 
 class Exec(C.Structure):
     """mmvae_exec: the caller-owned execution context of one engine (side stream, fork / join events, split factors,
     experiment switches)."""
     _fields_ = [("side_stream", C.c_void_p), ("ev", C.c_void_p * N_EVENTS), ("early_grad_event", C.c_void_p),
-                ("early_recorded", C.c_int32), ("split", C.c_int32 * 6), ("tune", C.c_int32 * N_TUNE),
-                ("at_mid", AT_MID_FN), ("at_mid_user", C.c_void_p)]
+                ("early_recorded", C.c_int32), ("split", C.c_int32 * 6), ("tune", C.c_int32 * N_TUNE)]
 
 
 def exec_from_env(engine: int = 0) -> Exec:
@@ -172,8 +167,6 @@ def lib():
     L.mmvae_aug_pack.argtypes = [C.POINTER(AugDims), C.POINTER(AugTensors), vp, vp]
     L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, i32, ex, vp]
     L.mmvae_gather_rows.argtypes = [vp, i64, i64, vp, i64, i32, vp, vp]
-    L.mmvae_gather_rows_ex.argtypes = [vp, i64, i64, vp, i64, i32, vp, i32, vp]
-    L.mmvae_gather_rows_ex.restype = C.c_int
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_splits", "mmvae_forward", "mmvae_loss",
                "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",
                "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus", "mmvae_aug_pack",
@@ -292,43 +285,6 @@ class Engine:
 
     def _s(self):
         return _stream(self.device)
-
-    def mid_event(self, on: bool = True):
-        """The event the step records behind its first layer (fc1 + epilogue) once switched on: where it leaves its first
-        throughput-bound kernel and enters the latency-bound encoder chain.  A producer of the next batch on another
-        stream waits for it (``stream.wait_event``) so that its copy runs beside the chain.  None without a side stream."""
-        if self.side is None:
-            return None
-        self.ex.tune[TUNE_MID_EVENT] = 1 if on else 0
-        return self._events[7] if on else None
-
-    def at_mid(self, fn=None):
-        """Install (or, with None, remove) the producer of the next batch: ``fn(stream)`` is called on the host from inside
-        the next train_step call (no other call invokes it), right behind its first layer, with ``stream`` a ``torch.cuda.ExternalStream``
-        of the engine's side stream forked from that point; what it enqueues there (row gather, H2D copy) runs beside the
-        latency-bound encoder chain and is complete when the step is.  An exception raised by ``fn`` is re-raised by
-        ``raise_at_mid_error()`` (ctypes cannot propagate it through the C call).  No-op without a side stream."""
-        self._at_mid_err = None
-        if fn is None or self.side is None:
-            self._at_mid_cb = None
-            self.ex.at_mid = AT_MID_FN()
-            return False
-        ext = torch.cuda.ExternalStream(self.side.cuda_stream, device=self.device)
-
-        def _cb(_user, _stream):
-            try:
-                fn(ext)
-            except BaseException as e:      # noqa: BLE001 -- handed to the caller after the C call returns
-                self._at_mid_err = e
-
-        self._at_mid_cb = AT_MID_FN(_cb)    # keep the thunk alive as long as the library may call it
-        self.ex.at_mid = self._at_mid_cb
-        return True
-
-    def raise_at_mid_error(self):
-        e, self._at_mid_err = getattr(self, "_at_mid_err", None), None
-        if e is not None:
-            raise e
 
     def _x(self):
         return C.byref(self.ex)
@@ -469,10 +425,8 @@ def consensus(counts: torch.Tensor, want_norm: bool = False):
     return (out, norm) if want_norm else out
 
 
-def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None,
-                max_workgroups: int = 0) -> torch.Tensor:
-    """out[i] = data[idx[i]] for a 2-D float32 CUDA matrix (rows may be strided) and int64 CUDA indices;
-    ``max_workgroups`` > 0 caps the copy's grid (a copy running beside a train step: see mmvae_gather_rows_ex)."""
+def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = data[idx[i]] for a 2-D float32 CUDA matrix (rows may be strided) and int64 CUDA indices."""
     if data.device.type != "cuda" or idx.device.type != "cuda":
         raise NativeError("gather_rows needs CUDA tensors (no CPU fallback)")
     assert data.dim() == 2 and data.dtype == torch.float32 and data.stride(1) == 1
@@ -481,9 +435,8 @@ def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tenso
     if out is None:
         out = torch.empty(n, Dm, dtype=torch.float32, device=data.device)
     if n:
-        check(lib().mmvae_gather_rows_ex(_ptr(data), data.stride(0), data.shape[0], _ptr(idx), n, Dm, _ptr(out),
-                                         int(max_workgroups), _stream(data.device)),
-              "mmvae_gather_rows")
+        check(lib().mmvae_gather_rows(_ptr(data), data.stride(0), data.shape[0], _ptr(idx), n, Dm, _ptr(out),
+                                      _stream(data.device)), "mmvae_gather_rows")
     return out
 
 

@@ -257,28 +257,38 @@ class cpl_mixVAE:
             for b in loader:
                 yield self.train_step(first(b))
             return
+        # ring buffers (loader batches, augmenter outputs) are reused every few batches: batch k may only be produced once
+        # the step that read its slot last (step k - lag) is over; a one-slot ring cannot be pipelined at all
+        aug_ring = 3
+        lring = int(getattr(loader, "ring", 0))
+        lag = min(lring if lring > 0 else aug_ring, aug_ring)
+        if lag < 2:
+            for b in loader:
+                yield self.train_step(first(b))
+            return
         main = torch.cuda.current_stream(self.device)
         side = N.shared_stream(self.device, "produce")
         it = iter(loader)
-        ring = 3                                                # augmenter outputs in flight: produced, consumed, next
         aug_out = {}
+        done = {}                                               # step index -> main-stream event at its end
         count = [0]
 
-        def produce(record=True):
+        def produce():
+            k = count[0]
+            if k - lag in done:
+                side.wait_event(done.pop(k - lag))
             b = next(it, None)
             if b is None:
                 return None
             x = first(b).to(self.device, non_blocking=True)
             xs = x.expand(A, -1, -1)
             if self.netA is not None:
-                key = (count[0] % ring, x.shape[0])
+                key = (k % aug_ring, x.shape[0])
                 if key not in aug_out:                          # persistent outputs: no allocator traffic per batch
                     aug_out[key] = (torch.empty(A, x.shape[0], self.netA._dims[4], device=self.device),
                                     torch.empty(A, x.shape[0], x.shape[1], device=self.device))
                 xs = self.netA(xs, True, 0.1, out=aug_out[key])[1]   # cpl_mixvae.py:422-423
             count[0] += 1
-            if not record:                                      # enqueued from inside the step's call (at_mid): the step's own join covers it
-                return xs, x, None
             ev = torch.cuda.Event()
             ev.record(side)
             return xs, x, ev
@@ -286,70 +296,30 @@ class cpl_mixVAE:
         side.wait_stream(main)                                  # parameters / loader state written on the main stream
         with torch.cuda.stream(side):
             cur = produce()
-        done = []                                               # main-stream events, one per finished step
-        # Without an augmenter the production of a batch is a copy (row gather / H2D): it is issued BEHIND the step it runs
-        # beside and waits for that step's mid event -- recorded where the step leaves fc1 and enters the latency-bound
-        # encoder chain -- so that it streams through HBM while the chip is mostly idle, not beside fc1 (measured at the
-        # benchmark shape: 0.80 ms per shuffled step with the copy issued in front of the step).  With an augmenter the
-        # production is a 1.7 ms chain of GEMMs: it starts in front of the step, as before.
-        # Issued from here behind the step's C call, though, the copy reaches the device ~300 us into the step and lands
-        # beside the fc11 kernel (tools/epoch_timeline.py: 98 us instead of 36, fc11 151 -> 182 us).  So the engine calls
-        # the producer itself, from inside the step's call, right behind fc1 (mmvae_exec.at_mid): the copy is enqueued on the
-        # engine's own side stream at that point and is complete when the step is -- no event of its own.
+        # Without an augmenter the production of a batch is a copy (row gather of a loader the row-indexed step above does
+        # not cover, or the H2D copy of a host batch): it is issued BEHIND the step's call, so that it reaches the device
+        # some 300 us into the step instead of beside fc1 (measured at the benchmark shape: 0.75 against 0.80 ms per
+        # shuffled step).  With an augmenter the production is a 1.7 ms chain of GEMMs: it starts in front of the step.
         late = self.netA is None and not D.is_dist()
-        held = {}
-
-        def at_mid(stream):
-            with torch.cuda.stream(stream):
-                held["nxt"] = produce(record=False)
-
-        hooked = []
-        # batch n + 1 is gathered from inside step n, which still reads batch n afterwards (fc11 + loss, dW1): the loader's
-        # ring needs a second slot (ring = 0: a fresh tensor per batch), else the producer stays behind the step
-        ring_ok = getattr(loader, "ring", 0) == 0 or getattr(loader, "ring", 0) >= 2
-        use_hook = late and ring_ok and os.environ.get("MMVAE_AT_MID", "1") != "0"
-        thin = use_hook and hasattr(loader, "gather_workgroups")
-        prev_wg = getattr(loader, "gather_workgroups", 0)
-        if thin:
-            loader.gather_workgroups = int(os.environ.get("MMVAE_GATHER_WG", "512"))   # beside the step: thinner and 10 us longer, 7 us cheaper per step
-        try:
-            while cur is not None:
-                # ring buffers (loader batches, augmenter outputs) are reused every few batches: the side stream may only
-                # overwrite a slot once the step that read it is over (two steps back is enough for rings of >= 3)
-                if len(done) >= 2:
-                    side.wait_event(done[-2])
-                if not late:
-                    with torch.cuda.stream(side):
-                        nxt = produce()
-                xs, x, ev = cur
-                if ev is not None:
-                    main.wait_event(ev)
-                eng = self.model._ensure(xs.shape[1]) if use_hook else None
-                in_call = eng is not None and eng.at_mid(at_mid)
-                if in_call and eng not in hooked:
-                    hooked.append(eng)
-                held.pop("nxt", None)
-                buf = self._step(xs)
-                if in_call:
-                    eng.raise_at_mid_error()
-                if late and "nxt" in held:
-                    nxt = held.pop("nxt")
-                elif late:                                      # no side stream / the step did not reach the hook
-                    with torch.cuda.stream(side):
-                        nxt = produce()
-                x.record_stream(main)                           # produced on the side stream, read on the main one
-                fin = torch.cuda.Event()
-                fin.record(main)
-                done.append(fin)
-                if len(done) > 4:
-                    done.pop(0)
-                yield buf
-                cur = nxt
-        finally:
-            for eng in hooked:
-                eng.at_mid(None)
-            if thin:
-                loader.gather_workgroups = prev_wg
+        k = 0
+        while cur is not None:
+            if not late:
+                with torch.cuda.stream(side):
+                    nxt = produce()
+            xs, x, ev = cur
+            main.wait_event(ev)
+            buf = self._step(xs)
+            if late:
+                with torch.cuda.stream(side):
+                    nxt = produce()
+            x.record_stream(main)                               # produced on the side stream, read on the main one
+            fin = torch.cuda.Event()
+            fin.record(main)
+            done[k] = fin
+            done.pop(k - 2 * lag, None)
+            k += 1
+            yield buf
+            cur = nxt
 
     def train(self, train_loader, test_loader, n_epoch, n_epoch_p=0, c_p=0, c_onehot=0, min_con=0.5,
               max_prun_it=0, rank=None, run=None, ws=1, good_enuf_consensus=0.75):

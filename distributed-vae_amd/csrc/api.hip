@@ -201,7 +201,7 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
         L.pl_d10 = take(A * 3 * Br * 128 / 2);
         L.pl_small = take(A * (int64_t)PL_SMALL_SLOTS * 3 * 128 * 128 / 2);
     }
-    L.rowmap = take(B);
+    L.rowmap = take(B + MAP_PAD);
     L.loss_scratch = take(4096);
     L.total = off;
     return L;
@@ -321,14 +321,6 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         if ((rc = launch_x3_planes(c, params, merged ? 17 : 1, nz))) return rc;   // fp32x3: slice planes of W1, [W11 | b11], the small layers
         if ((rc = launch_fc1_fwd_fast(c, params, x, xs))) return rc;
         if ((rc = launch_fc1_epi(c, params))) return rc;
-        if (c.ex.at_mid && c.side() && couple_done) {   // only mmvae_train_step joins the side stream before it returns
-            // the caller's producer of the next batch: on the side stream from here, ahead of the coupling fork's work
-            if ((rc = fork_to_side(c, EV_SPARE))) return rc;
-            c.ex.at_mid(c.ex.at_mid_user, c.ex.side_stream);
-        } else if (c.tune(MMVAE_TUNE_MID_EVENT) && c.side() && hipEventRecord(c.ev(EV_SPARE), c.stream) != hipSuccess) {
-            set_error("event record failed");
-            return MMVAE_E_LAUNCH;
-        }
     } else if ((rc = launch_fc1_fwd(c, nz, params, x, xs))) {
         return rc;
     }
@@ -468,7 +460,7 @@ using namespace mmvae;
 
 extern "C" {
 
-int mmvae_abi_version(void) { return 3; }
+int mmvae_abi_version(void) { return 4; }
 const char* mmvae_last_error_string(void) { return g_err; }
 int mmvae_check_dims(const mmvae_dims* d) { return check_dims(d); }
 

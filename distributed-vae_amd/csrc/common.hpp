@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int WAVE = 64;
 constexpr int ROWS32 = 32;   // row block of the small-layer / row-wise kernels
 constexpr int NP = 128;      // padded width of every narrow (<=128) dimension in MFMA tiles
+constexpr int MAP_PAD = 256;  // valid entries behind the row map's last one (scalar requests run up to two K tiles of 64 ahead)
 constexpr int DW11_LD = 132;  // row stride of the dW11 slab: H weights + 1 bias column, H <= 128
 constexpr int SMALL_LD = 256; // row stride of a small-layer dW slab: [N<=128][K+1<=256]
 
@@ -87,7 +88,7 @@ struct Layout {
     // zeroes), sync_bwd directly behind acc (inside the range the first kernel of a backward pass zeroes).
     int64_t sync_fwd, sync_bwd;
     int sync_arm_words;
-    int64_t rowmap;                // uint32 [B]: element offsets of the batch's rows in the resident matrix (mmvae_train_step_rows)
+    int64_t rowmap;                // uint32 [B + MAP_PAD]: element offsets of the batch's rows in the resident matrix (mmvae_train_step_rows)
     int64_t loss_scratch;          // small
     int64_t total;
 };
@@ -747,7 +748,7 @@ struct Ctx {
     mutable bool rowmap_ready = false;
 };
 // events of mmvae_exec.ev by role
-enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE /* MMVAE_TUNE_MID_EVENT: behind fc1 */ };
+enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE /* unused */ };
 
 #ifdef __HIPCC__
 NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h);

@@ -57,19 +57,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ d
 
 using namespace mmvae;
 
-extern "C" int mmvae_gather_rows_ex(const float* data, int64_t ld, int64_t n_rows, const int64_t* idx, int64_t n, int32_t D,
-                                    float* out, int32_t max_workgroups, void* stream) {
-    if (!data || !idx || !out || n <= 0 || D <= 0 || n_rows <= 0 || ld < D || max_workgroups < 0) { set_error("gather_rows: bad argument"); return MMVAE_E_BADARG; }
+extern "C" int mmvae_gather_rows(const float* data, int64_t ld, int64_t n_rows, const int64_t* idx, int64_t n, int32_t D,
+                                 float* out, void* stream) {
+    if (!data || !idx || !out || n <= 0 || D <= 0 || n_rows <= 0 || ld < D) { set_error("gather_rows: bad argument"); return MMVAE_E_BADARG; }
     const bool vec = (D % 4 == 0) && (ld % 4 == 0) && ((uintptr_t)data % 16 == 0) && ((uintptr_t)out % 16 == 0);
-    const int blocks = (int)imin64(cdiv64(n, 4), max_workgroups > 0 ? max_workgroups : 4096);
+    const int blocks = (int)imin64(cdiv64(n, 4), 4096);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (vec) hipLaunchKernelGGL((k_gather_rows<true>), dim3(blocks), dim3(256), 0, s, data, ld, n_rows, idx, n, D, out);
     else hipLaunchKernelGGL((k_gather_rows<false>), dim3(blocks), dim3(256), 0, s, data, ld, n_rows, idx, n, D, out);
     HIP_LAUNCH_CHECK("k_gather_rows");
     return 0;
-}
-
-extern "C" int mmvae_gather_rows(const float* data, int64_t ld, int64_t n_rows, const int64_t* idx, int64_t n, int32_t D,
-                                 float* out, void* stream) {
-    return mmvae_gather_rows_ex(data, ld, n_rows, idx, n, D, out, 0, stream);
 }

@@ -128,6 +128,7 @@ struct TileRegsT {
 struct OperandDev {
     __amdgpu_buffer_rsrc_t rs, rb;   // matrix, mask words
     __amdgpu_buffer_rsrc_t rm;       // row map (row indirection; see Operand::rowmap)
+    const unsigned* mp;              // the same map as a pointer: K-minor operands read it with scalar loads (map_request)
     int ld, rows, K, wpr, ones_row;
     bool bits;
     float4 bn_sub, bn_mul;           // BN = true (k_x3_small): this thread's four rows read (v - bn_sub) * bn_mul
@@ -139,6 +140,7 @@ __device__ __forceinline__ OperandDev make_operand_dev(const Operand& o) {
     d.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.ptr), 0, (int)((o.rowmap ? o.nrec : n) * 4), 0x00020000);
     d.rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(o.rowmap ? o.rowmap : reinterpret_cast<const unsigned*>(o.ptr)), 0,
                                              (int)((o.rowmap ? o.map_n : 1) * 4), 0x00020000);
+    d.mp = o.rowmap;
     d.bits = o.bits != nullptr;
     const int64_t nb = (KMINOR ? (int64_t)o.K : (int64_t)o.rows) * o.wpr;
     d.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(d.bits ? o.bits : reinterpret_cast<const uint32_t*>(o.ptr)), 0,
@@ -181,12 +183,11 @@ __device__ __forceinline__ void quad_load(TileRegsT<BITS, Eng<NP>::NQ>& t, const
 }
 
 // The same request through a row map (Operand::rowmap).  ro[q]: the element offset of piece q's memory row, i.e. of the logical
-// row r0 + (tid >> 3) + 32 p (KMAJOR: the same for every K tile, requested once by ro_init) or of k (KMINOR: requested one
-// stage ahead -- the piece of tile k0 consumes ro[q] and immediately requests the entry of tile k0 + KSTEP, so the map never
-// puts a second memory round trip in front of the operand's load).
-template <bool KMINOR, int NP, int KSTEP>
+// row r0 + (tid >> 3) + 32 p (KMAJOR: the same for every K tile, requested once by ro_init) or of k (KMINOR: a new set per K
+// tile, from map_request / map_offsets below).
+template <bool KMINOR, int NP>
 __device__ __forceinline__ void quad_load_idx(TileRegsT<true, Eng<NP>::NQ>& t, const OperandDev& o, int r0, int k0, int kend, int q,
-                                              unsigned (&ro)[Eng<NP>::NQ]) {
+                                              const unsigned (&ro)[Eng<NP>::NQ]) {
     const int tid = threadIdx.x & 255;
     int p, h;
     piece_ph<KMINOR, NP>(q, p, h);
@@ -204,23 +205,64 @@ __device__ __forceinline__ void quad_load_idx(TileRegsT<true, Eng<NP>::NQ>& t, c
         const int row = r0 + (tid & 31) * 4;
         off = (int)ro[q] + (row < o.ld ? row : 0);
         woff = kc * o.wpr + (min(row, o.rows - 1) >> 5);
-        ro[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(o.rm, min(k + KSTEP, o.K - 1) * 4, 0, 0);
     }
     t.v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 4, 0, 0));
     t.wd[q] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
 }
-template <bool KMINOR, int NP>
-__device__ __forceinline__ void ro_init(unsigned (&ro)[Eng<NP>::NQ], const OperandDev& o, int r0, int kfirst) {
+// K-minor operand through its row map: piece q of a thread lies in memory row k = k0 + 2 ((tid >> 5) + 8 p) + h with p = q >> 1,
+// h = q & 1, i.e. k0 + 4 wave + 16 p + {0, 1} for the lower half of a wave and + {2, 3} for the upper one: the map entries a
+// wave needs for one K tile are KT / 16 aligned groups of four consecutive words, the same for all its lanes.  They are
+// requested with SCALAR loads (s_load_dwordx4 through the constant cache) one K tile ahead and turned into the per-lane
+// offsets ro[] with one select each -- nothing of the map goes through the vector memory pipe, which is what bounds the
+// staging phase of these kernels (as vector loads -- one dword request per piece -- the map cost dW1 14 us of 77).  The map is
+// padded with MAP_PAD valid entries behind its last one (Layout::rowmap): requests run up to two K tiles past the K range.
+typedef unsigned mapw4 __attribute__((ext_vector_type(4)));
+typedef const mapw4 __attribute__((address_space(4)))* map4_ptr;
+template <int NP>
+struct MapRegs { mapw4 s[Eng<NP>::KT / 16]; };
+template <int NP>
+__device__ __forceinline__ void map_request(MapRegs<NP>& mr, const OperandDev& o, int k0) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & 255) >> 6);
+    const unsigned* base = o.mp + __builtin_amdgcn_readfirstlane(k0) + 4 * wv;
+#pragma unroll
+    for (int p = 0; p < Eng<NP>::KT / 16; ++p) mr.s[p] = *(map4_ptr)(const void*)(base + 16 * p);
+}
+template <int NP>
+__device__ __forceinline__ void map_offsets(unsigned (&ro)[Eng<NP>::NQ], const MapRegs<NP>& mr) {
+    const bool hi = (threadIdx.x & 32) != 0;
+#pragma unroll
+    for (int q = 0; q < Eng<NP>::NQ; ++q) {
+        const int p = q >> 1, h = q & 1;
+        ro[q] = hi ? mr.s[p][2 + h] : mr.s[p][h];
+    }
+}
+template <int NP>     // K-major operand: the offsets of this thread's rows, once per block tile
+__device__ __forceinline__ void ro_init(unsigned (&ro)[Eng<NP>::NQ], const OperandDev& o, int r0) {
     const int tid = threadIdx.x & 255;
 #pragma unroll
     for (int q = 0; q < Eng<NP>::NQ; ++q) {
         int p, h;
-        piece_ph<KMINOR, NP>(q, p, h);
-        const int i = KMINOR ? min(kfirst + 2 * ((tid >> 5) + 8 * p) + h, o.K - 1) : min(r0 + (tid >> 3) + 32 * p, o.rows - 1);
-        ro[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(o.rm, i * 4, 0, 0);
+        piece_ph<false, NP>(q, p, h);
+        ro[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(o.rm, min(r0 + (tid >> 3) + 32 * p, o.rows - 1) * 4, 0, 0);
     }
 }
-
+// the indexed operand's offsets for its first K tile (and, K-minor, the request for the second one's)
+template <bool KMINOR, int NP, int KSTEP>
+__device__ __forceinline__ void idx_begin(unsigned (&ro)[Eng<NP>::NQ], MapRegs<NP>& mr, const OperandDev& o, int r0, int kfirst) {
+    if constexpr (KMINOR) {
+        map_request<NP>(mr, o, kfirst);
+        map_offsets<NP>(ro, mr);
+        map_request<NP>(mr, o, kfirst + KSTEP);
+    } else ro_init<NP>(ro, o, r0);
+}
+// ... and for the K tile at kld, at the head of the staging phase that requests it
+template <bool KMINOR, int NP, int KSTEP>
+__device__ __forceinline__ void idx_next(unsigned (&ro)[Eng<NP>::NQ], MapRegs<NP>& mr, const OperandDev& o, int kld) {
+    if constexpr (KMINOR) {
+        map_offsets<NP>(ro, mr);
+        map_request<NP>(mr, o, kld + KSTEP);
+    }
+}
 template <bool KMINOR, bool BITS = true, int NP = 1, bool BN = false>
 __device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileRegsT<BITS, Eng<NP>::NQ>& t, const OperandDev& o, int r0,
                                            int k0, int kend, int q) {
@@ -366,8 +408,8 @@ struct SplitJobs { SplitJob j[24]; int first[25]; int n; XbitsJob xb; };   // jo
 __global__ __launch_bounds__(256) void k_presplit(const SplitJobs js) {
     if (js.xb.zero_n4 > 0) grid_zero(js.xb.zero_p, js.xb.zero_n4);
     if (js.xb.rows && blockIdx.z == 0) {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < js.xb.B; i += gridDim.x * 256) {
-            const int64_t r = js.xb.rows[i];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < js.xb.B + MAP_PAD; i += gridDim.x * 256) {   // the pad reads row 0
+            const int64_t r = i < js.xb.B ? js.xb.rows[i] : 0;
             js.xb.map[i] = (unsigned)((r < 0 ? 0 : (r >= js.xb.n_rows ? js.xb.n_rows - 1 : r)) * js.xb.rows_ld);
         }
     }
@@ -568,37 +610,40 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegsT<true> ta, tb;
-    unsigned ro[Eng<1>::NQ] = {};
+    unsigned ro[Eng<1>::NQ] = {};      // IDX: element offsets of the indexed operand's memory rows (see quad_load_idx)
+    MapRegs<1> mr = {};
     // Software pipeline at the granularity of one 16-byte piece: a piece of tile t + 1 is rounded and written to LDS
     // and the SAME registers immediately request the piece of tile t + 2, so sixteen loads per thread are in flight
     // all the time and every load has a whole iteration (the other fifteen pieces, the MFMAs, the barrier) to land.
     auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
         constexpr bool LOAD = decltype(load_tag)::value;
+        if constexpr (LOAD && IDX == 1) idx_next<AMINOR, 1, KT>(ro, mr, oa, kld);
+        if constexpr (LOAD && IDX == 2) idx_next<BMINOR, 1, KT>(ro, mr, ob, kld);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             // (no run-time condition around a load: hipcc then waits for every load separately)
             quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
             if constexpr (LOAD) {
-                if constexpr (IDX == 1) quad_load_idx<AMINOR, 1, KT>(ta, oa, m0, kld, ke, q, ro);
+                if constexpr (IDX == 1) quad_load_idx<AMINOR, 1>(ta, oa, m0, kld, ke, q, ro);
                 else quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
             }
             quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
             if constexpr (LOAD) {
-                if constexpr (IDX == 2) quad_load_idx<BMINOR, 1, KT>(tb, ob, n0, kld, ke, q, ro);
+                if constexpr (IDX == 2) quad_load_idx<BMINOR, 1>(tb, ob, n0, kld, ke, q, ro);
                 else quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
             }
         }
     };
     if (kb < ke) {
         if constexpr (IDX == 1) {
-            ro_init<AMINOR, 1>(ro, oa, m0, kb);
+            idx_begin<AMINOR, 1, KT>(ro, mr, oa, m0, kb);
 #pragma unroll
-            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<AMINOR, 1, KT>(ta, oa, m0, kb, ke, q, ro);
+            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<AMINOR, 1>(ta, oa, m0, kb, ke, q, ro);
         } else tile_load<AMINOR>(ta, oa, m0, kb, ke);
         if constexpr (IDX == 2) {
-            ro_init<BMINOR, 1>(ro, ob, n0, kb);
+            idx_begin<BMINOR, 1, KT>(ro, mr, ob, n0, kb);
 #pragma unroll
-            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<BMINOR, 1, KT>(tb, ob, n0, kb, ke, q, ro);
+            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<BMINOR, 1>(tb, ob, n0, kb, ke, q, ro);
         } else tile_load<BMINOR>(tb, ob, n0, kb, ke);
     }
     if (kb < ke) {
@@ -678,6 +723,7 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegsT<true, E::NQ> ta, tb;
     unsigned ro[E::NQ] = {};           // IDX: element offsets of the indexed operand's memory rows (see quad_load_idx)
+    MapRegs<3> mr = {};
     PlaneRegs ps;
     constexpr bool APL = SPL && SHARE == 1, BPL = SPL && (SHARE == 2 || SHARE == 3);
     static_assert(IDX == 0 || SHARE != 3, "row indirection: not with the K-alternating form");
@@ -686,6 +732,8 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     // one piece of each operand in turn; a piece's registers request the next tile as soon as they have been written out
     auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
         constexpr bool LOAD = decltype(load_tag)::value;
+        if constexpr (LOAD && IDX == 1) idx_next<AMINOR, 3, KSTEP>(ro, mr, oa, kld);
+        if constexpr (LOAD && IDX == 2) idx_next<BMINOR, 3, KSTEP>(ro, mr, ob, kld);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if constexpr (APL) {
@@ -697,7 +745,7 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
                 if (do_a) {
                     quad_store<AMINOR, true, 3>(Ad, ta, oa, m0, kst, ke, i);
                     if constexpr (LOAD) {
-                        if constexpr (IDX == 1) quad_load_idx<AMINOR, 3, KTv>(ta, oa, m0, kld, ke, i, ro);
+                        if constexpr (IDX == 1) quad_load_idx<AMINOR, 3>(ta, oa, m0, kld, ke, i, ro);
                         else quad_load<AMINOR, true, 3>(ta, oa, m0, kld, ke, i);
                     }
                 }
@@ -711,7 +759,7 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
                 if (do_b) {
                     quad_store<BMINOR, true, 3>(Bd, tb, ob, n0, kst, ke, i);
                     if constexpr (LOAD) {
-                        if constexpr (IDX == 2) quad_load_idx<BMINOR, 3, KTv>(tb, ob, n0, kld, ke, i, ro);
+                        if constexpr (IDX == 2) quad_load_idx<BMINOR, 3>(tb, ob, n0, kld, ke, i, ro);
                         else quad_load<BMINOR, true, 3>(tb, ob, n0, kld, ke, i);
                     }
                 }
@@ -726,9 +774,9 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             }
         } else if (do_a) {
             if constexpr (IDX == 1) {
-                ro_init<AMINOR, 3>(ro, oa, m0, kfirst);
+                idx_begin<AMINOR, 3, KSTEP>(ro, mr, oa, m0, kfirst);
 #pragma unroll
-                for (int q = 0; q < E::NQ; ++q) quad_load_idx<AMINOR, 3, KTv>(ta, oa, m0, kfirst, ke, q, ro);
+                for (int q = 0; q < E::NQ; ++q) quad_load_idx<AMINOR, 3>(ta, oa, m0, kfirst, ke, q, ro);
             } else tile_load<AMINOR, true, 3>(ta, oa, m0, kfirst, ke);
         }
         if constexpr (BPL) {
@@ -738,9 +786,9 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             }
         } else if (do_b) {
             if constexpr (IDX == 2) {
-                ro_init<BMINOR, 3>(ro, ob, n0, kfirst);
+                idx_begin<BMINOR, 3, KSTEP>(ro, mr, ob, n0, kfirst);
 #pragma unroll
-                for (int q = 0; q < E::NQ; ++q) quad_load_idx<BMINOR, 3, KTv>(tb, ob, n0, kfirst, ke, q, ro);
+                for (int q = 0; q < E::NQ; ++q) quad_load_idx<BMINOR, 3>(tb, ob, n0, kfirst, ke, q, ro);
             } else tile_load<BMINOR, true, 3>(tb, ob, n0, kfirst, ke);
         }
     }

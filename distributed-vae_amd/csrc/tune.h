@@ -1,5 +1,5 @@
 // Private: indices of mmvae_exec.tune (include/mmvae.h) -- experiment switches for A/B timing, ablations and test hooks.
-// 0 = production behaviour for every one of them.  MMVAE_TUNE_ENGINE (17) and MMVAE_TUNE_MID_EVENT (18) are public and
+// 0 = production behaviour for every one of them.  MMVAE_TUNE_ENGINE (17) is public and
 // defined in mmvae.h.  The Python binding translates environment variables into these (_native.TUNE_ENV); the library
 // itself reads none.
 #pragma once
@@ -18,7 +18,7 @@ enum {
     MMVAE_TUNE_ABLATE_L = 14,      // latent kernels: ablations / stamps
     MMVAE_TUNE_LAT_FULLWAVE = 15,  // latent kernels: one wave per cell instead of the half-wave layout
     MMVAE_TUNE_ABLATE_B = 16,      // bf16 GEMM engine: 1 no MFMAs, 2 no global loads, 4 no LDS stores (results wrong)
-    // 17 MMVAE_TUNE_ENGINE, 18 MMVAE_TUNE_MID_EVENT: public (mmvae.h)
+    // 17 MMVAE_TUNE_ENGINE: public (mmvae.h); 18: retired (was the mid event of round 2)
     MMVAE_TUNE_BN_PARTIALS = 19,   // BatchNorm batch sums through per-workgroup partial arrays instead of the accumulators
     MMVAE_TUNE_PRESPLIT_ALL = 20,  // fp32x3 engine: all slice planes through k_presplit launches
     MMVAE_TUNE_CHAIN_FP32 = 21,    // fp32x3 engine: the chain kernels' own GEMMs stay on the fp32 matrix instruction

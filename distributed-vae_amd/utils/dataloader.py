@@ -92,11 +92,10 @@ class DeviceLoader:
         # of 70-90 ms instead of 11).  A yielded batch stays valid until `ring` - 1 more batches have been drawn --
         # training loops consume a batch at once; ring = 0 returns a new tensor per batch, as a DataLoader does.
         self.ring = int(ring)
-        # cap of the row gather's grid, 0 = none: the trainer sets 512 while the gather runs beside its train step
-        # (mmvae_gather_rows_ex: slower alone, cheaper for the step's latency-bound chain kernels)
-        self.gather_workgroups = 0
         self._bufs = None
         self._slot = 0
+        self.prefetch_order = True       # see _epoch_rows
+        self._order_stream, self._ahead = None, None
         self._pin, self._pin_ev, self._pin_k, self._copy_stream = None, None, 0, None
         self.host_order = False      # True: torch's CPU permutation (DistributedSampler's exact sequence), uploaded per epoch
 
@@ -183,22 +182,46 @@ class DeviceLoader:
         for i in range(0, n, int(rows)):
             yield N.gather_rows(self.data, self.index[i:i + int(rows)])
 
+    def _epoch_rows(self) -> torch.Tensor:
+        """Row indices (into ``self.data``) of this rank's epoch, in visiting order, and the epoch bookkeeping of one pass.
+        With the permutation drawn on the device the NEXT epoch's rows are prepared right away on a stream of their own (the
+        order is a function of seed + epoch): drawn at the head of its epoch, the permutation's five small launches sit
+        between two train steps -- 70 us per epoch at the benchmark shape, 7 us per step of a ten-step epoch."""
+        e = self._epoch()
+        dev = self.index.device
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        if self.host_order:
+            rows = self.index[self._upload(self.epoch_order())]
+        elif ahead is not None and ahead[0] == e:
+            rows = ahead[1]
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ahead[2])
+            rows.record_stream(cur)
+        else:
+            rows = self.index[self.epoch_order_device()]
+        if self._auto_epoch is not None:
+            self._auto_epoch += 1
+        if not self.host_order and self.shuffle and dev.type == "cuda" and self.prefetch_order:
+            if self._order_stream is None:
+                self._order_stream = torch.cuda.Stream(device=dev)
+            self._order_stream.wait_stream(torch.cuda.current_stream(dev))     # self.index may just have been written
+            with torch.cuda.stream(self._order_stream):
+                nxt = self.index[self._shard(self._base_order(e + 1, dev))]
+                ev = torch.cuda.Event()
+                ev.record(self._order_stream)
+            self._ahead = (e + 1, nxt, ev)
+        return rows
+
     def iter_rows(self):
         """One epoch as ROW INDICES instead of gathered batches: yields int64 device tensors ``rows`` (the batch is
         ``self.data[rows]``), same order, sharding, ``drop_last`` and epoch bookkeeping as ``__iter__``.  For consumers that
         read the resident matrix through the indices (``mixVAE_model.fused_train_step_rows``): nothing is copied."""
-        order = self._upload(self.epoch_order()) if self.host_order else self.epoch_order_device()
-        if self._auto_epoch is not None:
-            self._auto_epoch += 1
-        rows = self.index[order]
+        rows = self._epoch_rows()
         for i in range(len(self)):
             yield rows[i * self.batch_size:(i + 1) * self.batch_size]
 
     def __iter__(self):
-        order = self._upload(self.epoch_order()) if self.host_order else self.epoch_order_device()
-        if self._auto_epoch is not None:
-            self._auto_epoch += 1
-        rows = self.index[order]
+        rows = self._epoch_rows()
         nb = len(self)
         if self.ring > 0 and (self._bufs is None or self._bufs[0][0].shape[0] != self.batch_size):
             self._bufs = [(torch.empty(self.batch_size, self.data.shape[1], dtype=torch.float32, device=self.data.device),
@@ -210,11 +233,11 @@ class DeviceLoader:
                 xb, ib = self._bufs[self._slot]
                 self._slot = (self._slot + 1) % self.ring
                 xb, ib = xb[:r.numel()], ib[:r.numel()]
-                N.gather_rows(self.data, r, xb, max_workgroups=self.gather_workgroups)
+                N.gather_rows(self.data, r, xb)
                 ib.copy_(r)
                 yield xb, ib
             else:
-                yield N.gather_rows(self.data, r, max_workgroups=self.gather_workgroups), r.to(torch.float32)
+                yield N.gather_rows(self.data, r), r.to(torch.float32)
 
 
 def get_loaders(dataset, label: Sequence = [], seed=None, batch_size=128, train_size=0.9, use_dist_sampler=False,

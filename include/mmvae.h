@@ -119,19 +119,14 @@ typedef struct mmvae_noise {
  *   split        split factors of the large GEMMs, 0 = automatic: 0 fc1 split-K, 1 fc11 column splits, 2 dW1 batch
  *                splits, 3 small-layer dW batch splits, 4 d(d10) gene splits, 5 dW11 batch splits.  They change the
  *                workspace layout: pass the same context to mmvae_workspace_bytes / mmvae_ws_offset.
- *   tune         MMVAE_TUNE_ENGINE / MMVAE_TUNE_MID_EVENT below; the other entries are the implementation's experiment
+ *   tune         MMVAE_TUNE_ENGINE below; the other entries are the implementation's experiment
  *                switches (0 = production behaviour).  The library reads no environment variables. */
 #define MMVAE_N_EVENTS 8
 #define MMVAE_N_TUNE 24
-/* mmvae_exec.tune: 0 everywhere = production behaviour.  Two entries are part of the interface: */
+/* mmvae_exec.tune: 0 everywhere = production behaviour.  One entry is part of the interface: */
 #define MMVAE_TUNE_ENGINE 17    /* the GEMM engine the caller is going to run (mmvae_hyper.gemm_bf16 & 0xFF; 0 = not stated).
                                    The split factors of the workspace layout are chosen for the workgroup shapes of that
                                    engine; any engine runs correctly on any layout */
-#define MMVAE_TUNE_MID_EVENT 18 /* != 0 and a side stream given -> mmvae_forward / mmvae_train_step record ev[7] on the call's
-                                   stream behind the first layer (fc1 + its epilogue), i.e. where the step leaves its first
-                                   throughput-bound kernel and enters the latency-bound encoder chain.  A caller that produces
-                                   the NEXT batch on another stream (row gather, H2D copy) lets that stream wait for it, so
-                                   that the copy runs beside the chain instead of beside fc1 */
 /* Every other index is an experiment switch of the implementation (A/B timing, ablations, test hooks), listed in the
  * library's private header distributed-vae_amd/csrc/tune.h; callers leave them 0. */
 typedef struct mmvae_exec {
@@ -141,16 +136,6 @@ typedef struct mmvae_exec {
     int32_t early_recorded;
     int32_t split[6];
     int32_t tune[MMVAE_N_TUNE];
-    /* Optional (NULL = none; needs side_stream): called ON THE HOST by mmvae_train_step -- and only by it: it is the one
-     * call that joins the side stream before its work on the main stream ends -- while it enqueues its work, right behind
-     * the first layer (fc1 + its epilogue), with the side stream forked from that point (ev[7]).  Whatever the callee
-     * enqueues on `stream` -- the row gather or H2D copy of the NEXT batch -- runs beside the latency-bound encoder chain,
-     * ahead of the step's own side-stream work, and is complete when the call's work on its main stream is (the step
-     * joins the side stream before its gradient reduction).  mmvae_forward, mmvae_eval_classify and mmvae_backward never
-     * call it.  Issued from the caller's own code behind the call instead, such a copy reaches the device some 300 us
-     * into the step and lands beside the fc11 kernel. */
-    void (*at_mid)(void *user, void *stream);
-    void *at_mid_user;
 } mmvae_exec;
 
 /* Where things are, in floats.  Filled by mmvae_param_layout. Tensor order t = 0..27:
@@ -354,12 +339,6 @@ int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, 
  * (out-of-range indices are clamped; the host loader validates them); out: [n, D] contiguous. */
 int mmvae_gather_rows(const float *data, int64_t ld, int64_t n_rows, const int64_t *idx, int64_t n, int32_t D,
                       float *out, void *stream);
-/* The same copy with at most max_workgroups workgroups (0 = as many as the copy can use: 36 us for 5000 x 5000 at 0.70 of
- * the HBM peak).  A copy that runs BESIDE a train step (mmvae_exec.at_mid) is better off slower and thinner: at 512
- * workgroups it takes 45 us alone but costs the latency-bound encoder chain it runs beside 7 us less per step. */
-int mmvae_gather_rows_ex(const float *data, int64_t ld, int64_t n_rows, const int64_t *idx, int64_t n, int32_t D,
-                         float *out, int32_t max_workgroups, void *stream);
-
 /* ---- data-parallel gradient exchange (SURVEY.md sections 8b / 8e) ------------------------------------------------------
  * ONE RCCL all-reduce (average) of the flat fp32 gradient buffer per step, issued by the library on the stream the step
  * runs on (stream-ordered behind mmvae_train_step(do_adam = 0), in front of mmvae_adam_step; no host synchronisation, no

@@ -179,14 +179,17 @@ def test_shuffled_epoch_through_row_indices_equals_gathered_batches(monkeypatch)
     from tests import gpu_util as U
     data = R.synthetic_batch(1300, 520, seed=9).to(U.DEV)
     out = []
-    for mode in ("1", "0"):
+    # gathered batches through loader rings of 4 (default), 2 and 1 slots (the last cannot be pipelined: the trainer must
+    # notice) and fresh tensors per batch (ring 0): all the same numbers
+    for mode, ring in (("1", 4), ("0", 4), ("0", 2), ("0", 1), ("0", 0)):
         monkeypatch.setenv("MMVAE_ROWS", mode)
         torch.manual_seed(77)
         t = cpl_mixVAE(saving_folder="", device=U.DEV, save_flag=False)
         t.init_model(n_categories=12, state_dim=2, input_dim=520, fc_dim=100, lowD_dim=6, x_drop=0.5, s_drop=0.0, n_arm=2)
-        ld = DeviceLoader(data, torch.arange(1300), 256, True, True, seed=5)
+        ld = DeviceLoader(data, torch.arange(1300), 256, True, True, seed=5, ring=ring)
         hist = t.train(ld, None, n_epoch=2, good_enuf_consensus=2.0)
         torch.cuda.synchronize()
         out.append((t.model.flat_parameters().detach().cpu().clone(), hist["losses"], getattr(t, "_rows_ok", True)))
     assert out[0][2] is True                                         # the row-indexed path was taken, not refused
-    assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    for o in out[1:]:
+        assert torch.equal(out[0][0], o[0]) and out[0][1] == o[1]

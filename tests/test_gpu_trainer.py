@@ -289,88 +289,3 @@ def test_cfg5_stand_in_through_the_trainer():
     assert abs(bufs[:, 0].sum() / 4 - hist["losses"][0]) <= 1e-5 * abs(hist["losses"][0])
     for a in range(A):
         assert abs(bufs[:, 5 + a].sum() / D / 4 - hist["loss_recs"][a][0]) <= 1e-5 * abs(hist["loss_recs"][a][0])
-
-
-def test_at_mid_hook_runs_inside_the_step_and_its_work_is_complete_with_the_step():
-    """mmvae_exec.at_mid (include/mmvae.h): the producer of the next batch is called on the host from inside the step's call,
-    behind fc1, with the engine's side stream; what it enqueues there is complete when the step's main-stream work is (no
-    event of its own), the step's results do not change, an exception raised in it surfaces after the call, and removing the
-    hook stops the calls."""
-    from tests import gpu_util as U
-    from distributed_vae_amd import _native as N
-    A, B, D = 2, 1100, 2600
-    h = R.Hyper(input_dim=D, fc_dim=100, n_categories=12, state_dim=2, lowD_dim=6, n_arm=A)
-    torch.manual_seed(3)
-    m = U.build_model(h, None)
-    m.train()
-    x = R.synthetic_batch(B, D, seed=4).to(U.DEV)
-    eng = m._ensure(B)
-    hyper, noise = m._hyper(1.0, False), N.make_noise(None, 11, A)
-    bn0, nbt0 = m._bn_flat.clone(), m._nbt.clone()
-    g0 = torch.zeros_like(m._flat_grad)
-    l0 = eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, g0, False, None, None, 1, 0.0).clone()
-    src = torch.rand(4 << 20, device=U.DEV)
-    dst = torch.zeros_like(src)
-    calls = []
-
-    def producer(stream):
-        calls.append(stream.cuda_stream)
-        with torch.cuda.stream(stream):
-            dst.copy_(src * 2.0)
-
-    assert eng.at_mid(producer)
-    m._bn_flat.copy_(bn0)
-    m._nbt.copy_(nbt0)
-    g1 = torch.zeros_like(m._flat_grad)
-    l1 = eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, g1, False, None, None, 1, 0.0).clone()
-    eng.raise_at_mid_error()
-    ok = torch.equal(dst, src * 2.0)          # enqueued on the main stream behind the step: the step has joined the side stream
-    torch.cuda.synchronize()
-    assert calls == [eng.side.cuda_stream]
-    assert bool(ok)
-    assert torch.equal(l0, l1) and torch.equal(g0, g1)
-
-    def failing(stream):
-        raise RuntimeError("producer failed")
-
-    eng.at_mid(failing)
-    eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, g1, False, None, None, 1, 0.0)
-    with pytest.raises(RuntimeError, match="producer failed"):
-        eng.raise_at_mid_error()
-    eng.at_mid(None)
-    eng.train_step(hyper, noise, m._flat, m._bn_flat, m._nbt, x, 0, g1, False, None, None, 1, 0.0)
-    torch.cuda.synchronize()
-    assert len(calls) == 1
-
-
-def test_at_mid_hook_is_not_called_by_forward_or_eval_classify():
-    """Only mmvae_train_step joins the side stream before it returns, so only it may hand the side stream to the caller's
-    producer: with the hook installed, ``mmvae_forward`` (training and eval mode) and ``mmvae_eval_classify`` must not call
-    it -- a forward between two training steps would otherwise consume (and lose) a loader batch and leave a copy unordered
-    with the main stream."""
-    from tests import gpu_util as U
-    from distributed_vae_amd import _native as N
-    from distributed_vae_amd._utils import confmat_counts
-    A, B, D = 2, 300, 520
-    h = R.Hyper(input_dim=D, fc_dim=100, n_categories=12, state_dim=2, lowD_dim=6, n_arm=A)
-    torch.manual_seed(3)
-    m = U.build_model(h, None)
-    m.train()
-    x = R.synthetic_batch(B, D, seed=4).to(U.DEV)
-    xs = x.expand(A, -1, -1)
-    eng = m._ensure(B)
-    calls = []
-    assert eng.at_mid(lambda stream: calls.append(1))
-    out = m(xs, 1.0, 0.0)                                   # training-mode forward through the three-call path
-    m.loss(out[0], [], [], xs, out[7], out[8], out[4], out[6], 0.0)[0].backward()
-    m.eval()
-    with torch.no_grad():
-        m(xs, 1.0, 0.0, eval=True)
-    m.eval_labels(xs, 1.0, confmat_counts(A, h.n_categories, U.DEV))
-    torch.cuda.synchronize()
-    assert calls == []
-    m.train()
-    m.fused_train_step(xs, 1.0, None, do_adam=False)        # the train step does call it
-    torch.cuda.synchronize()
-    assert calls == [1]
-    eng.at_mid(None)

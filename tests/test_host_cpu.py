@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     L = N.lib()
     for n in names:
         assert hasattr(L, n), n
-    assert L.mmvae_abi_version() == N.ABI_VERSION == 3
+    assert L.mmvae_abi_version() == N.ABI_VERSION == 4
     # the library keeps no process-wide or per-thread knobs: no setters, and it reads no environment variables
     assert not [n for n in names if n.startswith("mmvae_set_")]
     blob = open(N.LIB_PATH, "rb").read()

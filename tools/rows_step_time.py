@@ -31,6 +31,14 @@ def timed(fn, n=60):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n
 
+mode = os.environ.get("MODE")      # one variant only (under rocprofv3 --kernel-trace --stats: per-kernel durations of that variant)
+if mode:
+    fn = {"fixed": lambda i: m.fused_train_step(batches[i % 10].expand(A, -1, -1), 1.0, opt, True),
+          "identity": lambda i: m.fused_train_step_rows(data, ident[i % 10], 1.0, opt, True),
+          "random": lambda i: m.fused_train_step_rows(data, rnd[i % 10], 1.0, opt, True),
+          "sorted": lambda i: m.fused_train_step_rows(data, rnd[i % 10].sort().values, 1.0, opt, True)}[mode]
+    print("%s %.4f ms" % (mode, timed(fn)))
+    sys.exit(0)
 print("fixed batches          %.4f ms" % timed(lambda i: m.fused_train_step(batches[i % 10].expand(A, -1, -1), 1.0, opt, True)))
 print("row map, identity      %.4f ms" % timed(lambda i: m.fused_train_step_rows(data, ident[i % 10], 1.0, opt, True)))
 print("row map, random rows   %.4f ms" % timed(lambda i: m.fused_train_step_rows(data, rnd[i % 10], 1.0, opt, True)))
