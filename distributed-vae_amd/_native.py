@@ -149,9 +149,11 @@ def lib():
     L.mmvae_adam_step.argtypes = [i64, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]
     L.mmvae_train_step.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, vp,
                                    C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, ex, vp]
-    L.mmvae_train_step_rows.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, i64, i64, vp, vp,
+    L.mmvae_train_step_rows.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, vp, i64, i64, vp, vp,
                                         C.c_size_t, vp, vp, i32, vp, vp, i64, f32, f32, f32, f32, f32, i32, ex, vp]
     L.mmvae_train_step_rows.restype = C.c_int
+    L.mmvae_to_bf16.argtypes = [vp, i64, i64, i32, vp, vp]
+    L.mmvae_to_bf16.restype = C.c_int
     L.mmvae_debug_stage.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), i32, vp, vp, i64, vp,
                                     C.c_size_t, vp, ex, vp]
     L.mmvae_dump_noise.argtypes = [C.POINTER(Dims), C.POINTER(Hyper), C.POINTER(Noise), vp, vp, vp, vp, vp]
@@ -350,12 +352,16 @@ class Engine:
         return self.loss_buf
 
     def train_step_rows(self, hyper, noise, params, bn_running, nbt, data, rows, grads, do_adam, exp_avg,
-                        exp_avg_sq, step, lr, b1=0.9, b2=0.999, adam_eps=1e-8, wd=0.0, decoupled=False):
+                        exp_avg_sq, step, lr, b1=0.9, b2=0.999, adam_eps=1e-8, wd=0.0, decoupled=False, data16=None):
         """The fused step on a batch that is never materialised: cell b = row rows[b] of the resident matrix ``data``
-        (mmvae_train_step_rows).  Raises NotImplementedError where the library does not offer it (gather then)."""
+        (mmvae_train_step_rows).  ``data16``: the matrix's bf16 copy (``to_bf16``; bf16 engine only).  Raises
+        NotImplementedError where the library does not offer it (gather then)."""
         assert data.dim() == 2 and data.stride(1) == 1 and rows.dtype == torch.int64 and rows.numel() == self.dims.B
+        if data16 is not None:
+            assert (data16.dtype == torch.bfloat16 and data16.shape == data.shape and data16.stride() == data.stride()
+                    and data16.device == data.device)
         check(lib().mmvae_train_step_rows(C.byref(self.dims), C.byref(hyper), C.byref(noise), _ptr(params),
-                                          _ptr(bn_running), _ptr(nbt), _ptr(data), int(data.stride(0)), int(data.shape[0]),
+                                          _ptr(bn_running), _ptr(nbt), _ptr(data), _ptr(data16), int(data.stride(0)), int(data.shape[0]),
                                           _ptr(rows), _ptr(self.ws), self.ws_bytes, _ptr(grads), _ptr(self.loss_buf),
                                           int(do_adam), _ptr(exp_avg), _ptr(exp_avg_sq), int(step), lr, b1, b2, adam_eps, wd,
                                           int(decoupled), self._x(), self._s()), "mmvae_train_step_rows")
@@ -423,6 +429,18 @@ def consensus(counts: torch.Tensor, want_norm: bool = False):
     norm = torch.empty(P, Cc, Cc, dtype=torch.float64, device=cnt.device) if want_norm else None
     check(lib().mmvae_consensus(_ptr(cnt), P, Cc, _ptr(norm), _ptr(out), _stream(cnt.device)), "mmvae_consensus")
     return (out, norm) if want_norm else out
+
+
+def to_bf16(data: torch.Tensor) -> torch.Tensor:
+    """The bf16 copy of a resident float32 matrix (round to nearest even; same shape and strides in elements) for the bf16
+    engine's row-indexed step (mmvae_to_bf16; made once per data set)."""
+    if data.device.type != "cuda":
+        raise NativeError("to_bf16 needs a CUDA tensor (no CPU fallback)")
+    assert data.dim() == 2 and data.dtype == torch.float32 and data.stride(1) == 1
+    ld = int(data.stride(0))
+    out = torch.empty(data.shape[0] * ld, dtype=torch.bfloat16, device=data.device).as_strided(data.shape, data.stride())
+    check(lib().mmvae_to_bf16(_ptr(data), ld, data.shape[0], data.shape[1], _ptr(out), _stream(data.device)), "mmvae_to_bf16")
+    return out
 
 
 def gather_rows(data: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -196,13 +196,14 @@ class cpl_mixVAE:
         self.optimizer.step()
         return buf
 
-    def _step_rows(self, data: torch.Tensor, rows: torch.Tensor):
-        """``_step`` on the batch ``data[rows]`` read in place (``mixVAE_model.fused_train_step_rows``)."""
+    def _step_rows(self, data: torch.Tensor, rows: torch.Tensor, data16=None):
+        """``_step`` on the batch ``data[rows]`` read in place (``mixVAE_model.fused_train_step_rows``); ``data16``: the
+        matrix's bf16 copy for the bf16 configuration (bf16 storage)."""
         if D.is_dist():
-            return D.dp_train_step(self.model, None, self.temp, self.optimizer, rows=(data, rows))
+            return D.dp_train_step(self.model, None, self.temp, self.optimizer, rows=(data, rows, data16))
         if isinstance(self.optimizer, FusedAdam) and self.optimizer.model is self.model:
-            return self.model.fused_train_step_rows(data, rows, self.temp, self.optimizer, do_adam=True)
-        buf = self.model.fused_train_step_rows(data, rows, self.temp, None, do_adam=False)
+            return self.model.fused_train_step_rows(data, rows, self.temp, self.optimizer, do_adam=True, data16=data16)
+        buf = self.model.fused_train_step_rows(data, rows, self.temp, None, do_adam=False, data16=data16)
         self.model.bind_grads()
         self.optimizer.step()
         return buf
@@ -242,8 +243,14 @@ class cpl_mixVAE:
             first_rows = next(it, None)
             if first_rows is None:
                 return
+            # the bf16 configuration on bf16 storage: the loader keeps a bf16 copy of its matrix (made
+            # once) and the GEMMs read that; MMVAE_BF16_STORAGE=0 keeps them on the fp32 matrix
+            data16 = None
+            if (getattr(self.model, "gemm_dtype", "fp32") == "bf16" and hasattr(loader, "data_bf16")
+                    and os.environ.get("MMVAE_BF16_STORAGE", "1") != "0"):
+                data16 = loader.data_bf16()
             try:
-                buf = self._step_rows(loader.data, first_rows)
+                buf = self._step_rows(loader.data, first_rows, data16)
             except NotImplementedError:
                 self._rows_ok = False
                 if hasattr(loader, "_auto_epoch") and loader._auto_epoch is not None:
@@ -251,7 +258,7 @@ class cpl_mixVAE:
             else:
                 yield buf
                 for rows in it:
-                    yield self._step_rows(loader.data, rows)
+                    yield self._step_rows(loader.data, rows, data16)
                 return
         if self.device.type != "cuda" or not self.pipeline:
             for b in loader:

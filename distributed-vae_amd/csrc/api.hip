@@ -613,8 +613,8 @@ int mmvae_train_step(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_nois
 }
 
 int mmvae_train_step_rows(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noise* nz, float* params,
-                          float* bn_running, int64_t* nbt, const float* data, int64_t ld, int64_t n_rows, const int64_t* rows,
-                          void* ws, size_t ws_bytes, float* grads, float* loss_out, int do_adam, float* exp_avg,
+                          float* bn_running, int64_t* nbt, const float* data, const uint16_t* data_bf16, int64_t ld, int64_t n_rows,
+                          const int64_t* rows, void* ws, size_t ws_bytes, float* grads, float* loss_out, int do_adam, float* exp_avg,
                           float* exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float adam_eps,
                           float weight_decay, int decoupled, mmvae_exec* ex, void* stream) {
     Ctx c;
@@ -632,6 +632,13 @@ int mmvae_train_step_rows(const mmvae_dims* d, const mmvae_hyper* h, const mmvae
         (int64_t)cdiv(d->B, 128) * c.lay.sp.ks_gd10 > c.lay.n11 || c.tune(MMVAE_TUNE_FC11_ZG_OFF) || ((h->gemm_bf16 >> 8) & 15)) {
         set_error("train_step_rows: only the fused training step of the fp32x3 / bf16 engines reads the batch through a row map");
         return MMVAE_E_UNSUPPORTED;
+    }
+    if (data_bf16) {   // bf16 storage: the bf16 engine reads x from the copy and keeps dZ11 as bf16
+        if (!b16 || (d->D & 7) || (ld & 7) || (reinterpret_cast<uintptr_t>(data_bf16) & 15)) {
+            set_error("train_step_rows: data_bf16 needs the bf16 engine, D %% 8 == 0, ld %% 8 == 0 and a 16-byte aligned copy");
+            return MMVAE_E_UNSUPPORTED;
+        }
+        c.x16 = data_bf16;
     }
     c.x_rows = rows;
     c.x_ld = ld;

@@ -744,6 +744,10 @@ struct Ctx {
     // mmvae_train_step_rows: the batch is rows x_rows[0 .. B) (device, int64) of the resident matrix [x_nrows][x_ld] that the
     // call's `x` points at; the head launch of the step turns them into the row map (Layout::rowmap) and sets rowmap_ready
     const int64_t* x_rows = nullptr;
+    // ... and, optionally, its bf16 copy (same shape and leading dimension, in elements): the bf16 engine's large GEMMs and its
+    // fused fc11 kernel read x from it and dZ11 travels as bf16 (dz16: the fused kernel of this call wrote it that way)
+    const unsigned short* x16 = nullptr;
+    mutable bool dz16 = false;
     int64_t x_ld = 0, x_nrows = 0;
     mutable bool rowmap_ready = false;
 };

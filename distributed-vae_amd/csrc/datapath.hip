@@ -53,6 +53,21 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ d
     }
 }
 
+
+// dst[r][c] = bf16(src[r][c]) (round to nearest even, v_cvt_pk_bf16_f32: the rounding the one-plane engine applies to its
+// operands on their way into LDS), c < D rounded up to the row pitch: the bf16 copy of a resident matrix, made once per data set
+__global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ src, int64_t ld, int64_t n_rows, int D, unsigned short* __restrict__ dst) {
+    const int64_t quads = ld >> 2;                       // ld % 4 == 0: whole rows, pitch included (columns >= D are never read)
+    const int64_t n = n_rows * quads;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 a, b;
+        a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
+        *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    }
+}
+
 }  // namespace mmvae
 
 using namespace mmvae;
@@ -66,5 +81,17 @@ extern "C" int mmvae_gather_rows(const float* data, int64_t ld, int64_t n_rows, 
     if (vec) hipLaunchKernelGGL((k_gather_rows<true>), dim3(blocks), dim3(256), 0, s, data, ld, n_rows, idx, n, D, out);
     else hipLaunchKernelGGL((k_gather_rows<false>), dim3(blocks), dim3(256), 0, s, data, ld, n_rows, idx, n, D, out);
     HIP_LAUNCH_CHECK("k_gather_rows");
+    return 0;
+}
+
+extern "C" int mmvae_to_bf16(const float* src, int64_t ld, int64_t n_rows, int32_t D, uint16_t* dst, void* stream) {
+    if (!src || !dst || n_rows <= 0 || D <= 0 || ld < D) { set_error("to_bf16: bad argument"); return MMVAE_E_BADARG; }
+    if ((ld & 3) || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 7)) {
+        set_error("to_bf16: needs ld %% 4 == 0, a 16-byte aligned source and an 8-byte aligned destination");
+        return MMVAE_E_UNSUPPORTED;
+    }
+    const int64_t n = n_rows * (ld >> 2);
+    hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)imin64(cdiv64(n, 256 * 4), 8192)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, ld, n_rows, D, dst);
+    HIP_LAUNCH_CHECK("k_to_bf16");
     return 0;
 }

@@ -109,6 +109,9 @@ struct Operand {
     const unsigned* rowmap;
     int64_t nrec;
     int map_n;
+    // bf16 storage (the bf16 configuration on a bf16 copy of x / a bf16 dZ11, mmvae_train_step_rows(data_bf16)): ptr addresses
+    // 2-byte elements (same ld, in elements); read through oct_load / oct_store below.  rows, K, ld: multiples of 8.
+    int src16;
 };
 
 // One K tile of an operand in flight: rows [r0, r0 + 128) x k [k0, k0 + KT).  `load` only REQUESTS the data (NQ
@@ -137,7 +140,7 @@ template <bool KMINOR>
 __device__ __forceinline__ OperandDev make_operand_dev(const Operand& o) {
     OperandDev d;
     const int64_t n = KMINOR ? (int64_t)o.K * o.ld : (int64_t)o.rows * o.ld;
-    d.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.ptr), 0, (int)((o.rowmap ? o.nrec : n) * 4), 0x00020000);
+    d.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.ptr), 0, (int)((o.rowmap ? o.nrec : n) * (o.src16 ? 2 : 4)), 0x00020000);
     d.rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(o.rowmap ? o.rowmap : reinterpret_cast<const unsigned*>(o.ptr)), 0,
                                              (int)((o.rowmap ? o.map_n : 1) * 4), 0x00020000);
     d.mp = o.rowmap;
@@ -320,6 +323,76 @@ __device__ __forceinline__ void quad_store(unsigned* __restrict__ T, const TileR
         split3(x[2], x[3], w1);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(&T[pl * PLANE + idx]) = make_uint2(w0[pl], w1[pl]);
+    }
+}
+
+// ---- operands kept as bf16 in HBM (Operand::src16; one-plane engine, K tile 64) ----------------------------------------------
+// A piece is 16 bytes = EIGHT elements, four pieces per thread and K tile (an fp32 operand: eight pieces of four): K-major
+// piece p = row (tid >> 3) + 32 p, k = k0 + 8 (tid & 7) .. + 7; K-minor piece p = memory row k = k0 + (tid >> 4) + 16 p, rows
+// 8 (tid & 15) .. + 7.  The values are what quad_store would have produced from the fp32 original (round to nearest even, at
+// the producer instead of here), so they go to the LDS image as they are -- one 16-byte store, no conversion -- with the keep
+// bits ANDed on as half-word masks.  IDX: through the row map; ro[p] is the element offset of piece p's memory row.
+struct OctRegs { u32x4v v[4]; uint32_t wd[4]; };
+template <bool KMINOR, bool IDX>
+__device__ __forceinline__ void oct_load(OctRegs& t, const OperandDev& o, int r0, int k0, int kend, int p, const unsigned (&ro)[8]) {
+    const int tid = threadIdx.x & 255;
+    int off, woff;
+    if (!KMINOR) {
+        const int row = r0 + (tid >> 3) + 32 * p;
+        const int rc = min(row, o.rows - 1);
+        const int k = k0 + 8 * (tid & 7);
+        const bool ok = row < o.rows && k + 7 < kend && k + 7 < o.K;         // K % 8 == 0, k0 % 8 == 0
+        off = (IDX ? (int)ro[p] : rc * o.ld) + (ok ? k : 0);
+        woff = rc * o.wpr + ((ok ? k : 0) >> 5);
+    } else {
+        const int k = k0 + (tid >> 4) + 16 * p;
+        const int kc = min(k, o.K - 1);
+        const int row = r0 + 8 * (tid & 15);                                 // ld % 8 == 0: the eight stay inside the memory row
+        off = (IDX ? (int)ro[p] : kc * o.ld) + (row < o.ld ? row : 0);
+        woff = kc * o.wpr + (min(row, o.rows - 1) >> 5);
+    }
+    t.v[p] = __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(o.rs, off * 2, 0, 0));
+    t.wd[p] = o.bits ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(o.rb, woff * 4, 0, 0) : 0xFFFFFFFFu;
+}
+template <bool KMINOR>
+__device__ __forceinline__ void oct_store(unsigned* __restrict__ T, const OctRegs& t, const OperandDev& o, int r0, int k0, int kend, int p) {
+    const int tid = threadIdx.x & 255;
+    int byte, idx;      // keep bits of the eight elements; dword index of the 16-byte LDS store
+    if (!KMINOR) {
+        const int rr = (tid >> 3) + 32 * p, row = r0 + rr;
+        const int k = k0 + 8 * (tid & 7);
+        const bool ok = row < o.rows && k + 7 < kend && k + 7 < o.K;
+        byte = ok ? (int)((t.wd[p] >> (k & 31)) & 0xFFu) : 0;
+        idx = rr * LDB + 4 * (tid & 7);
+    } else {
+        const int kl = (tid >> 4) + 16 * p, k = k0 + kl;
+        const int r8 = 8 * (tid & 15);
+        const bool kok = k < kend && k < o.K;
+        const int nrow = min(max(o.rows - (r0 + r8), 0), 8);
+        byte = kok ? (int)((t.wd[p] >> ((r0 + r8) & 31)) & ((1u << nrow) - 1u)) : 0;
+        idx = (kl * LDK + r8) >> 1;
+    }
+    u32x4v w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned m = ((unsigned)__builtin_amdgcn_sbfe(byte, 2 * j, 1) & 0xFFFFu) | ((unsigned)__builtin_amdgcn_sbfe(byte, 2 * j + 1, 1) & 0xFFFF0000u);
+        w[j] = t.v[p][j] & m;
+    }
+    *reinterpret_cast<u32x4v*>(&T[idx]) = w;
+}
+// row-map offsets of the four pieces: K-major once per block tile; K-minor per K tile from the scalar map registers (the
+// memory rows of a wave's pieces are k0 + 4 wave + 16 p + quarter-wave: the same groups of four words as map_request reads)
+__device__ __forceinline__ void oct_ro_init(unsigned (&ro)[8], const OperandDev& o, int r0) {
+    const int tid = threadIdx.x & 255;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ro[p] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(o.rm, min(r0 + (tid >> 3) + 32 * p, o.rows - 1) * 4, 0, 0);
+}
+__device__ __forceinline__ void oct_map_offsets(unsigned (&ro)[8], const MapRegs<1>& mr) {
+    const int qq = (threadIdx.x >> 4) & 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned lo = (qq & 1) ? mr.s[p][1] : mr.s[p][0], hi = (qq & 1) ? mr.s[p][3] : mr.s[p][2];
+        ro[p] = (qq & 2) ? hi : lo;
     }
 }
 
@@ -586,7 +659,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // C tile -> slab.  grid (tiles_m * tiles_n, KS, A): block (m tile, n tile) x k range ks x arm.  Tile t + 1 is written to
 // the second LDS buffer while tile t is multiplied (one barrier per K tile); a piece's registers request tile t + 2 as
 // soon as they have been written out for tile t + 1.
-template <bool AMINOR, bool BMINOR, int EPI = 0, int IDX = 0>   // IDX: 1 / 2 = the A / B operand through its row map (see k_x3_gemm)
+// IDX: 1 / 2 = the A / B operand through its row map (see k_x3_gemm); S16: 1 / 2 = the A / B operand is bf16 in memory
+template <bool AMINOR, bool BMINOR, int EPI = 0, int IDX = 0, int S16 = 0>
 __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const GemmArgs g = g_in;
     __shared__ __attribute__((aligned(16))) unsigned As[2][BT * LDB];   // two K tiles in LDS: tile t is multiplied while tile
@@ -610,41 +684,75 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegsT<true> ta, tb;
+    OctRegs t16;                       // S16: the bf16-source operand's pieces (ta / tb of that operand stay unused)
     unsigned ro[Eng<1>::NQ] = {};      // IDX: element offsets of the indexed operand's memory rows (see quad_load_idx)
     MapRegs<1> mr = {};
+    static_assert(IDX == 0 || S16 == 0 || IDX == S16, "row map and bf16 storage: the same operand (x)");
     // Software pipeline at the granularity of one 16-byte piece: a piece of tile t + 1 is rounded and written to LDS
     // and the SAME registers immediately request the piece of tile t + 2, so sixteen loads per thread are in flight
     // all the time and every load has a whole iteration (the other fifteen pieces, the MFMAs, the barrier) to land.
     auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
         constexpr bool LOAD = decltype(load_tag)::value;
-        if constexpr (LOAD && IDX == 1) idx_next<AMINOR, 1, KT>(ro, mr, oa, kld);
-        if constexpr (LOAD && IDX == 2) idx_next<BMINOR, 1, KT>(ro, mr, ob, kld);
+        if constexpr (LOAD && IDX == 1 && AMINOR) {
+            if constexpr (S16 == 1) { oct_map_offsets(ro, mr); map_request<1>(mr, oa, kld + KT); }
+            else idx_next<AMINOR, 1, KT>(ro, mr, oa, kld);
+        }
+        if constexpr (LOAD && IDX == 2 && BMINOR) {
+            if constexpr (S16 == 2) { oct_map_offsets(ro, mr); map_request<1>(mr, ob, kld + KT); }
+            else idx_next<BMINOR, 1, KT>(ro, mr, ob, kld);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             // (no run-time condition around a load: hipcc then waits for every load separately)
-            quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
-            if constexpr (LOAD) {
-                if constexpr (IDX == 1) quad_load_idx<AMINOR, 1>(ta, oa, m0, kld, ke, q, ro);
-                else quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
+            if constexpr (S16 == 1) {
+                if (q < 4) {
+                    oct_store<AMINOR>(Ad, t16, oa, m0, kst, ke, q);
+                    if constexpr (LOAD) oct_load<AMINOR, IDX == 1>(t16, oa, m0, kld, ke, q, ro);
+                }
+            } else {
+                quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
+                if constexpr (LOAD) {
+                    if constexpr (IDX == 1) quad_load_idx<AMINOR, 1>(ta, oa, m0, kld, ke, q, ro);
+                    else quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
+                }
             }
-            quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
-            if constexpr (LOAD) {
-                if constexpr (IDX == 2) quad_load_idx<BMINOR, 1>(tb, ob, n0, kld, ke, q, ro);
-                else quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
+            if constexpr (S16 == 2) {
+                if (q < 4) {
+                    oct_store<BMINOR>(Bd, t16, ob, n0, kst, ke, q);
+                    if constexpr (LOAD) oct_load<BMINOR, IDX == 2>(t16, ob, n0, kld, ke, q, ro);
+                }
+            } else {
+                quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
+                if constexpr (LOAD) {
+                    if constexpr (IDX == 2) quad_load_idx<BMINOR, 1>(tb, ob, n0, kld, ke, q, ro);
+                    else quad_load<BMINOR>(tb, ob, n0, kld, ke, q);
+                }
             }
         }
     };
+    // first K tile: the indexed operand's offsets, then every piece's request
+    auto first = [&](auto a_tag) __attribute__((always_inline)) {
+        constexpr bool ISA = decltype(a_tag)::value;
+        constexpr bool MINOR = ISA ? AMINOR : BMINOR;
+        constexpr bool IDXD = IDX == (ISA ? 1 : 2), IS16 = S16 == (ISA ? 1 : 2);
+        const OperandDev& o = ISA ? oa : ob;
+        const int r0 = ISA ? m0 : n0;
+        if constexpr (IS16) {
+            if constexpr (IDXD) {
+                if constexpr (MINOR) { map_request<1>(mr, o, kb); oct_map_offsets(ro, mr); map_request<1>(mr, o, kb + KT); }
+                else oct_ro_init(ro, o, r0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) oct_load<MINOR, IDXD>(t16, o, r0, kb, ke, q, ro);
+        } else if constexpr (IDXD) {
+            idx_begin<MINOR, 1, KT>(ro, mr, o, r0, kb);
+#pragma unroll
+            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<MINOR, 1>(ISA ? ta : tb, o, r0, kb, ke, q, ro);
+        } else tile_load<MINOR>(ISA ? ta : tb, o, r0, kb, ke);
+    };
     if (kb < ke) {
-        if constexpr (IDX == 1) {
-            idx_begin<AMINOR, 1, KT>(ro, mr, oa, m0, kb);
-#pragma unroll
-            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<AMINOR, 1>(ta, oa, m0, kb, ke, q, ro);
-        } else tile_load<AMINOR>(ta, oa, m0, kb, ke);
-        if constexpr (IDX == 2) {
-            idx_begin<BMINOR, 1, KT>(ro, mr, ob, n0, kb);
-#pragma unroll
-            for (int q = 0; q < Eng<1>::NQ; ++q) quad_load_idx<BMINOR, 1>(tb, ob, n0, kb, ke, q, ro);
-        } else tile_load<BMINOR>(tb, ob, n0, kb, ke);
+        first(VecTag{});
+        first(ScalarTag{});
     }
     if (kb < ke) {
         if (kb + KT < ke) stage(As[0], Bs[0], kb, kb + KT, VecTag{});
@@ -984,6 +1092,10 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
 // no lane movement.  The B operand uses the same order: W11[gene][h] for four consecutive genes and one h per lane comes
 // out of the [gene][h] image that is in LDS anyway through the transposing read (two ds_read_b64_tr_b16).  The d(d10)
 // accumulators (32 cells x 128 h per wave) live across the whole gene range and are written once, to the gene-split slab.
+// S16 (bf16 storage): x is read from its bf16 copy (g.fo.x addresses 2-byte elements; the loss and dZ11 then see the rounded
+// x) and dZ11 is WRITTEN as bf16 (g.fo.dz likewise) -- exactly the values the d(d10) product here and the dW11 GEMM take
+// anyway, so only the loss's view of x changes; the kernel moves 2 x 2 + 2 bytes per cell and gene instead of 2 x 4 + 4.
+template <bool S16>
 __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
     const GemmArgs g = g_in;
     __shared__ __attribute__((aligned(16))) unsigned Ws[2][BT * LDB];   // W11 tile: [gene][k = h], two K tiles
@@ -1049,7 +1161,12 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int gene = j0 + 32 * (2 * half + gl) + 8 * q + 4 * hh;
-                    xin[gl][q] = *reinterpret_cast<const float4*>(xa + rowoff + min(gene, D - 4));      // D % 4 == 0
+                    if constexpr (S16) {
+                        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(xa) + rowoff + min(gene, D - 4));
+                        xin[gl][q] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+                    } else
+                        xin[gl][q] = *reinterpret_cast<const float4*>(xa + rowoff + min(gene, D - 4));      // D % 4 == 0
                 }
             __builtin_amdgcn_sched_barrier(0);
             f32x16 acc[2] = {zero16(), zero16()};       // z^T[gene sub-tile 2 half + gl][this wave's 32 cells]
@@ -1085,7 +1202,10 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
                         se += ok ? er * er : 0.f;
                         mism += (ok && ((xr > 0.1f) != (xv[e] > 0.1f))) ? 1 : 0;
                     }
-                    if (ok) *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) =
+                    if constexpr (S16) {
+                        if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dza) + (int64_t)cell * D + gene) =
+                            make_uint2(pack_bf16(dzr[4 * q], dzr[4 * q + 1]), pack_bf16(dzr[4 * q + 2], dzr[4 * q + 3]));
+                    } else if (ok) *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) =
                         make_float4(dzr[4 * q], dzr[4 * q + 1], dzr[4 * q + 2], dzr[4 * q + 3]);
                 }
                 // d(d10) += dZ11 piece (registers) x W11 rows 32 gi .. + 31 (LDS): two K steps of sixteen genes
@@ -1575,8 +1695,8 @@ __global__ __launch_bounds__(512, 1) void k_x3_small(const TnDescs descs, int nd
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers (same workspace layouts and split factors as the fp32 fast path)
 // ---------------------------------------------------------------------------------------------------------------
-static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1, nullptr, 0, 0, 0, nullptr, 0, 0}; }
-static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1, nullptr, 0, 0, 0, nullptr, 0, 0}; }
+static Operand kmajor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 0, nullptr, 0, -1, nullptr, 0, 0, 0, nullptr, 0, 0, 0}; }
+static Operand kminor(const float* p, int64_t ld, int rows, int K) { return Operand{p, ld, rows, K, 1, nullptr, 0, -1, nullptr, 0, 0, 0, nullptr, 0, 0, 0}; }
 
 // Slice planes of the four small operands (fp32x3 engine).  They are written by launch_x3_planes at fixed points of the
 // step -- W1 and [W11 | b11] at the start of the forward pass, [d10 | 1] behind the decoder chain, dZ1 behind the encoder's
@@ -1688,6 +1808,9 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
         if (split3_gemms(c)) {
             use_planes(c, g.b, PL_W1);
             hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true, 1>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+        } else if (c.x16) {         // bf16 storage: x from its bf16 copy
+            g.a.ptr = reinterpret_cast<const float*>(c.x16); g.a.src16 = 1;
+            hipLaunchKernelGGL((k_bf16_gemm<false, false, 0, 1, 1>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         } else
             hipLaunchKernelGGL((k_bf16_gemm<false, false, 0, 1>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
     } else if (split3_gemms(c)) {   // (fc_dim <= 124: one tile wide, the two tiles of a block share the W1 tile)
@@ -1753,7 +1876,13 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.fo_x_arm = xs;
         if (fused) {   // train step: d(d10) comes out of the same launch (which & 2 is then a no-op)
             g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
-            hipLaunchKernelGGL(k_bf16_fc11g, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+            if (c.x16) {   // bf16 storage: x from its bf16 copy, dZ11 written as bf16 (dW11 below reads it that way)
+                g.fo.x = reinterpret_cast<const float*>(c.x16);
+                g.fo_arm = (int64_t)d.B * d.D / 2;          // (arm stride of dZ11 in floats: B * D two-byte elements)
+                c.dz16 = true;
+                hipLaunchKernelGGL(k_bf16_fc11g<true>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+            } else
+                hipLaunchKernelGGL(k_bf16_fc11g<false>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
             HIP_LAUNCH_CHECK("k_bf16_fc11g");
         } else {
             hipLaunchKernelGGL(k_bf16_fc11, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
@@ -1798,6 +1927,9 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
             if (split3_gemms(c)) {
                 use_planes(c, g.a, PL_DZ1);
                 hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true, 2>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+            } else if (c.x16) {
+                g.b.ptr = reinterpret_cast<const float*>(c.x16); g.b.src16 = 1;
+                hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 2, 2>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
             } else
                 hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 2>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         } else if (split3_gemms(c)) {   // one tile high: the two tiles of a block share the dZ1 tile
@@ -1820,6 +1952,10 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         if (split3_gemms(c)) {   // one tile wide: the two tiles of a block share the [d10 | 1] tile
             use_planes(c, g.b, PL_D10);
             hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+        } else if (c.dz16) {        // bf16 storage: the fused fc11 kernel of this step wrote dZ11 as bf16
+            g.a.src16 = 1;
+            g.a_arm = (int64_t)d.B * d.D / 2;
+            hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 0, 1>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         } else
             hipLaunchKernelGGL((k_bf16_gemm<true, true>), dim3(cdiv(d.D, BT) * cdiv(d.H + 1, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         HIP_LAUNCH_CHECK("k_bf16_gemm<dW11>");

@@ -131,8 +131,9 @@ def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False, rows=None)
     B = xs.shape[-2] if rows is None else int(rows[1].numel())
     eng = model._ensure(B)
     eng.enable_early_grad_event(overlap)
-    if rows is not None:      # (data, row indices): the batch is read through a row map, never materialised
-        buf = model.fused_train_step_rows(rows[0], rows[1], temp, optimizer, do_adam=False)
+    if rows is not None:      # (data, row indices[, bf16 copy of data]): the batch is read through a row map, never materialised
+        buf = model.fused_train_step_rows(rows[0], rows[1], temp, optimizer, do_adam=False,
+                                          data16=rows[2] if len(rows) > 2 else None)
     else:
         buf = model.fused_train_step(xs, temp, optimizer, do_adam=False)
     flat = model.flat_grad()

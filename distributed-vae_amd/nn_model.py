@@ -418,11 +418,12 @@ class mixVAE_model(nn.Module):
                               None, None, 1, 0.0)
 
 
-    def fused_train_step_rows(self, data, rows, temp, opt=None, do_adam=True):
+    def fused_train_step_rows(self, data, rows, temp, opt=None, do_adam=True, data16=None):
         """``fused_train_step`` on the batch ``data[rows]`` without materialising it (``x.expand`` over the arms): the step
         reads the cells x genes matrix through a row map (mmvae_train_step_rows; bit-identical to gather + step).  Raises
         ``NotImplementedError`` where the library does not offer it -- engines other than fp32x3, no input dropout, a
-        matrix beyond 4 GB --: gather the batch and call ``fused_train_step`` then."""
+        matrix beyond 4 GB --: gather the batch and call ``fused_train_step`` then.  ``data16`` (``gemm_dtype == "bf16"``
+        only): the matrix's bf16 copy (``_native.to_bf16``, ``DeviceLoader.data_bf16()``): bf16 storage, see DESIGN.md section 13."""
         if data.device.type != "cuda" or data.dtype != torch.float32 or data.shape[1] != self.input_dim:
             raise N.NativeError("fused_train_step_rows needs the float32 cells x genes matrix on the GPU")
         rows = rows.to(device=data.device, dtype=torch.int64).contiguous()
@@ -435,11 +436,11 @@ class mixVAE_model(nn.Module):
                 g = opt.param_groups[0]
                 buf = eng.train_step_rows(hyper, noise, self._flat, self._bn_flat, self._nbt, data, rows, self._flat_grad, True,
                                           opt.exp_avg, opt.exp_avg_sq, opt.step_count + 1, g["lr"], g["betas"][0],
-                                          g["betas"][1], g["eps"], g["weight_decay"], opt.decoupled)
+                                          g["betas"][1], g["eps"], g["weight_decay"], opt.decoupled, data16=data16)
                 opt.step_count += 1
             else:
                 buf = eng.train_step_rows(hyper, noise, self._flat, self._bn_flat, self._nbt, data, rows, self._flat_grad, False,
-                                          None, None, 1, 0.0)
+                                          None, None, 1, 0.0, data16=data16)
         except NotImplementedError:
             if self._explicit_noise is None:
                 self._noise_offset -= 1            # the refused call consumed nothing

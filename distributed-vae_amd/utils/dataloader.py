@@ -96,6 +96,7 @@ class DeviceLoader:
         self._slot = 0
         self.prefetch_order = True       # see _epoch_rows
         self._order_stream, self._ahead = None, None
+        self._data16 = None
         self._pin, self._pin_ev, self._pin_k, self._copy_stream = None, None, 0, None
         self.host_order = False      # True: torch's CPU permutation (DistributedSampler's exact sequence), uploaded per epoch
 
@@ -181,6 +182,13 @@ class DeviceLoader:
         n = int(self.index.numel())
         for i in range(0, n, int(rows)):
             yield N.gather_rows(self.data, self.index[i:i + int(rows)])
+
+    def data_bf16(self):
+        """The bf16 copy of ``self.data`` for the bf16 configuration's row-indexed step (made on first use, once per data
+        set: ``_native.to_bf16``), or None where that step cannot use it (gene count or row pitch not a multiple of 8)."""
+        if self._data16 is None and self.data.device.type == "cuda" and self.data.shape[1] % 8 == 0 and self.data.stride(0) % 8 == 0:
+            self._data16 = N.to_bf16(self.data)
+        return self._data16
 
     def _epoch_rows(self) -> torch.Tensor:
         """Row indices (into ``self.data``) of this rank's epoch, in visiting order, and the epoch bookkeeping of one pass.

@@ -265,9 +265,18 @@ int mmvae_train_step(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_nois
  * offsets the step's head launch derives from `rows`), so a shuffled batch costs what a resident one does.  Bit-identical to
  * mmvae_gather_rows + mmvae_train_step.  Offered where it is built -- the fused training step of the fp32x3 and bf16 engines
  * (gemm_bf16 & 0xFF == 2 with fc_dim <= 111, or == 1; x_drop > 0), ld % 4 == 0, 16-byte aligned data, n_rows * ld < 2^30 floats --; otherwise
- * MMVAE_E_UNSUPPORTED: gather the batch and call mmvae_train_step. */
+ * MMVAE_E_UNSUPPORTED: gather the batch and call mmvae_train_step.
+ *
+ * data_bf16 (optional, NULL = none; the bf16 engine only, BASELINE.json configs[2]): a bf16 copy of `data` with the same
+ * shape and leading dimension (in elements), made once per data set by mmvae_to_bf16.  The engine rounds x to bf16 on its way
+ * to the matrix pipe anyway; with the copy fc1, dW1 and the fused fc11 kernel read 2 bytes per cell and gene instead of 4, and
+ * dZ11 travels from the fused kernel to the dW11 GEMM as bf16 (the values that GEMM takes in any case).  Same results as the
+ * step on an fp32 matrix that holds the rounded values -- bit for bit --; against the unrounded matrix only the
+ * reconstruction loss changes: it compares with the rounded x (within the configuration's 5e-2 gate).
+ * Needs D % 8 == 0, ld % 8 == 0, a 16-byte aligned copy; MMVAE_E_UNSUPPORTED otherwise or with another engine. */
 int mmvae_train_step_rows(const mmvae_dims *d, const mmvae_hyper *h, const mmvae_noise *nz, float *params,
-                          float *bn_running, int64_t *num_batches_tracked, const float *data, int64_t ld,
+                          float *bn_running, int64_t *num_batches_tracked, const float *data,
+                          const uint16_t *data_bf16, int64_t ld,
                           int64_t n_rows, const int64_t *rows, void *ws, size_t ws_bytes, float *grads,
                           float *loss_out, int do_adam, float *exp_avg, float *exp_avg_sq, int64_t step, float lr,
                           float beta1, float beta2, float adam_eps, float weight_decay, int decoupled,
@@ -339,6 +348,10 @@ int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, 
  * (out-of-range indices are clamped; the host loader validates them); out: [n, D] contiguous. */
 int mmvae_gather_rows(const float *data, int64_t ld, int64_t n_rows, const int64_t *idx, int64_t n, int32_t D,
                       float *out, void *stream);
+/* dst[r, c] = bf16(src[r, c]) (round to nearest even), r < n_rows, whole rows of ld elements: the bf16 copy of a resident
+ * matrix for mmvae_train_step_rows(data_bf16).  src: [n_rows, ld] fp32, ld % 4 == 0, 16-byte aligned; dst: [n_rows, ld]
+ * 2-byte elements. */
+int mmvae_to_bf16(const float *src, int64_t ld, int64_t n_rows, int32_t D, uint16_t *dst, void *stream);
 /* ---- data-parallel gradient exchange (SURVEY.md sections 8b / 8e) ------------------------------------------------------
  * ONE RCCL all-reduce (average) of the flat fp32 gradient buffer per step, issued by the library on the stream the step
  * runs on (stream-ordered behind mmvae_train_step(do_adam = 0), in front of mmvae_adam_step; no host synchronisation, no

@@ -193,3 +193,26 @@ def test_shuffled_epoch_through_row_indices_equals_gathered_batches(monkeypatch)
     assert out[0][2] is True                                         # the row-indexed path was taken, not refused
     for o in out[1:]:
         assert torch.equal(out[0][0], o[0]) and out[0][1] == o[1]
+
+
+def test_bf16_trainer_epoch_on_bf16_storage_equals_fp32_storage_of_the_rounded_matrix(monkeypatch):
+    """``cpl_mixVAE.train`` in the bf16 configuration: the loader's bf16 copy feeds the row-indexed steps (default) -- same
+    parameters and history, bit for bit, as with MMVAE_BF16_STORAGE=0 when the matrix holds bf16-representable values."""
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    from distributed_vae_amd.utils.dataloader import DeviceLoader
+    from oracle import restatement as R
+    from tests import gpu_util as U
+    data = R.synthetic_batch(1300, 520, seed=9).to(torch.bfloat16).float().to(U.DEV)
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MMVAE_BF16_STORAGE", mode)
+        torch.manual_seed(77)
+        t = cpl_mixVAE(saving_folder="", device=U.DEV, save_flag=False)
+        t.init_model(n_categories=12, state_dim=2, input_dim=520, fc_dim=100, lowD_dim=6, x_drop=0.5, s_drop=0.0, n_arm=2,
+                     gemm_dtype="bf16")
+        ld = DeviceLoader(data, torch.arange(1300), 256, True, True, seed=5)
+        hist = t.train(ld, None, n_epoch=2, good_enuf_consensus=2.0)
+        torch.cuda.synchronize()
+        out.append((t.model.flat_parameters().detach().cpu().clone(), hist["losses"], ld._data16 is not None))
+    assert out[0][2] is True and out[1][2] is False
+    assert torch.equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]

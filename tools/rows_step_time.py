@@ -31,11 +31,14 @@ def timed(fn, n=60):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n
 
+from distributed_vae_amd import _native as N
+data16 = N.to_bf16(data) if m.gemm_dtype == "bf16" else None
 mode = os.environ.get("MODE")      # one variant only (under rocprofv3 --kernel-trace --stats: per-kernel durations of that variant)
 if mode:
     fn = {"fixed": lambda i: m.fused_train_step(batches[i % 10].expand(A, -1, -1), 1.0, opt, True),
           "identity": lambda i: m.fused_train_step_rows(data, ident[i % 10], 1.0, opt, True),
           "random": lambda i: m.fused_train_step_rows(data, rnd[i % 10], 1.0, opt, True),
+          "storage16": lambda i: m.fused_train_step_rows(data, rnd[i % 10], 1.0, opt, True, data16=data16),
           "sorted": lambda i: m.fused_train_step_rows(data, rnd[i % 10].sort().values, 1.0, opt, True)}[mode]
     print("%s %.4f ms" % (mode, timed(fn)))
     sys.exit(0)
@@ -43,3 +46,6 @@ print("fixed batches          %.4f ms" % timed(lambda i: m.fused_train_step(batc
 print("row map, identity      %.4f ms" % timed(lambda i: m.fused_train_step_rows(data, ident[i % 10], 1.0, opt, True)))
 print("row map, random rows   %.4f ms" % timed(lambda i: m.fused_train_step_rows(data, rnd[i % 10], 1.0, opt, True)))
 print("fixed batches          %.4f ms" % timed(lambda i: m.fused_train_step(batches[i % 10].expand(A, -1, -1), 1.0, opt, True)))
+if data16 is not None:
+    print("random rows, bf16 storage %.4f ms" % timed(lambda i: m.fused_train_step_rows(data, rnd[i % 10], 1.0, opt, True, data16=data16)))
+    print("row map, random rows   %.4f ms" % timed(lambda i: m.fused_train_step_rows(data, rnd[i % 10], 1.0, opt, True)))
