@@ -129,10 +129,14 @@ def P_count(N, A, B, D, H, L, C, S):
     return sum(int(lay.rows[t]) * int(lay.cols[t]) for t in range(N.N_PARAM_TENSORS))
 
 
-def bf16_config(args, model_args, batches, nb, A, B, D, H, L, C, S, P, world, rank, dev, timed, DD, FusedAdam, mixVAE_model):
+def bf16_config(args, model_args, data, batches, nb, A, B, D, H, L, C, S, P, world, rank, dev, timed, DD, FusedAdam, mixVAE_model):
     """BASELINE.json configs[2] (bf16 GEMM operands, data parallel over the node's GPUs): the same K timed steps with
     ``gemm_dtype = "bf16"`` on a fresh model.  With the matrix pipe 16 x faster the step is priced against HBM: SURVEY.md
-    section 8(d)'s algorithmic bytes per cell with bf16 operands, A (10 D + 80 H + 36 P / B), times cells/s, over 8 TB/s."""
+    section 8(d)'s algorithmic bytes per cell with bf16 operands, A (10 D + 80 H + 36 P / B), times cells/s, over 8 TB/s.
+    The configuration runs on bf16 STORAGE: the resident matrix has a bf16 copy (made once, outside
+    the timed region, as the matrix's upload is) and the step reads the same cells through it (mmvae_train_step_rows with
+    data_bf16; dZ11 travels as bf16); the same step on the fp32 matrix is timed beside it (``fp32_storage``)."""
+    from distributed_vae_amd import _native as N
     torch.manual_seed(546)
     m = mixVAE_model(**model_args).to(dev)
     m.train()
@@ -140,25 +144,38 @@ def bf16_config(args, model_args, batches, nb, A, B, D, H, L, C, S, P, world, ra
     opt = FusedAdam(m, lr=1e-3)
     if world > 1:
         DD.broadcast_flat(m.flat_parameters())
+    storage = D % 8 == 0 and data.stride(0) % 8 == 0
+    data16 = N.to_bf16(data) if storage else None
+    rows = [torch.arange(i * B, (i + 1) * B, device=dev) for i in range(nb)]
 
-    def step(i):
+    def step16(i):
+        if world > 1 or args.rehearse_dp:
+            return DD.dp_train_step(m, None, 1.0, opt, rehearse=args.rehearse_dp, rows=(data, rows[i % nb], data16))
+        return m.fused_train_step_rows(data, rows[i % nb], 1.0, opt, do_adam=True, data16=data16)
+
+    def step32(i):
         xs = batches[i % nb].expand(A, -1, -1)
         if world > 1 or args.rehearse_dp:
             return DD.dp_train_step(m, xs, 1.0, opt, rehearse=args.rehearse_dp)
         return m.fused_train_step(xs, 1.0, opt, do_adam=True)
 
-    dt, ev, loss = timed(step)
+    dt32, ev32, loss32 = timed(step32)
+    dt, ev, loss = timed(step16) if storage else (dt32, ev32, loss32)
     cells = world * B * args.steps / dt
     by_cell = A * (10 * D + 80 * H + 36 * P / B)
     out = {"value": cells, "unit": "cells/s", "ms_per_step": dt / args.steps * 1e3, "ms_per_step_hip_events": ev,
            "dtype": "bf16 operands in the five D x H GEMMs, f32 accumulation and everything else", "n_gpus": world,
+           "storage": "bf16 copy of the resident matrix, dZ11 as bf16 (mmvae_train_step_rows with data_bf16)" if storage
+                      else "fp32 (gene count or row pitch not a multiple of 8)",
            "last_loss": loss, "bytes_per_cell_algorithmic": by_cell,
            "roofline": {"bound": "hbm", "achieved": cells / world * by_cell / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": cells / world * by_cell / 1e9 / PEAK_HBM_GBS,
-                        "note": "whole step, per GPU: algorithmic bytes per cell (SURVEY.md 8d, bf16 operands) x cells/s; "
-                                "this build keeps x and dZ11 in fp32 in HBM and rounds on load, so it moves more than that"}}
+                        "note": "whole step, per GPU: algorithmic bytes per cell (SURVEY.md 8d, bf16 operands) x cells/s"},
+           "fp32_storage": {"value": world * B * args.steps / dt32, "ms_per_step": dt32 / args.steps * 1e3,
+                            "ms_per_step_hip_events": ev32, "last_loss": loss32,
+                            "note": "the same configuration reading x and dZ11 as fp32 and rounding on load (rounds 1-2)"}}
     if rank == 0 and not args.no_roofline and (A, B, D, H) == (2, 5000, 5000, 100):
-        out["roofline"]["stages"] = measure_bf16_stages(m, batches[0], A, B, D, H)
+        out["fp32_storage"]["stages"] = measure_bf16_stages(m, batches[0], A, B, D, H)
     return out
 
 
@@ -236,6 +253,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-operand configuration measured beside the headline")
+    ap.add_argument("--bf16-fp32-storage", action="store_true",
+                    help="--gemm-dtype bf16 only: read x / dZ11 as fp32 and round on load instead of the bf16 copy")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
     ap.add_argument("--gemm-dtype", choices=["fp32", "fp32x3", "fp32_mfma", "bf16"], default="fp32",
                     help="operand type of the five D x H GEMMs: fp32 (the headline / parity configuration; the library's "
@@ -315,7 +334,17 @@ def main():
     data = synthetic_rows(nb * B, D, 546 + rank, dev)
     batches = [data[i * B:(i + 1) * B] for i in range(nb)]
 
+    # --gemm-dtype bf16: the configuration runs on bf16 storage (see bf16_config) unless --bf16-fp32-storage
+    data16 = None
+    if args.gemm_dtype == "bf16" and not args.bf16_fp32_storage and D % 8 == 0 and data.stride(0) % 8 == 0:
+        data16 = N.to_bf16(data)
+        row_sets = [torch.arange(i * B, (i + 1) * B, device=dev) for i in range(nb)]
+
     def step(i):
+        if data16 is not None:
+            if world > 1 or args.rehearse_dp:
+                return DD.dp_train_step(model, None, 1.0, opt, rehearse=args.rehearse_dp, rows=(data, row_sets[i % nb], data16))
+            return model.fused_train_step_rows(data, row_sets[i % nb], 1.0, opt, do_adam=True, data16=data16)
         xs = batches[i % nb].expand(A, -1, -1)
         if world > 1 or args.rehearse_dp:
             return DD.dp_train_step(model, xs, 1.0, opt, rehearse=args.rehearse_dp)
@@ -408,7 +437,7 @@ def main():
     if args.gemm_dtype != "bf16" and not args.no_bf16:
         # BASELINE.json configs[2] beside the headline: the same step with bf16 operands in the five D x H GEMMs
         try:
-            out["bf16_config"] = bf16_config(args, model_args, batches, nb, A, B, D, H, L, C, S, P_count(N, A, B, D, H, L, C, S),
+            out["bf16_config"] = bf16_config(args, model_args, data, batches, nb, A, B, D, H, L, C, S, P_count(N, A, B, D, H, L, C, S),
                                              world, rank, dev, timed, DD, FusedAdam, mixVAE_model)
         except Exception as e:   # noqa: BLE001
             out["bf16_config"] = {"error": f"{type(e).__name__}: {e}"}

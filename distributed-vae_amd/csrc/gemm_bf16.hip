@@ -791,6 +791,13 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
 // 500- and 1000-wide trunk layers at M = 5000: 40 to 160 tiles): twice the workgroups, half the K loop each.  With SPL the B
 // operand comes from planes, copied by each group for its own K tiles.
 // IDX: 1 / 2 = the A / B operand is read through its row map (Operand::rowmap: x of a batch that is never materialised)
+// K tiles of the fp32 operand a group keeps in flight.  2 (-DX3_DEPTH=2) was measured and lost: the kernels sit at 234 - 242 of
+// the 256 registers a thread of a 512-thread workgroup has, twenty more for the second tile spilled (2 - 40 registers) and
+// stretched the schedule -- fc1 79 -> 123 us, dW1 80 -> 108 us
+#ifndef X3_DEPTH
+#define X3_DEPTH 1
+#endif
+static_assert(X3_DEPTH == 1 || X3_DEPTH == 2, "one or two K tiles in flight");
 template <bool AMINOR, bool BMINOR, int EPI = 0, int SHARE = 0, bool SPL = false, int IDX = 0>
 __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     typedef Eng<3> E;
@@ -829,7 +836,14 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     constexpr int KSTEP = SHARE == 3 ? 2 * KTv : KTv;      // distance between consecutive K tiles of a group
     const int kfirst = SHARE == 3 ? kb + grp * KTv : kb;
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
-    TileRegsT<true, E::NQ> ta, tb;
+    // X3_DEPTH K tiles of a group's fp32 operand are in flight (register slot = tile index % X3_DEPTH).  With one, a CU keeps
+    // about 30 KB in flight and takes in 26 GB/s -- the latency-bound part of the intake curve (tools/micro/intake_bench.hip,
+    // profiles/r03_intake_microbench.txt: 29 GB/s at 16 KB in flight, 46 at 32 - 64 KB from L2, 28 from HBM) --, but the second
+    // tile's registers are not there (see X3_DEPTH above)
+    constexpr int DEPTH = X3_DEPTH;
+    // (only the fp32 operand -- the one that comes from HBM -- goes two deep: twenty registers; with the slice planes two deep
+    // as well the kernel spilled 48 - 64 registers)
+    TileRegsT<true, E::NQ> ta_[DEPTH], tb_[DEPTH];
     unsigned ro[E::NQ] = {};           // IDX: element offsets of the indexed operand's memory rows (see quad_load_idx)
     MapRegs<3> mr = {};
     PlaneRegs ps;
@@ -838,8 +852,13 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
     const PlaneDev dp = make_plane_dev(SHARE == 1 ? g.a : g.b, arm);
     const bool do_a = SHARE != 1 || grp == 0, do_b = SHARE != 2 || grp == 0;   // which operands this group stages
     // one piece of each operand in turn; a piece's registers request the next tile as soon as they have been written out
-    auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
-        constexpr bool LOAD = decltype(load_tag)::value;
+    // kst: the tile whose registers (slot SLOT) are written out; kld: the tile they then request (DEPTH tiles on, LOAD); kpl:
+    // the tile the plane registers request (one tile on, LOADP)
+    auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, int kpl, auto load_tag, auto loadp_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr bool LOAD = decltype(load_tag)::value, LOADP = decltype(loadp_tag)::value;
+        constexpr int SLOT = decltype(slot_tag)::value;
+        TileRegsT<true, E::NQ>& ta = ta_[SLOT];
+        TileRegsT<true, E::NQ>& tb = tb_[SLOT];
         if constexpr (LOAD && IDX == 1) idx_next<AMINOR, 3, KSTEP>(ro, mr, oa, kld);
         if constexpr (LOAD && IDX == 2) idx_next<BMINOR, 3, KSTEP>(ro, mr, ob, kld);
 #pragma unroll
@@ -847,7 +866,7 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             if constexpr (APL) {
                 if (do_a) {
                     plane_store<AMINOR>(Ad, ps, i);
-                    if constexpr (LOAD) plane_load<AMINOR>(ps, dp, m0, kld, i);
+                    if constexpr (LOADP) plane_load<AMINOR>(ps, dp, m0, kpl, i);
                 }
             } else if (i < E::NQ) {
                 if (do_a) {
@@ -861,7 +880,7 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             if constexpr (BPL) {
                 if (do_b) {
                     plane_store<BMINOR>(Bd, ps, i);
-                    if constexpr (LOAD) plane_load<BMINOR>(ps, dp, n0, kld, i);
+                    if constexpr (LOADP) plane_load<BMINOR>(ps, dp, n0, kpl, i);
                 }
             } else if (i < E::NQ) {
                 if (do_b) {
@@ -874,30 +893,42 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
             }
         }
     };
-    if (active && n_mine > 0) {
+    // the first DEPTH tiles' requests (tile d into slot d)
+    auto first = [&](auto slot_tag, int k) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        TileRegsT<true, E::NQ>& ta = ta_[SLOT];
+        TileRegsT<true, E::NQ>& tb = tb_[SLOT];
         if constexpr (APL) {
-            if (do_a) {
+            if (SLOT == 0 && do_a) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) plane_load<AMINOR>(ps, dp, m0, kfirst, i);
+                for (int i = 0; i < 6; ++i) plane_load<AMINOR>(ps, dp, m0, k, i);
             }
         } else if (do_a) {
             if constexpr (IDX == 1) {
-                idx_begin<AMINOR, 3, KSTEP>(ro, mr, oa, m0, kfirst);
+                if constexpr (SLOT == 0) idx_begin<AMINOR, 3, KSTEP>(ro, mr, oa, m0, k);
+                else idx_next<AMINOR, 3, KSTEP>(ro, mr, oa, k);
 #pragma unroll
-                for (int q = 0; q < E::NQ; ++q) quad_load_idx<AMINOR, 3>(ta, oa, m0, kfirst, ke, q, ro);
-            } else tile_load<AMINOR, true, 3>(ta, oa, m0, kfirst, ke);
+                for (int q = 0; q < E::NQ; ++q) quad_load_idx<AMINOR, 3>(ta, oa, m0, k, ke, q, ro);
+            } else tile_load<AMINOR, true, 3>(ta, oa, m0, k, ke);
         }
         if constexpr (BPL) {
-            if (do_b) {
+            if (SLOT == 0 && do_b) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) plane_load<BMINOR>(ps, dp, n0, kfirst, i);
+                for (int i = 0; i < 6; ++i) plane_load<BMINOR>(ps, dp, n0, k, i);
             }
         } else if (do_b) {
             if constexpr (IDX == 2) {
-                idx_begin<BMINOR, 3, KSTEP>(ro, mr, ob, n0, kfirst);
+                if constexpr (SLOT == 0) idx_begin<BMINOR, 3, KSTEP>(ro, mr, ob, n0, k);
+                else idx_next<BMINOR, 3, KSTEP>(ro, mr, ob, k);
 #pragma unroll
-                for (int q = 0; q < E::NQ; ++q) quad_load_idx<BMINOR, 3>(tb, ob, n0, kfirst, ke, q, ro);
-            } else tile_load<BMINOR, true, 3>(tb, ob, n0, kfirst, ke);
+                for (int q = 0; q < E::NQ; ++q) quad_load_idx<BMINOR, 3>(tb, ob, n0, k, ke, q, ro);
+            } else tile_load<BMINOR, true, 3>(tb, ob, n0, k, ke);
+        }
+    };
+    if (active && n_mine > 0) {
+        first(std::integral_constant<int, 0>{}, kfirst);
+        if constexpr (DEPTH > 1) {
+            if (n_mine > 1) first(std::integral_constant<int, DEPTH - 1>{}, kfirst + KSTEP);
         }
     }
 #ifdef X3_STAMPS
@@ -921,8 +952,16 @@ __global__ __launch_bounds__(512, 1) void k_x3_gemm(const GemmArgs g_in) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): how long the stage waits for its operands
                 { const long long t1 = __builtin_amdgcn_s_memtime(); t_ld += t1 - t0; t0 = t1; }
 #endif
-                if (k0 + KSTEP < ke) stage(Ad, Bd, k0, k0 + KSTEP, VecTag{});
-                else stage(Ad, Bd, k0, k0, ScalarTag{});
+                // tile t + DEPTH / t + 1 exist: their requests go out with tile t's store
+                const bool more = t + DEPTH < n_mine, morep = t + 1 < n_mine;
+                const int kld = k0 + DEPTH * KSTEP, kpl = k0 + KSTEP;
+                auto go = [&](auto slot_tag) __attribute__((always_inline)) {
+                    if (more) stage(Ad, Bd, k0, kld, kpl, VecTag{}, VecTag{}, slot_tag);
+                    else if (morep) stage(Ad, Bd, k0, k0, kpl, ScalarTag{}, VecTag{}, slot_tag);
+                    else stage(Ad, Bd, k0, k0, k0, ScalarTag{}, ScalarTag{}, slot_tag);
+                };
+                if (DEPTH == 1 || !(t & 1)) go(std::integral_constant<int, 0>{});
+                else go(std::integral_constant<int, DEPTH - 1>{});
 #ifdef X3_STAMPS
                 __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the LDS writes have been issued and accepted
                 { const long long t1 = __builtin_amdgcn_s_memtime(); t_st += t1 - t0; t0 = t1; }
@@ -1951,7 +1990,12 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
         if (split3_gemms(c)) {   // one tile wide: the two tiles of a block share the [d10 | 1] tile
             use_planes(c, g.b, PL_D10);
-            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
+            const int pad = c.tune(MMVAE_TUNE_DW11_LDS) * 1024;
+            if (pad > 0) {
+                static bool once = false;
+                if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_x3_gemm<true, true, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 40960); once = true; }
+            }
+            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), pad > 0 ? pad : 0, c.stream, g);
         } else if (c.dz16) {        // bf16 storage: the fused fc11 kernel of this step wrote dZ11 as bf16
             g.a.src16 = 1;
             g.a_arm = (int64_t)d.B * d.D / 2;

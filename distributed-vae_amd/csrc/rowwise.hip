@@ -1378,7 +1378,7 @@ struct RedDesc {
     int ks;   // slabs to sum
 };
 constexpr int MAX_RED = 28;
-struct RedDescs { RedDesc d[MAX_RED]; };
+struct RedDescs { RedDesc d[MAX_RED]; int first[MAX_RED + 1]; int n; };   // descriptor i owns blocks [first[i], first[i + 1]) of grid.x
 
 struct AdamArgs {
     float* p; float* m; float* v;        // null p: gradients only
@@ -1406,14 +1406,24 @@ __device__ __forceinline__ float adam_update1(const AdamArgs& adam, int64_t o, f
 
 template <bool VEC>
 __device__ __forceinline__ void reduce_desc(const RedDesc& d, int KS, int arm, float* __restrict__ grads, int64_t per_arm,
-                                            const AdamArgs& adam) {
+                                            const AdamArgs& adam, uint32_t bx, uint32_t nbx) {
     constexpr int E = VEC ? 4 : 1;
     const uint32_t cpr = (uint32_t)d.cols / E;                       // work items per row
     const uint32_t n = (uint32_t)d.rows * cpr;
     const float* base = d.slab + (int64_t)arm * d.arm_stride + d.col0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = bx * blockDim.x + threadIdx.x; i < n; i += nbx * blockDim.x) {
         const uint32_t r = i / cpr, cidx = (i - r * cpr) * E;
         const float* p = base + (int64_t)r * d.ld + cidx;
+        const int64_t o = (int64_t)arm * per_arm + d.dst_off + (int64_t)r * d.dst_ld + cidx;
+        // the parameter and its moments are requested WITH the slabs (one memory round trip per item instead of two)
+        float4 pi = make_float4(0.f, 0.f, 0.f, 0.f), mi = pi, vi = pi;
+        if constexpr (VEC) {
+            if (adam.p) {
+                pi = *reinterpret_cast<const float4*>(adam.p + o);
+                mi = *reinterpret_cast<const float4*>(adam.m + o);
+                vi = *reinterpret_cast<const float4*>(adam.v + o);
+            }
+        }
         float s[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) s[e] = 0.f;
@@ -1443,16 +1453,12 @@ __device__ __forceinline__ void reduce_desc(const RedDesc& d, int KS, int arm, f
         if (KS <= 4) add_slabs(std::integral_constant<int, 4>{});
         else if (KS <= 8) add_slabs(std::integral_constant<int, 8>{});
         else add_slabs(std::integral_constant<int, 16>{});
-        const int64_t o = (int64_t)arm * per_arm + d.dst_off + (int64_t)r * d.dst_ld + cidx;
         float g[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) g[e] = s[e] * d.scale;
         if constexpr (VEC) {
             *reinterpret_cast<float4*>(grads + o) = make_float4(g[0], g[1], g[2], g[3]);
             if (adam.p) {
-                const float4 pi = *reinterpret_cast<const float4*>(adam.p + o);
-                const float4 mi = *reinterpret_cast<const float4*>(adam.m + o);
-                const float4 vi = *reinterpret_cast<const float4*>(adam.v + o);
                 const float pin[4] = {pi.x, pi.y, pi.z, pi.w}, min_[4] = {mi.x, mi.y, mi.z, mi.w}, vin[4] = {vi.x, vi.y, vi.z, vi.w};
                 float po[4], mo[4], vo[4];
 #pragma unroll
@@ -1479,7 +1485,12 @@ __device__ __forceinline__ void reduce_desc(const RedDesc& d, int KS, int arm, f
 
 __global__ __launch_bounds__(256) void k_reduce(const RedDescs ds, float* __restrict__ grads, int64_t per_arm,
                                                 const AdamArgs adam_in) {
-    const int di = blockIdx.y, arm = blockIdx.z;
+    // grid (blocks of all descriptors, 1, A): large and small tensors in ONE launch -- the three D x H tensors want thousands of
+    // workgroups, the 23 small ones sixteen each, and as two launches the small one (latency-bound) cost as much as the large
+    int di = 0;
+    while (di + 1 < ds.n && (int)blockIdx.x >= ds.first[di + 1]) ++di;
+    const int arm = blockIdx.z;
+    const uint32_t bx = blockIdx.x - ds.first[di], nbx = ds.first[di + 1] - ds.first[di];
     const RedDesc& dr = ds.d[di];
     const RedDesc d = {dr.slab, dr.ks_stride, dr.arm_stride, dr.ld, dr.col0, dr.rows, dr.cols, dr.dst_off, dr.dst_ld, dr.scale, dr.ks};
     const AdamArgs adam = adam_in;
@@ -1489,8 +1500,8 @@ __global__ __launch_bounds__(256) void k_reduce(const RedDescs ds, float* __rest
                      ((reinterpret_cast<uintptr_t>(d.slab) | reinterpret_cast<uintptr_t>(grads) |
                        reinterpret_cast<uintptr_t>(adam.p) | reinterpret_cast<uintptr_t>(adam.m) |
                        reinterpret_cast<uintptr_t>(adam.v)) & 15) == 0;
-    if (vec) reduce_desc<true>(d, KS, arm, grads, per_arm, adam);
-    else reduce_desc<false>(d, KS, arm, grads, per_arm, adam);
+    if (vec) reduce_desc<true>(d, KS, arm, grads, per_arm, adam, bx, nbx);
+    else reduce_desc<false>(d, KS, arm, grads, per_arm, adam, bx, nbx);
 }
 
 __global__ void k_adam(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1703,25 +1714,20 @@ int launch_reduce_grads(const Ctx& c, float* grads, float gscale, const AdamHost
         aa = AdamArgs{ah->p, ah->m, ah->v, (float)(ah->lr / bc1), (float)(1.0 / sqrt(bc2)), ah->b1, ah->b2, ah->eps,
                       ah->wd, ah->lr, ah->decoupled};
     }
-    // two launches: the three large tensors want thousands of workgroups, the 23 small ones a handful
+    // which: 1 = the fc11 tensors (behind dW11, on whatever stream that ran), 2 = fc1.w and the small tensors, 3 = everything
     const int64_t big_elems = (int64_t)max(H, 1) * D;
     const int gx = (int)imin64(2048, cdiv64(big_elems / 4, 256));
-    if (which == 3) {
-        hipLaunchKernelGGL(k_reduce, dim3(gx, nbig, A), dim3(256), 0, c.stream, ds, grads, c.po.per_arm, aa);
-    } else {
-        RedDescs dsb{};
-        int nb = 0;
-        if (which & 2) dsb.d[nb++] = ds.d[0];
-        if (which & 1) { dsb.d[nb++] = ds.d[1]; dsb.d[nb++] = ds.d[2]; }
-        if (nb) hipLaunchKernelGGL(k_reduce, dim3(gx, nb, A), dim3(256), 0, c.stream, dsb, grads, c.po.per_arm, aa);
-    }
-    HIP_LAUNCH_CHECK("k_reduce<big>");
-    if (which & 2) {
-        RedDescs ds2{};
-        for (int i = nbig; i < n; ++i) ds2.d[i - nbig] = ds.d[i];
-        hipLaunchKernelGGL(k_reduce, dim3(16, n - nbig, A), dim3(256), 0, c.stream, ds2, grads, c.po.per_arm, aa);
-        HIP_LAUNCH_CHECK("k_reduce");
-    }
+    RedDescs out{};
+    int no = 0, blocks = 0;
+    auto add = [&](const RedDesc& r, int nb) { out.d[no] = r; out.first[no++] = blocks; blocks += nb; };
+    if (which & 2) add(ds.d[0], gx);
+    if (which & 1) { add(ds.d[1], gx); add(ds.d[2], cdiv(D, 256)); }
+    if (which & 2)
+        for (int i = nbig; i < n; ++i) add(ds.d[i], 16);
+    out.first[no] = blocks;
+    out.n = no;
+    if (no) hipLaunchKernelGGL(k_reduce, dim3(blocks, 1, A), dim3(256), 0, c.stream, out, grads, c.po.per_arm, aa);
+    HIP_LAUNCH_CHECK("k_reduce");
     return 0;
 }
 

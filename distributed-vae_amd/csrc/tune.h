@@ -13,7 +13,9 @@ enum {
     MMVAE_TUNE_PADLDS = 6,         // fc1 forward: extra dynamic LDS (occupancy experiments)
     MMVAE_TUNE_CHAIN_ROWS_FWD = 7, // cells per workgroup of the forward chain launches: 0 = 64 (as the backward chains), > 0 = this
                                    // many (multiple of 8, <= 64; measured: no gain from smaller blocks, api.hip make_layout)
-    // 9 .. 13: removed in round 3 (forcing the general-width kernels at fc_dim 100, fc11 grid shape, fc11 ablations)
+    MMVAE_TUNE_DW11_LDS = 9,       // dW11 beside the backward chain: KB of dynamic LDS added to its workgroups (40 fills the CU: kernels
+                                   // that use any LDS -- the latent backward -- then stay off the CUs dW11 holds)
+    // 10 .. 13: removed in round 3 (forcing the general-width kernels at fc_dim 100, fc11 grid shape, fc11 ablations)
     MMVAE_TUNE_FC11_ZG_OFF = 8,    // fc11 forward, loss and d(d10) as separate launches instead of the fused kernel
     MMVAE_TUNE_ABLATE_L = 14,      // latent kernels: ablations / stamps
     MMVAE_TUNE_LAT_FULLWAVE = 15,  // latent kernels: one wave per cell instead of the half-wave layout

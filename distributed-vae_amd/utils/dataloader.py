@@ -212,7 +212,9 @@ class DeviceLoader:
         if not self.host_order and self.shuffle and dev.type == "cuda" and self.prefetch_order:
             if self._order_stream is None:
                 self._order_stream = torch.cuda.Stream(device=dev)
-            self._order_stream.wait_stream(torch.cuda.current_stream(dev))     # self.index may just have been written
+                self._order_stream.wait_stream(torch.cuda.current_stream(dev))     # self.index may just have been written
+            # (no wait on the current stream after that: the host runs up to an epoch ahead of the device, and a prefetch
+            # ordered behind everything queued so far would run at the very end of the epoch it was meant to overlap)
             with torch.cuda.stream(self._order_stream):
                 nxt = self.index[self._shard(self._base_order(e + 1, dev))]
                 ev = torch.cuda.Event()

@@ -9,10 +9,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-eval --no-roofline --no-bf16"
 # 1. kernel stats of the fp32 train step (default engine: fp32x3), of the same step on the fp32 matrix instruction and of
-#    the bf16 configuration
+#    the bf16 configuration (on bf16 storage, its default, and on the fp32 matrix)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_fp32 -- $BENCH > $OUT/kstats_fp32.json 2> $OUT/kstats_fp32.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_mfma -- $BENCH --gemm-dtype fp32_mfma > $OUT/kstats_mfma.json 2> $OUT/kstats_mfma.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_bf16 -- $BENCH --gemm-dtype bf16 > $OUT/kstats_bf16.json 2> $OUT/kstats_bf16.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_bf16f -- $BENCH --gemm-dtype bf16 --bf16-fp32-storage > $OUT/kstats_bf16f.json 2> $OUT/kstats_bf16f.err
 cp $(find $OUT/kstats_fp32 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
 # one step's kernel timeline (start offset, duration, queue): default launch sequence, and with the encoder chains as one launch each
 python3 $ROOT/tools/step_timeline.py $OUT/kstats_fp32 > $OUT/${R}_step_timeline.txt
@@ -21,6 +22,7 @@ python3 $ROOT/tools/step_timeline.py $OUT/kstats_fused > $OUT/${R}_step_timeline
 cp $(find $OUT/kstats_fused -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_fused_chain_kernel_stats.csv
 cp $(find $OUT/kstats_mfma -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_fp32mfma_kernel_stats.csv
 cp $(find $OUT/kstats_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_bf16_kernel_stats.csv
+cp $(find $OUT/kstats_bf16f -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_bf16_fp32storage_kernel_stats.csv
 # 2. PMC passes (own runs, counters only): HBM traffic, matrix-pipe utilisation
 SHORT="python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-eval --no-roofline --no-bf16"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -40,5 +42,5 @@ json.dump({"sources_sha256": {s: hashlib.sha256(open(s, "rb").read()).hexdigest(
            "command": "tools/collect_profiles.sh $R"}, open("$OUT/${R}_pmc_meta.json", "w"), indent=1)
 PY
 # drop the bulky raw traces from what travels back (keep the summaries)
-rm -rf $OUT/kstats_fp32 $OUT/kstats_mfma $OUT/kstats_bf16 $OUT/kstats_fused $OUT/pmc_* $OUT/pmcb_*
+rm -rf $OUT/kstats_fp32 $OUT/kstats_mfma $OUT/kstats_bf16 $OUT/kstats_bf16f $OUT/kstats_fused $OUT/pmc_* $OUT/pmcb_*
 ls -la $OUT
