@@ -1194,19 +1194,29 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             // x of the two gene sub-tiles of this half (requested before the MFMAs that produce their z)
+            // S16: a lane's four genes of a group are 8 bytes; the two half-waves of a cell (lanes l, l + 32: genes 8 q + 0 .. 3
+            // and 8 q + 4 .. 7) instead request SIXTEEN bytes each -- the lower lane the whole group q = 2 qp, the upper one the
+            // whole group 2 qp + 1 -- and trade halves with v_permlane32_swap where the values are used (and the other way
+            // round for the dZ11 store): half the vector-memory instructions, and every store covers an aligned 16 bytes
+            // (as 8-byte stores dZ11 cost 1.5 x its bytes in partially written lines, PMC)
             float4 xin[2][4];
+            u32x4v xraw[2][2];
 #pragma unroll
-            for (int gl = 0; gl < 2; ++gl)
+            for (int gl = 0; gl < 2; ++gl) {
+                if constexpr (S16) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int gene = j0 + 32 * (2 * half + gl) + 8 * q + 4 * hh;
-                    if constexpr (S16) {
-                        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(xa) + rowoff + min(gene, D - 4));
-                        xin[gl][q] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
-                                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
-                    } else
+                    for (int qp = 0; qp < 2; ++qp) {
+                        const int gene = j0 + 32 * (2 * half + gl) + 8 * (2 * qp + hh);                   // D % 8 == 0
+                        xraw[gl][qp] = *reinterpret_cast<const u32x4v*>(reinterpret_cast<const unsigned short*>(xa) + rowoff + min(gene, D - 8));
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int gene = j0 + 32 * (2 * half + gl) + 8 * q + 4 * hh;
                         xin[gl][q] = *reinterpret_cast<const float4*>(xa + rowoff + min(gene, D - 4));      // D % 4 == 0
+                    }
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);
             f32x16 acc[2] = {zero16(), zero16()};       // z^T[gene sub-tile 2 half + gl][this wave's 32 cells]
 #pragma unroll
@@ -1225,6 +1235,19 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
                 const int gi = 2 * half + gl;
                 // acc[gl][4 q + e]: gene j0 + 32 gi + 8 q + 4 hh + e of cell `cell`
                 float dzr[16];
+                if constexpr (S16) {
+                    // lanes l / l + 32 hold (group 2 qp | group 2 qp + 1) whole: swap(lo, hi) hands every lane its own
+                    // four genes of both groups
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(xraw[gl][qp][0], xraw[gl][qp][2], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(xraw[gl][qp][1], xraw[gl][qp][3], false, false);
+                        xin[gl][2 * qp] = make_float4(__uint_as_float(s0[0] << 16), __uint_as_float(s0[0] & 0xFFFF0000u),
+                                                      __uint_as_float(s1[0] << 16), __uint_as_float(s1[0] & 0xFFFF0000u));
+                        xin[gl][2 * qp + 1] = make_float4(__uint_as_float(s0[1] << 16), __uint_as_float(s0[1] & 0xFFFF0000u),
+                                                          __uint_as_float(s1[1] << 16), __uint_as_float(s1[1] & 0xFFFF0000u));
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int gene = j0 + 32 * gi + 8 * q + 4 * hh;
@@ -1241,11 +1264,22 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
                         se += ok ? er * er : 0.f;
                         mism += (ok && ((xr > 0.1f) != (xv[e] > 0.1f))) ? 1 : 0;
                     }
-                    if constexpr (S16) {
-                        if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dza) + (int64_t)cell * D + gene) =
-                            make_uint2(pack_bf16(dzr[4 * q], dzr[4 * q + 1]), pack_bf16(dzr[4 * q + 2], dzr[4 * q + 3]));
-                    } else if (ok) *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) =
-                        make_float4(dzr[4 * q], dzr[4 * q + 1], dzr[4 * q + 2], dzr[4 * q + 3]);
+                    if constexpr (!S16) {
+                        if (ok) *reinterpret_cast<float4*>(dza + (int64_t)cell * D + gene) =
+                            make_float4(dzr[4 * q], dzr[4 * q + 1], dzr[4 * q + 2], dzr[4 * q + 3]);
+                    }
+                }
+                if constexpr (S16) {
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        const int qe = 2 * qp, qo = 2 * qp + 1;
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pack_bf16(dzr[4 * qe], dzr[4 * qe + 1]), pack_bf16(dzr[4 * qo], dzr[4 * qo + 1]), false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pack_bf16(dzr[4 * qe + 2], dzr[4 * qe + 3]), pack_bf16(dzr[4 * qo + 2], dzr[4 * qo + 3]), false, false);
+                        u32x4v w;
+                        w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
+                        const int gene = j0 + 32 * gi + 8 * (2 * qp + hh);
+                        if (cell < B && gene < D) *reinterpret_cast<u32x4v*>(reinterpret_cast<unsigned short*>(dza) + (int64_t)cell * D + gene) = w;
+                    }
                 }
                 // d(d10) += dZ11 piece (registers) x W11 rows 32 gi .. + 31 (LDS): two K steps of sixteen genes
 #pragma unroll

@@ -42,10 +42,11 @@ def _noise(rank, step):
     return R.draw_noise(_hyper(), CFG["B"], seed=5000 + 100 * rank + step)
 
 
-def _rank(rank, port, out_dir):
+def _rank(rank, port, out_dir, gemm="fp32", storage="1"):
     """Child process: one rank of the two (fresh interpreter, started before it touches the GPU)."""
     sys.path.insert(0, ROOT)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["MMVAE_BF16_STORAGE"] = storage
     import distributed_vae_amd  # noqa: F401
     from distributed_vae_amd import dist as D
     from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
@@ -59,12 +60,14 @@ def _rank(rank, port, out_dir):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     data = _data().to(dev)
+    if gemm == "bf16":
+        data = data.to(torch.bfloat16).float()        # bf16-representable values: storage on / off must agree bit for bit
     loader = DeviceLoader(data, torch.arange(data.shape[0]), c["B"], True, True, seed=546, world_size=WS, rank=rank)
     order = loader.index[loader.epoch_order_device()].cpu().numpy()     # the rows this rank visits in epoch 0
     t = cpl_mixVAE(saving_folder="", device=dev, save_flag=False)
     torch.manual_seed(7 + rank)                  # replicas start different: train() broadcasts rank 0's parameters
     t.init_model(n_categories=c["C"], state_dim=c["S"], input_dim=c["D"], fc_dim=c["H"], lowD_dim=c["L"], x_drop=0.5,
-                 s_drop=0.0, n_arm=c["A"])
+                 s_drop=0.0, n_arm=c["A"], gemm_dtype=gemm)
     if rank == 0:
         t.model.load_state_dict(R.init_state_dict(h, 546))
     t.model.set_explicit_noise([U.noise_to_device(_noise(rank, s), dev) for s in range(c["steps"])])
@@ -72,7 +75,7 @@ def _rank(rank, port, out_dir):
     hist = t.train(loader, None, n_epoch=1, rank=rank, ws=WS, good_enuf_consensus=2.0)
     torch.cuda.synchronize()
     assert not t.model._explicit_noise           # every scheduled draw was consumed by a train step
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=t.model.flat_parameters().detach().cpu().numpy(), order=order,
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), used16=np.array(loader._data16 is not None), params=t.model.flat_parameters().detach().cpu().numpy(), order=order,
              losses=np.array(hist["losses"]), c_dists=np.array(hist["c_dists"]), loss_joints=np.array(hist["loss_joints"]),
              loss_recs=np.array(hist["loss_recs"]), bn=t.model._bn_flat.detach().cpu().numpy(),
              **{"p/" + k: v.detach().cpu().numpy() for k, v in t.model.state_dict().items()})
@@ -135,6 +138,30 @@ def test_two_ranks_on_one_gpu_against_the_virtual_rank_oracle(tmp_path):
             want = sums[5 + a] / c["D"] / nsteps
             assert abs(out[r]["loss_recs"][a][0] - want) <= 2e-4 * abs(want)
     assert out[0]["losses"][0] == out[1]["losses"][0]
+
+
+def test_two_ranks_in_the_bf16_configuration_on_bf16_storage(tmp_path):
+    """The data-parallel trainer in the bf16 configuration: the row-indexed steps read each rank's loader through its bf16 copy
+    (``dp_train_step(rows=(data, rows, data16))``); replicas bit-equal, and the same parameters as with the copy switched off."""
+    import multiprocessing as mp
+    from distributed_vae_amd import dist as D
+    ctx = mp.get_context("spawn")
+    res = {}
+    for storage in ("1", "0"):
+        d = tmp_path / storage
+        d.mkdir()
+        port = D.find_port()
+        procs = [ctx.Process(target=_rank, args=(r, port, str(d), "bf16", storage)) for r in range(WS)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0, p.exitcode
+        res[storage] = [np.load(os.path.join(str(d), f"rank{r}.npz")) for r in range(WS)]
+    assert bool(res["1"][0]["used16"]) and not bool(res["0"][0]["used16"])
+    assert np.array_equal(res["1"][0]["params"], res["1"][1]["params"])
+    assert np.array_equal(res["1"][0]["params"], res["0"][0]["params"])
+    assert np.isfinite(res["1"][0]["params"]).all() and res["1"][0]["losses"][0] == res["0"][0]["losses"][0]
 
 
 def test_train_dp_entry_runs_two_ranks_on_one_gpu(tmp_path):
