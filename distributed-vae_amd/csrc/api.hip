@@ -344,6 +344,13 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     // (which need fc11's partials) follow dW11 on the side stream in do_backward -- no fork between fc11 and the backward
     // pass, and dW11 starts as soon as fc11 has finished.
     const bool t_early = fast && couple_done && c.side() && loss_out && fc11_split_path(c, params, x, xs);
+    if (t_early && c.tune(MMVAE_TUNE_COUPLE_LATE)) {
+        // experiment: no fork here -- do_backward puts the coupling kernel and the T sums in front of dW11, behind ITS fork
+        *couple_done = true;
+        if ((rc = launch_chain_fwd_dec(c, params))) return rc;
+        if (need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;
+        return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
+    }
     if (couple_done && c.side()) {
         if ((rc = fork_to_side(c, EV_LAT))) return rc;
         if ((rc = launch_couple(cs))) return rc;
@@ -387,6 +394,11 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     cs.stream = c.side();
     auto fork_dw11 = [&]() -> int {
         if (int r = fork_to_side(c, EV_FORK)) return r;
+        if (scalars_out && wait_loss && c.tune(MMVAE_TUNE_COUPLE_LATE)) {
+            if (int r = launch_couple(cs)) return r;
+            if (int r = launch_loss_finalize(cs, scalars_out, 1)) return r;
+            if (int r = record_on_side(c, EV_COUPLE)) return r;
+        }
         if (int r = launch_dw_big_fast(cs, x, xs, 2)) return r;
         if (early) {
             // data parallel: fc11.weight / fc11.bias (47 % of the parameters) are final here; reduce their slabs now
@@ -449,9 +461,14 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         return rc;
     }
     if (!small_on_side && (rc = launch_dw_small(c))) return rc;
+    const bool fc11_on_side = (early || side_red) && forked;
+    if (fc11_on_side && c.tune(MMVAE_TUNE_JOIN_LAST)) {   // experiment: nothing the last reduction reads comes from the side stream
+        if ((rc = launch_reduce_grads(c, grads, grad_scale, adam, fast, 2))) return rc;
+        return join_from_side(c, EV_JOIN);
+    }
     if (forked && (rc = join_from_side(c, EV_JOIN))) return rc;
     if (scalars_out && !forked && (rc = launch_loss_finalize(c, scalars_out, 2))) return rc;
-    return launch_reduce_grads(c, grads, grad_scale, adam, fast, ((early || side_red) && forked) ? 2 : 3);
+    return launch_reduce_grads(c, grads, grad_scale, adam, fast, fc11_on_side ? 2 : 3);
 }
 
 }  // namespace mmvae
