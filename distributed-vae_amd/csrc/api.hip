@@ -295,6 +295,11 @@ static int fork_to_side(const Ctx& c, int ev) {
     }
     return 0;
 }
+// the fork's event rode on the kernel in front of it (Ctx::stop_ev, launch_k): only the side stream's wait is left
+static int fork_wait_only(const Ctx& c, int ev) {
+    if (hipStreamWaitEvent(c.side(), c.ev(ev), 0) != hipSuccess) { set_error("stream fork failed"); return MMVAE_E_LAUNCH; }
+    return 0;
+}
 static int record_on_side(const Ctx& c, int ev) {
     if (hipEventRecord(c.ev(ev), c.side()) != hipSuccess) { set_error("event record failed"); return MMVAE_E_LAUNCH; }
     return 0;
@@ -335,7 +340,15 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         for (int layer = 2; layer <= 5; ++layer)
             if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
     }
+    // fork events ride on the kernels in front of the forks (the latent forward here, the fused fc11 kernel below)
+    const bool ride = !c.tune(MMVAE_TUNE_FORK_RECORD);
+    const bool t_early_ = fast && couple_done && c.side() && loss_out && !latent_only && fc11_split_path(c, params, x, xs);
+    c.stop_used = false;
+    if (ride && couple_done && c.side() && !latent_only && !(t_early_ && c.tune(MMVAE_TUNE_COUPLE_LATE))) c.stop_ev = c.ev(EV_LAT);
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt, labels))) return rc;
+    c.stop_ev = nullptr;
+    const bool lat_rode = c.stop_used;
+    c.stop_used = false;
     if (latent_only) return 0;   // evaluation labels need c only: no decoder, no fc11
     Ctx cs = c;
     cs.stream = c.side();
@@ -343,16 +356,25 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     // the coupling kernel's output) run on the side stream from here, beside the decoder chain and fc11; the loss scalars
     // (which need fc11's partials) follow dW11 on the side stream in do_backward -- no fork between fc11 and the backward
     // pass, and dW11 starts as soon as fc11 has finished.
-    const bool t_early = fast && couple_done && c.side() && loss_out && fc11_split_path(c, params, x, xs);
+    const bool t_early = t_early_;
+    // the fused step forks dW11 right behind fc11 (do_backward, MMVAE_TUNE_DW11_AT == 0): EV_FORK rides on the fc11 kernel
+    auto fc11_with_fork = [&]() -> int {
+        if (ride && need_grad && c.tune(MMVAE_TUNE_DW11_AT) == 0) c.stop_ev = c.ev(EV_FORK);
+        const int r = launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
+        c.stop_ev = nullptr;
+        c.fork_on_fc11 = c.stop_used;
+        c.stop_used = false;
+        return r;
+    };
     if (t_early && c.tune(MMVAE_TUNE_COUPLE_LATE)) {
         // experiment: no fork here -- do_backward puts the coupling kernel and the T sums in front of dW11, behind ITS fork
         *couple_done = true;
         if ((rc = launch_chain_fwd_dec(c, params))) return rc;
         if (need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;
-        return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
+        return fc11_with_fork();
     }
     if (couple_done && c.side()) {
-        if ((rc = fork_to_side(c, EV_LAT))) return rc;
+        if ((rc = lat_rode ? fork_wait_only(c, EV_LAT) : fork_to_side(c, EV_LAT))) return rc;
         if ((rc = launch_couple(cs))) return rc;
         *couple_done = true;
         if (t_early) {
@@ -362,7 +384,7 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     }
     if ((rc = launch_chain_fwd_dec(c, params))) return rc;
     if (fast && need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;   // fp32x3: slice planes of [d10 | 1] (fc11, dW11)
-    if (t_early) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
+    if (t_early) return fc11_with_fork();
     if (couple_done && *couple_done && (rc = record_on_side(c, EV_COUPLE))) return rc;
     if (fast) return launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
     return launch_fc11_fused(c, params, x, xs, x_rec, need_grad);
@@ -393,7 +415,8 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
     Ctx cs = c;
     cs.stream = c.side();
     auto fork_dw11 = [&]() -> int {
-        if (int r = fork_to_side(c, EV_FORK)) return r;
+        if (int r = (c.fork_on_fc11 ? fork_wait_only(c, EV_FORK) : fork_to_side(c, EV_FORK))) return r;
+        c.fork_on_fc11 = false;
         if (scalars_out && wait_loss && c.tune(MMVAE_TUNE_COUPLE_LATE)) {
             if (int r = launch_couple(cs)) return r;
             if (int r = launch_loss_finalize(cs, scalars_out, 1)) return r;

@@ -2,6 +2,7 @@
 // (fp32 MFMA tile products out of LDS, wave reductions, Philox) shared by every kernel file.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/mmvae.h"
 #include "tune.h"
@@ -750,7 +751,26 @@ struct Ctx {
     mutable bool dz16 = false;
     int64_t x_ld = 0, x_nrows = 0;
     mutable bool rowmap_ready = false;
+    // Fork events that ride on a kernel (hipExtLaunchKernel's stop event: the dispatch packet's own completion signal) instead
+    // of a hipEventRecord behind it -- a recorded event is a barrier packet of its own, 6 - 7 us of idle main stream at every
+    // fork.  The step's driver names the event the NEXT launch of a launcher that knows launch_k carries (stop_ev); the
+    // launcher consumes it and sets stop_used, and the fork then only makes the side stream wait.
+    mutable hipEvent_t stop_ev = nullptr;
+    mutable bool stop_used = false;
+    mutable bool fork_on_fc11 = false;   // EV_FORK rode on this call's fused fc11 kernel (do_backward's dW11 fork only waits)
 };
+#ifdef __HIPCC__
+template <class K, class... Args>
+inline void launch_k(const Ctx& c, K kernel, dim3 grid, dim3 block, unsigned shm, Args... args) {
+    if (c.stop_ev) {
+        hipExtLaunchKernelGGL(kernel, grid, block, shm, c.stream, nullptr, c.stop_ev, 0, args...);
+        c.stop_ev = nullptr;
+        c.stop_used = true;
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shm, c.stream, args...);
+    }
+}
+#endif
 // events of mmvae_exec.ev by role
 enum { EV_LAT = 0, EV_COUPLE, EV_FC11, EV_FORK, EV_JOIN, EV_DEC, EV_ENC, EV_SPARE /* unused */ };
 

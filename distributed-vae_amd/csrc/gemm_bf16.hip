@@ -1923,7 +1923,7 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
         g.fo_x_arm = xs;
         g.so = SlabOut{c.ws + L.GD10_slab, (int64_t)d.A * d.B * d.H, (int64_t)d.B * d.H, d.H, d.B, d.H};
         g.dbg = reinterpret_cast<long long*>(c.ws + c.lay.loss_scratch + 2048);
-        hipLaunchKernelGGL(k_x3_fc11g, dim3(cdiv(d.B, 128), NS, d.A), dim3(256), 0, c.stream, g);
+        launch_k(c, k_x3_fc11g, dim3(cdiv(d.B, 128), NS, d.A), dim3(256), 0, g);
         HIP_LAUNCH_CHECK("k_x3_fc11g");
         return 0;
     }
@@ -1953,9 +1953,9 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
                 g.fo.x = reinterpret_cast<const float*>(c.x16);
                 g.fo_arm = (int64_t)d.B * d.D / 2;          // (arm stride of dZ11 in floats: B * D two-byte elements)
                 c.dz16 = true;
-                hipLaunchKernelGGL(k_bf16_fc11g<true>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+                launch_k(c, k_bf16_fc11g<true>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, g);
             } else
-                hipLaunchKernelGGL(k_bf16_fc11g<false>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);
+                launch_k(c, k_bf16_fc11g<false>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, g);
             HIP_LAUNCH_CHECK("k_bf16_fc11g");
         } else {
             hipLaunchKernelGGL(k_bf16_fc11, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, c.stream, g);

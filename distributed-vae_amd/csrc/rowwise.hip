@@ -1605,8 +1605,7 @@ int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, flo
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
     const int fullwave = c.tune(MMVAE_TUNE_LAT_FULLWAVE);   // A/B timing
     if (!fullwave && a.dbg_off < 0 && c.d.C <= 32 * LH_CPL && c.d.L <= 32 && 2 * c.d.S <= 32) {
-        hipLaunchKernelGGL(k_lat_fwd_h, dim3(c.lay.nblkl, c.d.A), dim3(64 * LH_NW), shm, c.stream, a, nd, params, c.ws,
-                           bn_running, nbt);
+        launch_k(c, k_lat_fwd_h, dim3(c.lay.nblkl, c.d.A), dim3(64 * LH_NW), shm, a, nd, params, c.ws, bn_running, nbt);
         HIP_LAUNCH_CHECK("k_lat_fwd_h");
         return 0;
     }
