@@ -1359,6 +1359,9 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
 // and no row pitch serves both (60 dwords: transposing reads 2-way conflicts, 19 % of the kernel's busy cycles in the PMC
 // pass; 80: row reads 4-way).  The XOR below makes both conflict-free: rows r .. r + 3 differ in bits 2-3 of the block,
 // rows r, r + 4, r + 8, r + 12 in bits 0-1.
+#ifndef FC11_ABL
+#define FC11_ABL 0     // timing ablations of k_x3_fc11g (diagnostic builds only; results wrong): 1 no x loads, 2 no dZ11 stores,
+#endif                 // 4 no W11 DMA in the loop, 8 no epilogue, 16 / 32 no MFMAs in stage 1 / 2, 64 no mismatch count
 constexpr int FW_ROW = 64;                     // dwords per W11 image row
 constexpr int FW_PLANE = 64 * FW_ROW;          // dwords per slice image of a 64-gene tile
 constexpr int FW_TILE = 3 * FW_PLANE;
@@ -1384,6 +1387,10 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     // this lane's cell: its row of x (through the row map when the batch is not materialised) and of dZ11
     const int rowoff = g.fo.xmap ? (int)g.fo.xmap[min(cell, B - 1)] : min(cell, B - 1) * D;          // B * D < 2^30 (fast-path condition)
     const bool cell_ok = cell < B;
+    int dzoff = min(cell, B - 1) * D * 4;          // byte offset of the lane's row of dZ11 (a register of its own: with the product
+    asm volatile("" : "+v"(dzoff));                // inside the store's select hipcc branched around it, and a branch ends a region)
+    int dlim = cell_ok ? D : 0;                    // genes this lane may touch (a per-lane bound instead of `cell_ok && gene < D`:
+    asm volatile("" : "+v"(dlim));                 // a uniform-looking `cell_ok` became an exec-mask branch around the select)
 
     // LDS-DMA of W11 tile t into buffer (t - t0) % 3: 3 slices x 64 rows x 16 sixteen-byte blocks = 48 wave instructions of
     // 1 KB, twelve per wave; LDS slot (row, block b) takes the plane's block b ^ fw_swz(row) (blocks 14, 15: the planes'
@@ -1444,9 +1451,14 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
     };
     auto request_x = [&](float4 (&X)[4], int j0g, int q) __attribute__((always_inline)) {   // x of gene group q of the piece at j0g
         const int gene = j0g + 8 * q + 4 * hh;                      // D % 4 == 0: a float4 exists entirely or not at all
-        int off = (cell_ok && gene < D) ? (rowoff + gene) * 4 : -16;
+        int off = gene < dlim ? (rowoff + gene) * 4 : -16;
         asm("" : "+v"(off));       // (a plain select: hipcc otherwise branches around two copies of the load, and a branch
                                    // ends the region in which MFMAs and VALU instructions can be interleaved)
+        if constexpr (FC11_ABL & 1) { X[q] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+        if constexpr (FC11_ABL & 128) {   // the same requests in whole 128-byte lines (eight lanes per row; wrong data)
+            const int cc = min(c0 + 32 * wv + (lane >> 3) + 8 * q, B - 1), gg = min(j0g + 4 * (lane & 7), D - 4);
+            off = (cc * D + gg) * 4;
+        }
         X[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     };
     // six slice products of one K step
@@ -1492,18 +1504,24 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
             }
     };
     float4 xa_[4], xb_[4];
-    f32x16 acc_a = zero16(), acc_b = zero16();
+    f32x16 acc_a = zero16();
+    // The d10 slices are complete HERE, on every path into the main loop (they live in the accumulator half of the register
+    // file from now on: only MFMAs read them).  With this wait inside the `if` below, the path around it -- a block without
+    // tiles, which never runs the loop, but hipcc cannot know -- carried "d10 still in flight" to the loop header, and the
+    // wait-count pass put vmcnt(24) / (22) / (7) in front of the first MFMAs of EVERY piece: "all but the seven youngest
+    // vector-memory operations have completed" right behind the four x requests, i.e. a wait for the previous piece's stores
+    // and for the W11 tile requested half a tile earlier -- 50 us of the kernel's 155 (no-load and no-store ablations).
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+#pragma unroll
+    for (int s7 = 0; s7 < 7; ++s7)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+a"(dfr[s7][pl]));
     if (npieces > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) request_x(xa_, t0 * 64, q);
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): both first tiles and x
-        // (hipcc's wait-count pass does not see that wait: without a use of the registers HERE it keeps "d10 / x may still
-        // be in flight" alive around the loop's back edge and waits for vmcnt(0) -- i.e. for the x prefetch issued a moment
-        // earlier -- in front of the first MFMA of every tile)
-#pragma unroll
-        for (int s7 = 0; s7 < 7; ++s7)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) asm volatile("" : "+v"(dfr[s7][pl]));
+        // (hipcc's wait-count pass does not see that wait: without a use of the registers HERE it keeps "x may still be in
+        // flight" alive around the loop's back edge)
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(xa_[q].x), "+v"(xa_[q].y), "+v"(xa_[q].z), "+v"(xa_[q].w));
         __syncthreads();
@@ -1528,10 +1546,16 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
 #define X3_ST(var)
 #endif
     // piece p: epilogue reads `acc` / `xin`, the z product of piece p + 1 goes to `accn`, its x to `xnx`
-    auto piece = [&](int p, f32x16& acc, f32x16& accn, float4 (&xin)[4], float4 (&xnx)[4], int dma_tile) __attribute__((always_inline)) {
+    // (ONE z accumulator: the piece copies its z out of the accumulator registers at its head -- the epilogue's VALU
+    // instructions cannot read those anyway -- and the next piece's product goes into the same registers.  With two
+    // accumulators swapped from piece to piece hipcc parked d(d10)'s first tile in VGPRs around every z product: 32 more
+    // accumulator copies per tile.)
+    auto piece = [&](int p, f32x16& accn, float4 (&xin)[4], float4 (&xnx)[4], int dma_tile) __attribute__((always_inline)) {
         const int j0g = t0 * 64 + 32 * p;
         const unsigned* Wn = w_rows(p + 1 < npieces ? p + 1 : p);
         const unsigned short* Wt16 = reinterpret_cast<const unsigned short*>(w_rows(p));
+        f32x16 acc = accn;
+        asm volatile("" : "+v"(acc));
         accn = zero16();
         unsigned au[2][3][4];          // dZ11 slices: K step c (sixteen genes in register order), slice, four dwords
         float dzq[4];
@@ -1544,6 +1568,10 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
         // unit (lane-mask population counts), outside the VALU's dependency chains.
         auto chunk = [&](int ch) __attribute__((always_inline)) {
             const int q = ch >> 1;
+            if constexpr (FC11_ABL & 8) {
+                if (ch & 1) for (int pl = 0; pl < 3; ++pl) { au[q >> 1][pl][2 * (q & 1)] = 0x3f803f80u; au[q >> 1][pl][2 * (q & 1) + 1] = 0x3f803f80u; }
+                return;
+            }
             if ((ch & 1) == 0) {
                 const int gene = j0g + 8 * q + 4 * hh;
                 const float xv[4] = {xin[q].x, xin[q].y, xin[q].z, xin[q].w};
@@ -1557,12 +1585,18 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
                     seq[q] = __builtin_fmaf(er, er, seq[q]);
                     const float d_ = g.fo.coef * er;
                     dzq[e] = a_ > 0.f ? d_ : 0.f;
+                    if constexpr (!(FC11_ABL & 64))
                     mism += __builtin_popcountll(__builtin_amdgcn_ballot_w64(xr > 0.1f) ^ __builtin_amdgcn_ballot_w64(xv[e] > 0.1f));
                 }
                 // (always issued -- the counted wait at the end of a tile relies on it; what must not be written gets an offset
                 // beyond the buffer's range, which the hardware drops)
-                int soff = (cell_ok && gene < D) ? (cell * D + gene) * 4 : -16;
+                int soff = gene < dlim ? dzoff + gene * 4 : -16;
                 asm("" : "+v"(soff));
+                if constexpr (FC11_ABL & 256) {
+                    const int cc = min(c0 + 32 * wv + (lane >> 3) + 8 * q, B - 1), gg = min(j0g + 4 * (lane & 7), D - 4);
+                    soff = (cc * D + gg) * 4;
+                }
+                if constexpr (!(FC11_ABL & 2))
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, make_float4(dzq[0], dzq[1], dzq[2], dzq[3])), rz, soff, 0, 0);
             } else {
                 unsigned w0[3], w1[3];
@@ -1582,7 +1616,8 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < 7) z_frags(Wn, s + 2);
             if (s == 5) d_frags(Wt16, 0);           // (the first region of stage 2: its slot of the ring is free)
-            mfma6(accn, an[s % 3], s);
+            if constexpr (!(FC11_ABL & 16)) mfma6(accn, an[s % 3], s);
+            else { asm volatile("" :: "v"(an[s % 3][0]), "v"(an[s % 3][1]), "v"(an[s % 3][2])); }
             if (s < 5) chunk(s);
         }
         asm volatile("" : "+s"(mism));
@@ -1592,7 +1627,7 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
         asm volatile("" :: "v"(accn), "v"(au[0][0][0]), "v"(au[1][2][3]));
         X3_ST(t_s1)
 #endif
-        if (dma_tile >= 0) dma(dma_tile);
+        if (!(FC11_ABL & 4) && dma_tile >= 0) dma(dma_tile);
 #ifdef X3_STAMPS
         X3_ST(t_dma)
 #endif
@@ -1619,6 +1654,11 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
             }
             // product-major: consecutive MFMAs go to the two h tiles of the region (independent accumulators)
             const int n0 = 2 * (r & 1);
+            if constexpr (FC11_ABL & 32) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(wq[r & 1][j][0]), "v"(wq[r & 1][j][1]), "v"(wq[r & 1][j][2]), "v"(af[0]), "v"(af[1]), "v"(af[2]));
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) gd[n0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], wq[r & 1][j][0], gd[n0 + j], 0, 0, 0);
 #pragma unroll
@@ -1642,8 +1682,8 @@ __global__ __launch_bounds__(256, 1) void k_x3_fc11g(const GemmArgs g_in) {
         const int p = 2 * (t - t0);
         // the first piece of tile t also requests tile t + 2 (into the buffer of tile t - 1, which every wave left at the
         // barrier below; tiles t0 .. t0 + 2 were requested by the prologue)
-        piece(p, acc_a, acc_b, xa_, xb_, (t > t0 && t + 2 < t1) ? t + 2 : -1);
-        piece(p + 1, acc_b, acc_a, xb_, xa_, -1);
+        piece(p, acc_a, xa_, xb_, (t > t0 && t + 2 < t1) ? t + 2 : -1);
+        piece(p + 1, acc_a, xb_, xa_, -1);
         // ---- end of a tile (two pieces): tile t + 2 is needed next (the z product runs one piece ahead).  It was requested
         // in front of eight younger vector-memory instructions (the second piece's 4 loads + 4 stores); vector-memory
         // instructions retire in order, so "at most four outstanding" (those stores) guarantees this wave's share of it has
