@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmvae_hip.so")
 SOURCES = ["api.hip", "gemm_big.hip", "gemm_fast.hip", "gemm_bf16.hip", "chain.hip", "rowwise.hip", "consensus.hip", "augment.hip", "datapath.hip", "dp.hip"]
-HEADERS = ["common.hpp", "tune.h", os.path.join("..", "..", "include", "mmvae.h")]
+HEADERS = ["common.hpp", "couple.hpp", "tune.h", os.path.join("..", "..", "include", "mmvae.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file); without it
 # hipcc parks loop-carried accumulators in AGPRs and copies all 64 of them out and back every K tile.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]

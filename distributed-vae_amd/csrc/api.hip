@@ -344,7 +344,10 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     const bool ride = !c.tune(MMVAE_TUNE_FORK_RECORD);
     const bool t_early_ = fast && couple_done && c.side() && loss_out && !latent_only && fc11_split_path(c, params, x, xs);
     c.stop_used = false;
-    if (ride && couple_done && c.side() && !latent_only && !(t_early_ && c.tune(MMVAE_TUNE_COUPLE_LATE))) c.stop_ev = c.ev(EV_LAT);
+    // the coupling terms as a role of the decoder chain's launch: no fork behind the latent forward at all
+    const bool couple_role = t_early_ && !c.tune(MMVAE_TUNE_COUPLE_LATE) && dec_couple_ok(c);
+    c.couple_in_dec = false;
+    if (ride && couple_done && c.side() && !latent_only && !couple_role && !(t_early_ && c.tune(MMVAE_TUNE_COUPLE_LATE))) c.stop_ev = c.ev(EV_LAT);
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt, labels))) return rc;
     c.stop_ev = nullptr;
     const bool lat_rode = c.stop_used;
@@ -370,6 +373,13 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
         // experiment: no fork here -- do_backward puts the coupling kernel and the T sums in front of dW11, behind ITS fork
         *couple_done = true;
         if ((rc = launch_chain_fwd_dec(c, params))) return rc;
+        if (need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;
+        return fc11_with_fork();
+    }
+    if (couple_role) {
+        *couple_done = true;
+        c.couple_in_dec = true;
+        if ((rc = launch_chain_fwd_dec(c, params, true))) return rc;
         if (need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;
         return fc11_with_fork();
     }
@@ -462,7 +472,7 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         if ((rc = launch_dw_small(cs, 1))) return rc;
     }
     // T (sum of G log c, from the loss finalisation) is first needed here
-    if (wait_loss && (rc = join_from_side(c, EV_COUPLE))) return rc;
+    if (wait_loss && !c.couple_in_dec && (rc = join_from_side(c, EV_COUPLE))) return rc;
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
     if (use_side && dw11_at == 2 && (rc = fork_dw11())) return rc;   // (3: not forked -- dW11 behind dW1 on the main stream)
     if (enc_bwd_fused_ok(c)) {

@@ -13,6 +13,7 @@
 // weights -- is shared by sixteen waves instead of four, and 128-row workgroups emit a quarter of the partials
 // the next launch has to recombine (40 instead of 157 at B = 5000).
 #include "common.hpp"
+#include "couple.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -61,6 +62,7 @@ struct ChainFwdArgs {
     int64_t wpl_off;        // fp32x3 form (k_chain_fwd<true>): workspace offset of Layout::pl_small
     int B, ld, wrows;
     int rows;               // cells per workgroup (<= CHAIN_ROWS, multiple of 8): Layout::chain_rows_fwd
+    int nblk;               // row blocks per arm (the launch's grid.x, unless the launch has other roles beside the chain)
     int64_t per_arm;
     int ablate;   // timing experiments only (MMVAE_ABLATE_C)
     int64_t dbg_off;   // >= 0: workspace offset of a diagnostic stamp-counter block (bit 3 of ablate)
@@ -192,9 +194,9 @@ __device__ __forceinline__ void mma_nt_x3(f32x16& acc, const unsigned* Xp, int x
 }
 
 template <bool X3>
-__global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
-                                                   float* __restrict__ ws, float* __restrict__ bn_running,
-                                                   int64_t* __restrict__ nbt) {
+__device__ __forceinline__ void chain_fwd_body(const ChainFwdArgs& a_in, const float* __restrict__ params,
+                                               float* __restrict__ ws, float* __restrict__ bn_running,
+                                               int64_t* __restrict__ nbt) {
     // Copy the argument block into registers once.  Read in place, the kernarg segment may alias the
     // stores below as far as hipcc knows: it then re-loads fields after every store and waits vmcnt(0)
     // before each re-load, which serialises the epilogue's stores (measured: 47 % of the kernel).
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
                 if (a.acc_out_off >= 0) {
                     acc_add_stats(reinterpret_cast<long long*>(ws + a.acc_out_off) + (int64_t)arm * ACC_SET_I64, col, n, mu, M2);
                 } else {
-                    float* p = ws + a.stats_part_off + (((int64_t)arm * gridDim.x + blk) * 2) * N;
+                    float* p = ws + a.stats_part_off + (((int64_t)arm * a.nblk + blk) * 2) * N;
                     p[col] = mu;
                     p[N + col] = M2;
                 }
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         const int N = a.L[a.nlayers - 1].N;
         const int64_t plane = (int64_t)a.planes_rows * 128;
         unsigned short* pl = reinterpret_cast<unsigned short*>(ws + a.planes_off) + (int64_t)arm * 3 * plane;
-        const int rows_here = blk == (int)gridDim.x - 1 ? a.planes_rows - b0 : a.rows;
+        const int rows_here = blk == a.nblk - 1 ? a.planes_rows - b0 : a.rows;
         for (int i = tid; i < rows_here * 64; i += CH_NT) {
             const int r = i >> 6, c = (i & 63) * 2;
             unsigned w[3] = {0u, 0u, 0u};
@@ -493,6 +495,50 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, co
         for (int i = 0; i < 5; ++i) atomicAdd(dbg + i, ph[i]);
         atomicAdd(dbg + 5, 1ull);
     }
+}
+template <bool X3>
+__global__ __launch_bounds__(CH_NT) void k_chain_fwd(const ChainFwdArgs a_in, const float* __restrict__ params,
+                                                   float* __restrict__ ws, float* __restrict__ bn_running,
+                                                   int64_t* __restrict__ nbt) {
+    chain_fwd_body<X3>(a_in, params, ws, bn_running, nbt);
+}
+
+// The decoder chain of the fused train step with the coupling terms as a second ROLE of the same launch (fp32x3 form only):
+// grid (max(row blocks, ceil(coupling blocks / 2)), A + 1); blockIdx.y < A: the chain's row block blockIdx.x of that arm;
+// blockIdx.y == A: the two 256-thread halves of the workgroup take coupling row blocks 2 blockIdx.x and 2 blockIdx.x + 1
+// (couple.hpp).  The chain's 158 workgroups (A = 2) leave 98 CUs idle; the coupling's 79 run there, and the T sums are
+// complete three launches before the latent backward reads them -- no fork to the side stream behind the latent forward, no
+// join in front of the latent backward, no fill of the T set (the step's head launch zeroes it with the forward sets).
+struct CoupleRoleArgs {
+    int nchain, ncouple;         // row blocks of the chain / 32-cell blocks of the coupling
+    int B, C;
+    float eps, lam;
+    int64_t cc_off, csmp_off, c_mean_off, c_iv_off, couple_part_off, c_acc_off, t_acc_off;   // workspace offsets (floats)
+};
+template <int AT>
+__device__ __forceinline__ void couple_role(const CoupleRoleArgs& cr_in, float* __restrict__ ws) {
+    // (not inlined: the chain's code keeps the registers and the schedule it has as a kernel of its own)
+    const CoupleRoleArgs cr = cr_in;
+    if (2 * (int)blockIdx.x >= cr.ncouple) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int half = threadIdx.x >> 8, t256 = threadIdx.x & 255;
+    constexpr int HALF = 4 * AT * CPL * 64 + AT * CPL * 64 + 8;      // shT, sh_iv, sh_red
+    float* sh = smem + half * HALF;
+    const int blk = 2 * blockIdx.x + half;
+    couple_body<AT>(blk, blk < cr.ncouple, t256, cr.B, cr.C, cr.eps, cr.lam, ws + cr.cc_off, ws + cr.csmp_off, nullptr, 0,
+                    reinterpret_cast<const long long*>(ws + cr.c_acc_off), ws + cr.c_mean_off, ws + cr.c_iv_off,
+                    ws + cr.couple_part_off, nullptr, reinterpret_cast<long long*>(ws + cr.t_acc_off), sh,
+                    sh + 4 * AT * CPL * 64 + AT * CPL * 64, sh + 4 * AT * CPL * 64, nullptr);
+}
+template <int AT>
+__global__ __launch_bounds__(CH_NT) void k_chain_fwd_couple(const ChainFwdArgs a_in, const CoupleRoleArgs cr_in,
+                                                          const float* __restrict__ params, float* __restrict__ ws) {
+    if ((int)blockIdx.y == AT) {
+        couple_role<AT>(cr_in, ws);
+        return;
+    }
+    if ((int)blockIdx.x >= cr_in.nchain) return;
+    chain_fwd_body<true>(a_in, params, ws, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1578,6 +1624,7 @@ static int x3_ld(int maxdim) { return rup(maxdim, 16) / 2 + 4; }
 static size_t chain_smem_x3(int ld, int wrows) { return (size_t)(3 * CHAIN_ROWS * ld + 3 * wrows * ld + 256) * sizeof(float); }
 static int launch_fwd(const Ctx& c, ChainFwdArgs& a, int maxdim, const float* params, float* bn_running, int64_t* nbt, const char* what) {
     a.rows = c.lay.chain_rows_fwd;
+    a.nblk = c.lay.nblkf;
     const dim3 grid(c.lay.nblkf, c.d.A);
     if (c.small_planes && chain_x3_ok(c) && maxdim <= 128) {
         a.ld = x3_ld(maxdim);
@@ -1726,7 +1773,7 @@ int launch_chain_fwd_enc_eval(const Ctx& c, const float* params) {
     return launch_fwd(c, a, max(d.H, d.L), params, nullptr, nullptr, "k_chain_fwd<enc eval>");
 }
 
-int launch_chain_fwd_dec(const Ctx& c, const float* params) {
+int launch_chain_fwd_dec(const Ctx& c, const float* params, bool with_couple) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
     ChainFwdArgs a{};
@@ -1751,7 +1798,47 @@ int launch_chain_fwd_dec(const Ctx& c, const float* params) {
     a.ablate = c.tune(MMVAE_TUNE_ABLATE_C);
     a.dbg_off = L.loss_scratch + 2048;
     for (int i = 0; i < 5; ++i) a.L[i].pl_slot = 4 + i;
+    if (with_couple) {
+        // the coupling terms as a second role of this launch (k_chain_fwd_couple): fp32x3 form, accumulator sets, 2 .. 5 arms
+        const int maxdim = max(max(d.H, d.L), d.C + d.S);
+        a.rows = L.chain_rows_fwd;
+        a.nblk = L.nblkf;
+        a.ld = x3_ld(maxdim);
+        a.wrows = 128;
+        a.wpl_off = L.pl_small;
+        CoupleRoleArgs cr{};
+        cr.nchain = L.nblkf; cr.ncouple = L.nblk32; cr.B = d.B; cr.C = d.C; cr.eps = c.h.eps; cr.lam = c.h.lam;
+        cr.cc_off = L.CC; cr.csmp_off = L.CSMP; cr.c_mean_off = L.c_mean; cr.c_iv_off = L.c_iv; cr.couple_part_off = L.couple_part;
+        cr.c_acc_off = acc_set_off(L, d.A, ACC_C); cr.t_acc_off = acc_set_off(L, d.A, ACC_T);
+        if (c.tune(MMVAE_TUNE_COUPLE_SIDE) == 2) cr.ncouple = 0;   // timing experiment: the role's workgroups exit at once (results wrong)
+        const dim3 grid(max(L.nblkf, cdiv(L.nblk32, 2)), d.A + 1);
+        const size_t shm_c = (size_t)2 * (5 * d.A * CPL * 64 + 8) * sizeof(float);
+        const size_t shm = max(chain_smem_x3(a.ld, a.wrows), shm_c);
+#define MMVAE_DEC_COUPLE(AT) hipLaunchKernelGGL(k_chain_fwd_couple<AT>, grid, dim3(CH_NT), shm, c.stream, a, cr, params, c.ws)
+        switch (d.A) {
+            case 2: MMVAE_DEC_COUPLE(2); break;
+            case 3: MMVAE_DEC_COUPLE(3); break;
+            case 4: MMVAE_DEC_COUPLE(4); break;
+            default: MMVAE_DEC_COUPLE(5); break;
+        }
+#undef MMVAE_DEC_COUPLE
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) { set_error("k_chain_fwd_couple: %s", hipGetErrorString(e_)); return MMVAE_E_LAUNCH; }
+        return 0;
+    }
     return launch_fwd(c, a, max(max(d.H, d.L), d.C + d.S), params, nullptr, nullptr, "k_chain_fwd<dec>");
+}
+// the fused train step may run the coupling terms inside the decoder chain's launch (see k_chain_fwd_couple).  Measured
+// (A/B/A/B per arm count on one box, ms per step, role against side stream): A = 2 0.674 / 0.672, A = 3 0.901 / 0.896, A = 5
+// 1.479 / 1.489 -- the two bubbles it removes from the main stream show in a rocprofv3 trace (5 - 6 us each) but not in the
+// un-profiled step at two and three arms, where the combined launch is 3 us longer than the chain's own (its grid has a third
+// row of workgroups); at five arms the chain's 395 workgroups already run in two rounds and the role fills the second.  So: the
+// role from four arms up, the side stream below (MMVAE_TUNE_COUPLE_SIDE: 1 side stream always, 3 role always, 2 the role's
+// launch with its workgroups exiting at once -- a timing experiment, results wrong).
+bool dec_couple_ok(const Ctx& c) {
+    const mmvae_dims& d = c.d;
+    return c.h.training && c.use_acc() && c.small_planes && chain_x3_ok(c) && max(max(d.H, d.L), d.C + d.S) <= 128 && d.A >= 2 &&
+           d.A <= 5 && d.C <= CPL * 64 && c.tune(MMVAE_TUNE_COUPLE_SIDE) != 1 && (d.A >= 4 || c.tune(MMVAE_TUNE_COUPLE_SIDE) >= 2);
 }
 
 int launch_chain_bwd_dec(const Ctx& c, const float* params, int nslab) {

@@ -739,7 +739,9 @@ struct Ctx {
     // set by launch_x3_planes when this call has written the small-layer weight planes (Layout::pl_small): the chain
     // launchers then take the fp32x3 form of their kernels
     mutable bool small_planes = false;
-    int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, ACC_T) - lay.fc11_part; }
+    // (through the coupling's T set: the fused step's coupling runs inside the decoder chain's launch and finds it zeroed; the
+    // coupling's own launcher zeroes it again, it may run more than once per forward pass)
+    int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, ACC_BWD) - lay.fc11_part; }
     int64_t bwd_zero_floats() const { return lay.sync_bwd + (int64_t)d.A * lay.sync_arm_words - acc_set_off(lay, d.A, ACC_BWD); }
     mutable bool bwd_zeroed = false;   // set by the launcher of the first kernel of a backward pass (it zeroes that range)
     // mmvae_train_step_rows: the batch is rows x_rows[0 .. B) (device, int64) of the resident matrix [x_nrows][x_ld] that the
@@ -757,6 +759,7 @@ struct Ctx {
     // launcher consumes it and sets stop_used, and the fork then only makes the side stream wait.
     mutable hipEvent_t stop_ev = nullptr;
     mutable bool stop_used = false;
+    mutable bool couple_in_dec = false;  // the coupling ran as a role of the decoder chain's launch: main stream, nothing to wait for
     mutable bool fork_on_fc11 = false;   // EV_FORK rode on this call's fused fc11 kernel (do_backward's dW11 fork only waits)
 };
 #ifdef __HIPCC__
@@ -790,7 +793,8 @@ bool enc_bwd_fused_ok(const Ctx& c);
 int launch_chain_bwd_enc_fused(const Ctx& c, const float* params);
 int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
                    int32_t* labels = nullptr /*eval: argmax of c per cell and arm*/);
-int launch_chain_fwd_dec(const Ctx& c, const float* params);
+int launch_chain_fwd_dec(const Ctx& c, const float* params, bool with_couple = false /*the coupling terms as a role of the launch*/);
+bool dec_couple_ok(const Ctx& c);
 int launch_fc11_fused(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad);
 int launch_couple(const Ctx& c);
 int launch_loss_finalize(const Ctx& c, float* loss_out, int mode = 0 /*1: the T sums only, 2: the scalars only*/);

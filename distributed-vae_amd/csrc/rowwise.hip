@@ -13,6 +13,7 @@
 //
 // Wave reductions only (no MFMA): these tensors are [B, <=128] and HBM/L2 resident.
 #include "common.hpp"
+#include "couple.hpp"
 #include <type_traits>
 #include <math.h>
 #include <stdlib.h>
@@ -28,7 +29,6 @@ namespace mmvae {
         }                                                                             \
     } while (0)
 
-constexpr int CPL = 2;   // categories per lane: C <= 128
 
 NoiseDev make_noise_dev(const mmvae_noise* nz, const mmvae_hyper& h) {
     NoiseDev n{};
@@ -777,119 +777,12 @@ __global__ __launch_bounds__(256) void k_couple(int B, int C, float eps, float l
                                                 const long long* __restrict__ c_acc, float* __restrict__ c_mean,
                                                 float* __restrict__ c_iv, float* __restrict__ couple_part,
                                                 float* __restrict__ T_part, long long* __restrict__ t_acc) {
-    constexpr int A = AT;
-    __shared__ __attribute__((aligned(16))) float shT[4][AT][CPL * 64];
-    __shared__ float sh_red[4][2], sh_iv[AT][CPL * 64];
+    // (the arithmetic lives in couple.hpp: the decoder chain's launch of the fused train step runs it as one of its roles)
+    __shared__ __attribute__((aligned(16))) float shT[4 * AT * CPL * 64];
+    __shared__ float sh_red[8], sh_iv[AT * CPL * 64];
     __shared__ __attribute__((aligned(16))) float sh_scr[3 * PART_MAXG * CPL * 64];
-    const int blk = blockIdx.x, b0 = blk * 32;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // inv_var of every arm's c over the batch (nn_model.py:558-560): mean and unbiased variance; row block 0 keeps them
-    // for the backward
-    if (c_acc) {
-        if ((int)threadIdx.x < C) {
-#pragma unroll
-            for (int aa = 0; aa < A; ++aa) {
-                float mean, m2;
-                acc_mean_m2(c_acc + (int64_t)aa * ACC_SET_I64, threadIdx.x, B, mean, m2);
-                const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
-                sh_iv[aa][threadIdx.x] = ivv;
-                if (blk == 0) { c_mean[aa * C + threadIdx.x] = mean; c_iv[aa * C + threadIdx.x] = ivv; }
-            }
-        }
-        lds_barrier();
-    } else {
-        for (int aa = 0; aa < A; ++aa) {
-            float mean, m2;
-            stats_from_partials<256>(c_part + (int64_t)aa * c_n * 2 * C, c_n, B, LAT_ROWS, C, sh_scr, mean, m2);
-            if ((int)threadIdx.x < C) {
-                const float ivv = sqrtf(1.0f / (m2 / (float)(B - 1) + eps));
-                sh_iv[aa][threadIdx.x] = ivv;
-                if (blk == 0) { c_mean[aa * C + threadIdx.x] = mean; c_iv[aa * C + threadIdx.x] = ivv; }
-            }
-            lds_barrier();
-        }
-    }
-    float iv[AT][CPL], Tacc[AT][CPL];
-    bool vc[CPL];
-    int colc[CPL];
-#pragma unroll
-    for (int t = 0; t < CPL; ++t) {
-        const int col = lane + 64 * t;
-        vc[t] = col < C;
-        colc[t] = min(col, C - 1);
-#pragma unroll
-        for (int aa = 0; aa < A; ++aa) { iv[aa][t] = vc[t] ? sh_iv[aa][col] : 0.f; Tacc[aa][t] = 0.f; }
-    }
-    float dist = 0.f, l2 = 0.f;
-    const float coefG = 2.f * lam / (float)B;
-    // a wave owns rows wv, wv + 4, ..., wv + 28 of the block; RB rows at a time, every load of the batch requested (clamped
-    // addresses, no branches) before the first logarithm
-    constexpr int RB = AT <= 2 ? 4 : (AT <= 4 ? 2 : 1);
-    for (int i0 = 0; i0 < 8; i0 += RB) {
-        float ccv[RB][AT][CPL], csv[RB][AT][CPL];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int bc = min(b0 + wv + 4 * (i0 + rb), B - 1);
-#pragma unroll
-            for (int aa = 0; aa < A; ++aa)
-#pragma unroll
-                for (int t = 0; t < CPL; ++t) {
-                    const int64_t o = ((int64_t)aa * B + bc) * C + colc[t];
-                    ccv[rb][aa][t] = CCp[o];
-                    csv[rb][aa][t] = CSMPp[o];
-                }
-        }
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const bool rok = b0 + wv + 4 * (i0 + rb) < B;     // wave-uniform
-            float u[AT][CPL], lc[AT][CPL], us[CPL];
-#pragma unroll
-            for (int t = 0; t < CPL; ++t) {
-                us[t] = 0.f;
-#pragma unroll
-                for (int aa = 0; aa < A; ++aa) {
-                    lc[aa][t] = (vc[t] && rok) ? logf(ccv[rb][aa][t] + eps) : 0.f;
-                    u[aa][t] = lc[aa][t] * iv[aa][t];
-                    us[t] += u[aa][t];
-                }
-            }
-#pragma unroll
-            for (int aa = 0; aa < A; ++aa) {
-#pragma unroll
-                for (int t = 0; t < CPL; ++t) {
-                    const float G = coefG * ((float)A * u[aa][t] - us[t]);
-                    Tacc[aa][t] += G * lc[aa][t];
-                }
-#pragma unroll
-                for (int bb = aa + 1; bb < A; ++bb)
-#pragma unroll
-                    for (int t = 0; t < CPL; ++t) {
-                        const float du = u[aa][t] - u[bb][t];
-                        const float dc = (vc[t] && rok) ? csv[rb][aa][t] - csv[rb][bb][t] : 0.f;
-                        dist += du * du;
-                        l2 += dc * dc;
-                    }
-            }
-        }
-    }
-    dist = wave_sum(dist);
-    l2 = wave_sum(l2);
-#pragma unroll
-    for (int aa = 0; aa < A; ++aa)
-#pragma unroll
-        for (int t = 0; t < CPL; ++t) shT[wv][aa][lane + 64 * t] = Tacc[aa][t];
-    if (lane == 0) { sh_red[wv][0] = dist; sh_red[wv][1] = l2; }
-    lds_barrier();
-    for (int i = threadIdx.x; i < A * C; i += 256) {
-        const int aa = i / C, col = i % C;
-        const float tsum = shT[0][aa][col] + shT[1][aa][col] + shT[2][aa][col] + shT[3][aa][col];
-        if (t_acc) acc_add(t_acc + (int64_t)aa * ACC_SET_I64, 0, col, (double)tsum);
-        else T_part[((int64_t)blk * A + aa) * C + col] = tsum;
-    }
-    if (threadIdx.x == 0) {
-        couple_part[blk * 2] = sh_red[0][0] + sh_red[1][0] + sh_red[2][0] + sh_red[3][0];
-        couple_part[blk * 2 + 1] = sh_red[0][1] + sh_red[1][1] + sh_red[2][1] + sh_red[3][1];
-    }
+    couple_body<AT>(blockIdx.x, true, threadIdx.x, B, C, eps, lam, CCp, CSMPp, c_part, c_n, c_acc, c_mean, c_iv, couple_part, T_part,
+                    t_acc, shT, sh_red, sh_iv, sh_scr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -19,7 +19,9 @@ enum {
                                    // instead of beside the decoder chain
     MMVAE_TUNE_JOIN_LAST = 11,     // fused step: the side stream is joined BEHIND the last reduction (which needs nothing from it)
     MMVAE_TUNE_FORK_RECORD = 12,   // fork events through hipEventRecord behind the kernel instead of riding on it (launch_k, common.hpp)
-    // 13: removed in round 3 (forcing the general-width kernels at fc_dim 100, fc11 grid shape, fc11 ablations)
+    MMVAE_TUNE_COUPLE_SIDE = 13,   // fused step, where the coupling terms run: 0 = as a role of the decoder chain's launch from four arms up
+                                   // and on the side stream below (chain.hip dec_couple_ok), 1 = side stream always (fork behind the
+                                   // latent forward, join in front of the latent backward), 3 = role always, 2 = timing experiment in round 3 (forcing the general-width kernels at fc_dim 100, fc11 grid shape, fc11 ablations)
     MMVAE_TUNE_FC11_ZG_OFF = 8,    // fc11 forward, loss and d(d10) as separate launches instead of the fused kernel
     MMVAE_TUNE_ABLATE_L = 14,      // latent kernels: ablations / stamps
     MMVAE_TUNE_LAT_FULLWAVE = 15,  // latent kernels: one wave per cell instead of the half-wave layout

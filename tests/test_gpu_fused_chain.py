@@ -17,9 +17,10 @@ from oracle import restatement as R
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TUNE_FUSED = 23        # include/mmvae.h MMVAE_TUNE_FUSED_CHAIN: 0 one launch per layer (default), 1 one launch per chain
+TUNE_COUPLE = 13       # csrc/tune.h MMVAE_TUNE_COUPLE_SIDE: 1 coupling kernel on the side stream, 3 as a role of the decoder chain's launch
 
 
-def _step(h, B, seed, fused_switch, steps=2):
+def _step(h, B, seed, fused_switch, steps=2, tune=None):
     """`steps` fused train steps (Adam included) on explicit noise; returns what must not depend on the chain's form."""
     from distributed_vae_amd import _native as N
     from distributed_vae_amd.cpl_mixvae import FusedAdam
@@ -30,6 +31,8 @@ def _step(h, B, seed, fused_switch, steps=2):
     m.train()
     ex = N.exec_from_env(N.gemm_mode("fp32") & 0xFF)
     ex.tune[TUNE_FUSED] = fused_switch
+    for idx, val in (tune or {}).items():
+        ex.tune[idx] = val
     m._exec = ex
     opt = FusedAdam(m, lr=1e-3)
     xs = x.to(DEV).expand(h.n_arm, -1, -1)
@@ -85,3 +88,15 @@ def test_grid_larger_than_the_chip():
     h = R.Hyper(input_dim=1000, n_arm=5)
     ref = _step(h, 5000, 13, 0, steps=1)
     _same(_step(h, 5000, 13, 3, steps=1), ref)
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(5, 700, 256, 100, 10, 92), (4, 64, 128, 32, 6, 33)])
+def test_coupling_as_a_role_of_the_decoder_launch_equals_the_side_stream_kernel(shape):
+    """k_chain_fwd_couple (the fused step's coupling terms inside the decoder chain's launch, default from four arms up) against
+    k_couple on the side stream: the same arithmetic (couple.hpp), exact accumulator sets -- bit-identical loss vectors,
+    gradients, parameters and running statistics.  Reference: nn_model.py:558-569."""
+    A, B, D, H, L, C = shape
+    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=2, lowD_dim=L, n_arm=A)
+    ref = _step(h, B, 13, 0, tune={TUNE_COUPLE: 1})
+    _same(_step(h, B, 13, 0, tune={TUNE_COUPLE: 3}), ref)
+    _same(_step(h, B, 13, 0), ref)      # the default choice, whichever it is for this arm count
