@@ -17,6 +17,7 @@ from oracle import restatement as R
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TUNE_FUSED = 23        # include/mmvae.h MMVAE_TUNE_FUSED_CHAIN: 0 one launch per layer (default), 1 one launch per chain
+TUNE_FORK_RECORD = 12  # csrc/tune.h MMVAE_TUNE_FORK_RECORD: 1 = fork events recorded behind the kernel instead of riding on it
 TUNE_COUPLE = 13       # csrc/tune.h MMVAE_TUNE_COUPLE_SIDE: 1 coupling kernel on the side stream, 3 as a role of the decoder chain's launch
 
 
@@ -100,3 +101,12 @@ def test_coupling_as_a_role_of_the_decoder_launch_equals_the_side_stream_kernel(
     ref = _step(h, B, 13, 0, tune={TUNE_COUPLE: 1})
     _same(_step(h, B, 13, 0, tune={TUNE_COUPLE: 3}), ref)
     _same(_step(h, B, 13, 0), ref)      # the default choice, whichever it is for this arm count
+
+
+def test_fork_events_on_kernels_equal_recorded_events():
+    """The fused step's fork events ride on the latent forward / fused fc11 kernel as hipExtLaunchKernel stop events (csrc/common.hpp
+    launch_k); with MMVAE_TUNE_FORK_RECORD they are recorded behind the kernels as before.  Same launches, same order: bit-identical
+    results -- and a wrong event (a side stream that starts early) would show as a wrong dW11 or loss vector."""
+    h = R.Hyper(input_dim=1000, fc_dim=100, n_categories=92, state_dim=2, lowD_dim=10, n_arm=2)
+    ref = _step(h, 5000, 14, 0, steps=3, tune={TUNE_FORK_RECORD: 1})
+    _same(_step(h, 5000, 14, 0, steps=3), ref)
