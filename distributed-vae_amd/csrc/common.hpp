@@ -855,7 +855,15 @@ inline bool prologue_merged(const Ctx& c) {
     return c.h.training && c.h.x_drop > 0.f && (split3_gemms(c) || chain_x3_ok(c)) && !c.tune(MMVAE_TUNE_PRESPLIT_ALL);
 }
 inline bool dec_chain_writes_planes(const Ctx& c) { return split3_gemms(c) && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
-inline bool bn_apply_writes_planes(const Ctx& c) { return split3_gemms(c, 4) && (c.d.H & 1) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL); }
+// bf16 configuration on bf16 storage (mmvae_train_step_rows(data_bf16)): the NARROW operands of fc1 / dW1 (W1, dZ1) are read as
+// bf16 too -- slice 0 of the planes the fp32x3 engine uses -- instead of fp32 rounded by every block tile
+inline bool bf16_narrow_planes(const Ctx& c) {
+    return (c.h.gemm_bf16 & 0xFF) == 1 && c.x16 != nullptr && c.d.H <= 124 && (c.d.D & 7) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL) &&
+           !c.tune(MMVAE_TUNE_BF16_NARROW_FP32);
+}
+inline bool bn_apply_writes_planes(const Ctx& c) {
+    return (split3_gemms(c, 4) || bf16_narrow_planes(c)) && (c.d.H & 1) == 0 && !c.tune(MMVAE_TUNE_PRESPLIT_ALL);
+}
 int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64_t xs);
 int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t xs, float* x_rec, int need_grad, int which);
 int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);

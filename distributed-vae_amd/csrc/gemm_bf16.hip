@@ -659,7 +659,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // C tile -> slab.  grid (tiles_m * tiles_n, KS, A): block (m tile, n tile) x k range ks x arm.  Tile t + 1 is written to
 // the second LDS buffer while tile t is multiplied (one barrier per K tile); a piece's registers request tile t + 2 as
 // soon as they have been written out for tile t + 1.
-// IDX: 1 / 2 = the A / B operand through its row map (see k_x3_gemm); S16: 1 / 2 = the A / B operand is bf16 in memory
+// IDX: 1 / 2 = the A / B operand through its row map (see k_x3_gemm); S16: bit 0 / bit 1 = the A / B operand is bf16 in memory
 template <bool AMINOR, bool BMINOR, int EPI = 0, int IDX = 0, int S16 = 0>
 __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const GemmArgs g = g_in;
@@ -684,30 +684,31 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     const int ke = min(g.K, (int)(((int64_t)(blockIdx.y + 1) * nkt) / g.KS) * KT);
     f32x16 acc[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
     TileRegsT<true> ta, tb;
-    OctRegs t16;                       // S16: the bf16-source operand's pieces (ta / tb of that operand stay unused)
+    OctRegs t16a, t16b;                // S16 (bit 0: A, bit 1: B): a bf16-source operand's pieces (ta / tb of that operand stay unused)
     unsigned ro[Eng<1>::NQ] = {};      // IDX: element offsets of the indexed operand's memory rows (see quad_load_idx)
     MapRegs<1> mr = {};
-    static_assert(IDX == 0 || S16 == 0 || IDX == S16, "row map and bf16 storage: the same operand (x)");
+    static_assert(IDX == 0 || S16 == 0 || (S16 & IDX) != 0, "row map and bf16 storage: the indexed operand (x) is a bf16 one");
+    constexpr bool A16 = (S16 & 1) != 0, B16 = (S16 & 2) != 0;
     // Software pipeline at the granularity of one 16-byte piece: a piece of tile t + 1 is rounded and written to LDS
     // and the SAME registers immediately request the piece of tile t + 2, so sixteen loads per thread are in flight
     // all the time and every load has a whole iteration (the other fifteen pieces, the MFMAs, the barrier) to land.
     auto stage = [&](unsigned* Ad, unsigned* Bd, int kst, int kld, auto load_tag) __attribute__((always_inline)) {
         constexpr bool LOAD = decltype(load_tag)::value;
         if constexpr (LOAD && IDX == 1 && AMINOR) {
-            if constexpr (S16 == 1) { oct_map_offsets(ro, mr); map_request<1>(mr, oa, kld + KT); }
+            if constexpr (A16) { oct_map_offsets(ro, mr); map_request<1>(mr, oa, kld + KT); }
             else idx_next<AMINOR, 1, KT>(ro, mr, oa, kld);
         }
         if constexpr (LOAD && IDX == 2 && BMINOR) {
-            if constexpr (S16 == 2) { oct_map_offsets(ro, mr); map_request<1>(mr, ob, kld + KT); }
+            if constexpr (B16) { oct_map_offsets(ro, mr); map_request<1>(mr, ob, kld + KT); }
             else idx_next<BMINOR, 1, KT>(ro, mr, ob, kld);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             // (no run-time condition around a load: hipcc then waits for every load separately)
-            if constexpr (S16 == 1) {
+            if constexpr (A16) {
                 if (q < 4) {
-                    oct_store<AMINOR>(Ad, t16, oa, m0, kst, ke, q);
-                    if constexpr (LOAD) oct_load<AMINOR, IDX == 1>(t16, oa, m0, kld, ke, q, ro);
+                    oct_store<AMINOR>(Ad, t16a, oa, m0, kst, ke, q);
+                    if constexpr (LOAD) oct_load<AMINOR, IDX == 1>(t16a, oa, m0, kld, ke, q, ro);
                 }
             } else {
                 quad_store<AMINOR>(Ad, ta, oa, m0, kst, ke, q);
@@ -716,10 +717,10 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
                     else quad_load<AMINOR>(ta, oa, m0, kld, ke, q);
                 }
             }
-            if constexpr (S16 == 2) {
+            if constexpr (B16) {
                 if (q < 4) {
-                    oct_store<BMINOR>(Bd, t16, ob, n0, kst, ke, q);
-                    if constexpr (LOAD) oct_load<BMINOR, IDX == 2>(t16, ob, n0, kld, ke, q, ro);
+                    oct_store<BMINOR>(Bd, t16b, ob, n0, kst, ke, q);
+                    if constexpr (LOAD) oct_load<BMINOR, IDX == 2>(t16b, ob, n0, kld, ke, q, ro);
                 }
             } else {
                 quad_store<BMINOR>(Bd, tb, ob, n0, kst, ke, q);
@@ -734,9 +735,10 @@ __global__ __launch_bounds__(256, 2) void k_bf16_gemm(const GemmArgs g_in) {
     auto first = [&](auto a_tag) __attribute__((always_inline)) {
         constexpr bool ISA = decltype(a_tag)::value;
         constexpr bool MINOR = ISA ? AMINOR : BMINOR;
-        constexpr bool IDXD = IDX == (ISA ? 1 : 2), IS16 = S16 == (ISA ? 1 : 2);
+        constexpr bool IDXD = IDX == (ISA ? 1 : 2), IS16 = ISA ? A16 : B16;
         const OperandDev& o = ISA ? oa : ob;
         const int r0 = ISA ? m0 : n0;
+        OctRegs& t16 = ISA ? t16a : t16b;
         if constexpr (IS16) {
             if constexpr (IDXD) {
                 if constexpr (MINOR) { map_request<1>(mr, o, kb); oct_map_offsets(ro, mr); map_request<1>(mr, o, kb + KT); }
@@ -1881,6 +1883,10 @@ int launch_x3_planes(const Ctx& c, const float* params, int which, const mmvae_n
     if (which & 1 && x3) {
         jobs[n++] = plane_job(c, PL_W1, params + c.po.o[0], d.D, c.po.per_arm);
         jobs[n++] = plane_job(c, PL_W11, params + c.po.o[26], d.H, c.po.per_arm, params + c.po.o[27], c.po.per_arm);   // bias: column fc_dim
+    } else if ((which & 1) && bf16_narrow_planes(c)) {
+        // bf16 configuration on bf16 storage: slice 0 of W1's planes IS bf16(W1) -- fc1 reads its narrow operand from it in
+        // sixteen-byte pieces of eight elements, like x, instead of fp32 rounded by every block tile (half the bytes)
+        jobs[n++] = plane_job(c, PL_W1, params + c.po.o[0], d.D, c.po.per_arm);
     }
     if (which & 9) {   // bit 3: the small layers alone (a backward pass that is its own call)
         if (chain_x3_ok(c) && !c.small_planes) {   // the small layers' weights for the chain kernels: slot s = [N][K] of fc2..fc5, fc6..fc10
@@ -1923,7 +1929,13 @@ int launch_fc1_fwd_bf16(const Ctx& c, const float* params, const float* x, int64
             hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true, 1>), dim3(cdiv(cdiv(d.B, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
         } else if (c.x16) {         // bf16 storage: x from its bf16 copy
             g.a.ptr = reinterpret_cast<const float*>(c.x16); g.a.src16 = 1;
-            hipLaunchKernelGGL((k_bf16_gemm<false, false, 0, 1, 1>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+            if (bf16_narrow_planes(c)) {   // ... and W1 from slice 0 of its planes (launch_x3_planes): [128][rup(D, 32)] bf16, zero rows beyond H
+                const PlaneGeom pg = plane_geom(c, PL_W1);
+                g.b.ptr = reinterpret_cast<const float*>(c.ws + pg.ws_off); g.b.ld = pg.Cp; g.b.src16 = 1;
+                g.b_arm = 3 * (int64_t)pg.Rp * pg.Cp / 2;       // arm stride in FLOATS of the pointer arithmetic (planes: 2-byte elements)
+                hipLaunchKernelGGL((k_bf16_gemm<false, false, 0, 1, 3>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+            } else
+                hipLaunchKernelGGL((k_bf16_gemm<false, false, 0, 1, 1>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         } else
             hipLaunchKernelGGL((k_bf16_gemm<false, false, 0, 1>), dim3(cdiv(d.B, BT) * cdiv(d.H, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
     } else if (split3_gemms(c)) {   // (fc_dim <= 124: one tile wide, the two tiles of a block share the W1 tile)
@@ -2042,7 +2054,13 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
                 hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 1, true, 2>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
             } else if (c.x16) {
                 g.b.ptr = reinterpret_cast<const float*>(c.x16); g.b.src16 = 1;
-                hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 2, 2>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+                if (bf16_narrow_planes(c) && bn_apply_writes_planes(c)) {   // dZ1 from slice 0 of its planes (k_bn_bwd_apply): [rup(B, 256)][128] bf16
+                    const PlaneGeom pg = plane_geom(c, PL_DZ1);
+                    g.a.ptr = reinterpret_cast<const float*>(c.ws + pg.ws_off); g.a.ld = pg.Cp; g.a.src16 = 1;
+                    g.a_arm = 3 * (int64_t)pg.Rp * pg.Cp / 2;
+                    hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 2, 3>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
+                } else
+                    hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 2, 2>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
             } else
                 hipLaunchKernelGGL((k_bf16_gemm<true, true, 0, 2>), dim3(cdiv(d.H, BT) * cdiv(d.D, BT), g.KS, d.A), dim3(256), 0, c.stream, g);
         } else if (split3_gemms(c)) {   // one tile high: the two tiles of a block share the dZ1 tile

@@ -26,7 +26,9 @@ enum {
     MMVAE_TUNE_ABLATE_L = 14,      // latent kernels: ablations / stamps
     MMVAE_TUNE_LAT_FULLWAVE = 15,  // latent kernels: one wave per cell instead of the half-wave layout
     MMVAE_TUNE_ABLATE_B = 16,      // bf16 GEMM engine: 1 no MFMAs, 2 no global loads, 4 no LDS stores (results wrong)
-    // 17 MMVAE_TUNE_ENGINE: public (mmvae.h); 18: retired (was the mid event of round 2)
+    // 17 MMVAE_TUNE_ENGINE: public (mmvae.h)
+    MMVAE_TUNE_BF16_NARROW_FP32 = 18, // bf16 configuration on bf16 storage: the narrow operands of fc1 / dW1 (W1, dZ1) read as fp32 and rounded
+                                   // by every block tile, as before, instead of as bf16 from slice 0 of their planes
     MMVAE_TUNE_BN_PARTIALS = 19,   // BatchNorm batch sums through per-workgroup partial arrays instead of the accumulators
     MMVAE_TUNE_PRESPLIT_ALL = 20,  // fp32x3 engine: all slice planes through k_presplit launches
     MMVAE_TUNE_CHAIN_FP32 = 21,    // fp32x3 engine: the chain kernels' own GEMMs stay on the fp32 matrix instruction
