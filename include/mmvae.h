@@ -107,7 +107,10 @@ typedef struct mmvae_noise {
  *                [dW11 | db11] GEMM, the coupling terms and the loss scalars beside the latency-bound chains of the main
  *                stream (fork / join by the events below).  The caller keeps stream and events alive while work that
  *                uses them is in flight.
- *   ev           MMVAE_N_EVENTS hipEvent_t (hipEventDisableTiming suffices), all non-NULL when side_stream is.
+ *   ev           MMVAE_N_EVENTS hipEvent_t (hipEventDisableTiming suffices), all non-NULL when side_stream is.  The library records
+ *                them itself -- with hipEventRecord, or as the stop event of one of its own kernel launches (hipExtLaunchKernel):
+ *                either way an event belongs to ONE engine and is not to be recorded or waited on by the caller while a call
+ *                that uses it is in flight.
  *   early_grad_event  data-parallel overlap: when non-NULL (and side_stream is set), mmvae_backward and
  *                mmvae_train_step(do_adam == 0) reduce the gradients of fc11.weight / fc11.bias -- the last two
  *                tensors of every arm's segment of `grads`, 47 % of the parameters -- as soon as their GEMM has
