@@ -1323,9 +1323,9 @@ __device__ __forceinline__ void reduce_desc(const RedDesc& d, int KS, int arm, f
         // slab loads in flight per item: the smallest of 4 / 8 / 16 that covers KS (the clamped duplicates of the last slab
         // each cost a pass through the vector-memory pipe: 16 issued for 4 or 6 slabs were 2.7 - 4 x the loads needed);
         // the sum runs over the slabs in the same order whatever the chunk
-        auto add_slabs = [&](auto chunk) __attribute__((always_inline)) {
+        auto add_slabs = [&](auto chunk, int kbeg, int kend) __attribute__((always_inline)) {
             constexpr int CHK = decltype(chunk)::value;
-            for (int k0 = 0; k0 < KS; k0 += CHK) {
+            for (int k0 = kbeg; k0 < kend; k0 += CHK) {
                 float v[CHK][E];
 #pragma unroll
                 for (int k = 0; k < CHK; ++k) {
@@ -1343,9 +1343,13 @@ __device__ __forceinline__ void reduce_desc(const RedDesc& d, int KS, int arm, f
                     for (int e = 0; e < E; ++e) s[e] += (k0 + k < KS) ? v[k][e] : 0.f;
             }
         };
-        if (KS <= 4) add_slabs(std::integral_constant<int, 4>{});
-        else if (KS <= 8) add_slabs(std::integral_constant<int, 8>{});
-        else add_slabs(std::integral_constant<int, 16>{});
+        // (whole sixteens first, then the smallest chunk that covers the rest: 20 slabs -- the small-layer products at the benchmark
+        // shape -- are 16 + 4 loads, not 32)
+        const int k16 = KS > 8 ? (KS & ~15) : 0, rest = KS - k16;
+        if (k16 > 0) add_slabs(std::integral_constant<int, 16>{}, 0, k16);
+        if (rest > 8) add_slabs(std::integral_constant<int, 16>{}, k16, KS);
+        else if (rest > 4) add_slabs(std::integral_constant<int, 8>{}, k16, KS);
+        else if (rest > 0) add_slabs(std::integral_constant<int, 4>{}, k16, KS);
         float g[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) g[e] = s[e] * d.scale;
