@@ -380,7 +380,7 @@ static void aug_gemm_launch(hipStream_t s, bool relu, bool affine, const float* 
 }
 
 static int aug_gemm(hipStream_t s, int force_tile, bool relu, bool affine, const float* A, int lda, int M, const float* pk,
-                    const AugLayer& g, float* C, int ldc) {
+                    const AugLayer& g, float* C, int ldc, float* scratch = nullptr, int64_t scratch_floats = 0) {
     const int ncols = ldc < (int)pad4(g.N) ? ldc : (int)pad4(g.N);   // the K padding of the next layer is written too (zeros)
     const float* W = pk + g.w;
     const float* sc = pk + g.sc;
@@ -388,7 +388,7 @@ static int aug_gemm(hipStream_t s, int force_tile, bool relu, bool affine, const
     if (force_tile == 99 || force_tile == 98)   // bf16 operands (mmvae_augment's gemm_bf16 = 1) or fp32 operands split into
         // three bf16 slices (gemm_bf16 = 2): the shared tile engine of gemm_bf16.hip, fp32 epilogue
         return launch_bf16_affine(s, relu, affine, A, lda, M, W, g.ldw, g.N, g.ldw, sc, sh, C, ldc, ncols, force_tile == 98,
-                                  reinterpret_cast<const unsigned short*>(pk + g.pl), g.Np, g.Kp);
+                                  reinterpret_cast<const unsigned short*>(pk + g.pl), g.Np, g.Kp, scratch, scratch_floats);
     // the largest tile that still leaves two workgroups per CU (256 CUs); MMVAE_AUG_TILE=<BM><BN> code forces one
     const int force = force_tile;   // 11 12 21 22 (1 = 64, 2 = 128), 0 = automatic
     auto count = [&](int bm, int bn) { return (int64_t)cdiv(M, bm) * cdiv(ncols, bn); };
@@ -501,7 +501,8 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     const int ft = gemm_bf16 == 2 ? 98 : gemm_bf16 ? 99 : (ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0);
     int rc;
     // trunk: once per cell when the arms share x
-    if ((rc = aug_gemm(s, ft, true, true, x, d->D, T, packed, L.g[0], w + W.h1, W.ld1))) return rc;
+    // (the first layer may split K into slabs: the buffers of the last two hidden layers, h9 and h10, are adjacent and not in use yet)
+    if ((rc = aug_gemm(s, ft, true, true, x, d->D, T, packed, L.g[0], w + W.h1, W.ld1, w + W.h9, W.total - W.h9))) return rc;
     if ((rc = aug_gemm(s, ft, true, true, w + W.h1, W.ld1, T, packed, L.g[1], w + W.h2, W.ld1))) return rc;
     if ((rc = aug_gemm(s, ft, true, true, w + W.h2, W.ld1, T, packed, L.g[2], w + W.h3, W.ld3))) return rc;
     if ((rc = aug_gemm(s, ft, true, true, w + W.h3, W.ld3, T, packed, L.g[3], w + W.h4, W.ld3))) return rc;

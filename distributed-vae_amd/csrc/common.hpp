@@ -869,7 +869,8 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
 int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which);
 int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw, int N,
                        int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3 = 0,
-                       const unsigned short* w_planes = nullptr, int Np = 0, int Kp = 0);
+                       const unsigned short* w_planes = nullptr, int Np = 0, int Kp = 0,
+                       float* scratch = nullptr, int64_t scratch_floats = 0 /*room for split-K slabs of layers with few tiles and a long K*/);
 // fp32 [R][C] (row pitch ld) -> three bf16 slice planes [3][Rp][Cp], zero-padded (fp32x3 engine)
 int launch_presplit_one(hipStream_t s, const float* src, int64_t ld, int R, int C, int Rp, int Cp, unsigned short* dst);
 // evaluation labels / consensus (consensus.hip)

@@ -2112,9 +2112,36 @@ int launch_presplit_one(hipStream_t s, const float* src, int64_t ld, int R, int 
     return launch_presplit(s, 1, &j, 1);
 }
 
+// sum of the split-K slabs of an augmenter layer + its folded BatchNorm / ReLU epilogue: out[m][n] = act(sum_ks slab[ks][m][n] *
+// scale[n] + shift[n]) for n < N, zero for the padding columns N .. ncols - 1.  One float4 per thread (ld, ncols multiples of 4).
+__global__ __launch_bounds__(256) void k_aug_slab_epi(const float* __restrict__ slab, int64_t ks_stride, int KS, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, float* __restrict__ out, int ld, int M, int N,
+                                                      int ncols, int relu, int affine) {
+    const int c4n = ncols >> 2;
+    const int64_t n = (int64_t)M * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / c4n), c = (int)(i - (int64_t)m * c4n) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < KS; ++k) {   // (KS <= 4: the loads of all slabs are independent and issue together)
+            const float4 t = *reinterpret_cast<const float4*>(slab + k * ks_stride + (int64_t)m * ld + c);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = c + e;
+            const bool real = col < N;
+            float y = r[e] * ((affine && real) ? scale[col] : 1.f) + ((affine && real) ? shift[col] : 0.f);
+            if (relu) y = fmaxf(y, 0.f);
+            r[e] = real ? y : 0.f;
+        }
+        *reinterpret_cast<float4*>(out + (int64_t)m * ld + c) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, int lda, int M, const float* W, int ldw, int N,
                        int Kpad, const float* sc, const float* sh, float* C, int ldc, int ncols, int split3,
-                       const unsigned short* w_planes, int Np, int Kp) {
+                       const unsigned short* w_planes, int Np, int Kp, float* scratch, int64_t scratch_floats) {
     GemmArgs g{};
     g.a = kmajor(A, lda, M, Kpad);        // rows are zero-padded to Kpad = pad4(K) floats on both sides
     g.b = kmajor(W, ldw, N, Kpad);
@@ -2125,6 +2152,31 @@ int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, in
         // n tile and share its weight tile, copied from the planes; the activations are split on their way into LDS
         g.b.pl = w_planes; g.b.pl_plane = (int64_t)Np * Kp; g.b.pl_arm = 0; g.b.pl_ld = Kp;
         const int tiles = cdiv(M, BT) * cdiv(ncols, BT);
+        // A layer with fewer tile pairs than CUs and a long K (the first layer at the benchmark shape: 5000 x 1000 x 5000 = 160
+        // blocks on 256 CUs, 362 of the forward's 1 580 us): split K over KS blocks per pair -- the count in 2 .. 4 that needs
+        // the fewest rounds of the chip per unit of K -- into slabs in the caller's scratch, and a small pass sums them and
+        // applies the epilogue.
+        {
+            constexpr int N_CUS = 256;   // MI355X
+            const int pairs = cdiv(cdiv(M, BT), 2) * cdiv(ncols, BT);
+            int ks_best = 1;
+            double cost_best = (double)cdiv(pairs, N_CUS);
+            for (int ks = 2; ks <= 4; ++ks) {
+                const double cost = (double)cdiv(pairs * ks, N_CUS) / ks;
+                if (cost < 0.8 * cost_best && Kpad / ks >= 32 * Eng<3>::KT && (int64_t)ks * M * ldc <= scratch_floats) { ks_best = ks; cost_best = cost; }
+            }
+            if (scratch && ks_best > 1 && tiles > 192 && (ldc & 3) == 0 && (ncols & 3) == 0) {
+                g.KS = ks_best;
+                g.so = SlabOut{scratch, (int64_t)M * ldc, 0, ldc, M, N < ncols ? N : ncols};
+                hipLaunchKernelGGL((k_x3_gemm<false, false, 0, 2, true>), dim3(pairs, ks_best, 1), dim3(512), 0, s, g);
+                HIP_LAUNCH_CHECK("k_x3_gemm<affine, split K>");
+                const int64_t items = (int64_t)M * (ncols >> 2);
+                hipLaunchKernelGGL(k_aug_slab_epi, dim3((unsigned)imin64(4096, cdiv64(items, 256))), dim3(256), 0, s, scratch, (int64_t)M * ldc,
+                                   ks_best, sc, sh, C, ldc, M, N, ncols, relu ? 1 : 0, affine ? 1 : 0);
+                HIP_LAUNCH_CHECK("k_aug_slab_epi");
+                return 0;
+            }
+        }
         // fewer tile pairs than half the CUs: one tile per block, the groups split K (trunk layers 1000 -> 500, 500 -> 500,
         // 500 -> 100 at M = 5000: 77 -> 51, 45 -> 32, 44 -> 31 us; at 320 tiles the lost sharing of the weight tile costs more:
         // 360 -> 385, 82 -> 92, 50 -> 62 us)
@@ -2134,8 +2186,30 @@ int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, in
             hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 2, true>), dim3(cdiv(cdiv(M, BT), 2) * cdiv(ncols, BT), 1, 1), dim3(512), 0, s, g);
     } else if (split3)
         hipLaunchKernelGGL((k_x3_gemm<false, false, 1, 0>), dim3(cdiv(cdiv(M, BT) * cdiv(ncols, BT), 2), 1, 1), dim3(512), 0, s, g);
-    else
-        hipLaunchKernelGGL((k_bf16_gemm<false, false, 1>), dim3(cdiv(M, BT) * cdiv(ncols, BT), 1, 1), dim3(256), 0, s, g);
+    else {
+        // bf16 operands: one tile per 256-thread block, two blocks per CU; the same split of a long K for layers that leave
+        // slots of the chip empty (the first layer: 320 tiles on 512 slots)
+        const int tiles = cdiv(M, BT) * cdiv(ncols, BT);
+        constexpr int SLOTS = 512;
+        int ks_best = 1;
+        double cost_best = (double)cdiv(tiles, SLOTS);
+        for (int ks = 2; ks <= 4; ++ks) {
+            const double cost = (double)cdiv(tiles * ks, SLOTS) / ks;
+            if (cost < 0.8 * cost_best && Kpad / ks >= 16 * KT && (int64_t)ks * M * ldc <= scratch_floats) { ks_best = ks; cost_best = cost; }
+        }
+        if (scratch && ks_best > 1 && (ldc & 3) == 0 && (ncols & 3) == 0) {
+            g.KS = ks_best;
+            g.so = SlabOut{scratch, (int64_t)M * ldc, 0, ldc, M, N < ncols ? N : ncols};
+            hipLaunchKernelGGL((k_bf16_gemm<false, false>), dim3(tiles, ks_best, 1), dim3(256), 0, s, g);
+            HIP_LAUNCH_CHECK("k_bf16_gemm<affine, split K>");
+            const int64_t items = (int64_t)M * (ncols >> 2);
+            hipLaunchKernelGGL(k_aug_slab_epi, dim3((unsigned)imin64(4096, cdiv64(items, 256))), dim3(256), 0, s, scratch, (int64_t)M * ldc,
+                               ks_best, sc, sh, C, ldc, M, N, ncols, relu ? 1 : 0, affine ? 1 : 0);
+            HIP_LAUNCH_CHECK("k_aug_slab_epi");
+            return 0;
+        }
+        hipLaunchKernelGGL((k_bf16_gemm<false, false, 1>), dim3(tiles, 1, 1), dim3(256), 0, s, g);
+    }
     HIP_LAUNCH_CHECK("k_bf16_gemm<affine>");
     return 0;
 }
