@@ -179,6 +179,60 @@ def bf16_config(args, model_args, data, batches, nb, A, B, D, H, L, C, S, P, wor
     return out
 
 
+def other_configs(args, dev, data, B, mixVAE_model, FusedAdam, N):
+    """BASELINE.json's other fp32 workloads at per-GPU full size, driver-timed beside the headline: configs[3] (A = 5 arms,
+    D = 5000; train-scripts/*.sh fix the arm counts) and configs[4] (A = 3 at the real SmartSeq gene count D = 5032,
+    nn_model.py:18, on the synthetic stand-in of SURVEY.md 8d: 22 365 cells).  20 timed steps each after 5 warm-ups, wall
+    clock between synchronisations as the headline; `roofline_step` is SURVEY.md 8(d)'s arithmetic for the whole step."""
+    H, L, C, S = 100, 10, 92, 2
+    out = {}
+    steps, warm = 20, 5
+    for key, A, D, cells in (("cfg4_A5_D5000", 5, 5000, None), ("cfg5_A3_D5032", 3, 5032, 22365)):
+        if D == data.shape[1]:
+            d = data
+        else:
+            d = synthetic_rows((cells // B) * B, D, 546, dev)
+        nb = d.shape[0] // B
+        torch.manual_seed(546)
+        m = mixVAE_model(input_dim=D, fc_dim=H, n_categories=C, state_dim=S, lowD_dim=L, x_drop=0.5, s_drop=0.0, n_arm=A, lam=1,
+                         lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=dev, eps=1e-8, momentum=0.01,
+                         ref_prior=False, loss_mode="MSE").to(dev)
+        m.train()
+        m.gemm_dtype = args.gemm_dtype
+        opt = FusedAdam(m, lr=1e-3)
+        bs = [d[i * B:(i + 1) * B] for i in range(nb)]
+        for i in range(warm):
+            m.fused_train_step(bs[i % nb].expand(A, -1, -1), 1.0, opt, do_adam=True)
+        torch.cuda.synchronize()
+        stream = torch.cuda.current_stream(dev)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for i in range(steps):
+            buf = m.fused_train_step(bs[(warm + i) % nb].expand(A, -1, -1), 1.0, opt, do_adam=True)
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        P = P_count(N, A, B, D, H, L, C, S)
+        fl_cell, by_cell = A * flops_per_cell_arm(D, H, L, C, S), A * bytes_per_cell_arm(D, H, P, B)
+        cps = B * steps / dt
+        x3 = (N.gemm_mode(args.gemm_dtype) & 0xFF) == 2
+        eng_peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_FP32_MFMA_TFLOPS
+        t_m, t_h = fl_cell / (eng_peak * 1e12), by_cell / (PEAK_HBM_GBS * 1e9)
+        out[key] = {"arms": A, "genes": D, "batch": B, "cells_resident": int(d.shape[0]), "steps": steps, "warmup": warm,
+                    "ms_per_step": dt / steps * 1e3, "ms_per_step_hip_events_median": per[len(per) // 2],
+                    "value": cps, "unit": "cells/s", "last_loss": float(buf[0]),
+                    "flop_per_cell": fl_cell, "bytes_per_cell": by_cell,
+                    "roofline_step": {"bound": "hbm" if t_h >= t_m else "mfma", "frac": cps * max(t_h, t_m),
+                                      "bytes_frac_of_hbm_peak": cps * t_h, "flops_frac_of_engine_peak": cps * t_m}}
+        del m, opt, bs
+        if d is not data:
+            del d
+        torch.cuda.empty_cache()
+    return out
+
+
 def measure_bf16_stages(model, x, A, B, D, H):
     """Per-launch duration of the five bf16 GEMM kernels (HIP events on the launch stream, mmvae_debug_stage replays) and
     the HBM traffic they are priced by: fp32 bytes actually streamed per launch (x, dZ11, slabs) / duration."""
@@ -214,12 +268,22 @@ def measure_bf16_stages(model, x, A, B, D, H):
     return res
 
 
-def spawn_ranks(n: int, share_gpu: bool = False) -> int:
+def _launch_mod():
+    """distributed-vae_amd/launch.py by path: no torch, no HIP -- the parent of the ranks must not have initialised the GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mmvae_launch", os.path.join(ROOT, "distributed-vae_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def spawn_ranks(n: int, share_gpu: bool = False, log_dir: str = "") -> int:
     """--gpus N without a launcher: start N rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
-    environment) and wait for them.  This process has not initialised the GPU (counting devices does not), and it never
-    replaces itself: the ranks are children.  Returns the exit status to leave with."""
+    environment) and supervise them (launch.run_ranks: the first rank that exits non-zero stops the others and its stderr
+    tail is printed -- a rank that cannot open its device must not leave the rest waiting in their first collective).
+    This process has not initialised the GPU (counting devices does not), and it never replaces itself: the ranks are
+    children.  Returns the exit status to leave with."""
     import socket
-    import subprocess
     have = torch.cuda.device_count()
     if have < n and not (share_gpu and have >= 1):
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible: refusing to run the {n}-GPU job on fewer devices",
@@ -228,15 +292,7 @@ def spawn_ranks(n: int, share_gpu: bool = False) -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+    return _launch_mod().run_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], n, port, log_dir or None)
 
 
 def main():
@@ -256,6 +312,8 @@ def main():
     ap.add_argument("--bf16-fp32-storage", action="store_true",
                     help="--gemm-dtype bf16 only: read x / dZ11 as fp32 and round on load instead of the bf16 copy")
     ap.add_argument("--no-eval", action="store_true", help="skip the evaluation-label / consensus measurement")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the A = 5 / D = 5000 and A = 3 / D = 5032 lines (BASELINE.json configs[3], configs[4]) measured beside the headline")
     ap.add_argument("--gemm-dtype", choices=["fp32", "fp32x3", "fp32_mfma", "bf16"], default="fp32",
                     help="operand type of the five D x H GEMMs: fp32 (the headline / parity configuration; the library's "
                          "fp32 engine, i.e. fp32x3: every fp32 operand as three exact bf16 slices, six slice products per "
@@ -267,15 +325,19 @@ def main():
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="one rank, but through the data-parallel step (RCCL init, all-reduce(AVG) of the flat gradients, "
                          "separate Adam launch): exercises the N > 1 code path on a one-GPU box")
+    ap.add_argument("--log-dir", default="", help="N > 1 without a launcher: directory for the ranks' rank<r>.err files")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, args.share_gpu))   # no launcher: be one (before any GPU call in this process)
+        sys.exit(spawn_ranks(args.gpus, args.share_gpu, args.log_dir))   # no launcher: be one (before any GPU call in this process)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MMVAE_BENCH_FAIL_RANK") == str(rank):   # test hook: this rank dies right after start
+        print(f"rank {rank}: MMVAE_BENCH_FAIL_RANK set, exiting 1", file=sys.stderr, flush=True)
+        sys.exit(1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -296,10 +358,13 @@ def main():
         os.dup2(2, 1)
         try:
             backend = "gloo" if args.share_gpu else "nccl"
+            import datetime
+            # a rank that never arrives must not hold the others for the library default of ten minutes
+            tmo = datetime.timedelta(seconds=int(os.environ.get("MMVAE_INIT_TIMEOUT_S", "120")))
             if args.share_gpu:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
             else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
             warm = torch.ones(8, device=dev)
             dist.all_reduce(warm)                      # a real collective: every rank contributes 1
             torch.cuda.synchronize()
@@ -441,6 +506,12 @@ def main():
                                              world, rank, dev, timed, DD, FusedAdam, mixVAE_model)
         except Exception as e:   # noqa: BLE001
             out["bf16_config"] = {"error": f"{type(e).__name__}: {e}"}
+    if (rank == 0 and world == 1 and not args.no_other_configs and args.gemm_dtype != "bf16"
+            and (A, B, D) == (2, 5000, 5000)):
+        try:
+            out["other_configs"] = other_configs(args, dev, data, B, mixVAE_model, FusedAdam, N)
+        except Exception as e:   # noqa: BLE001
+            out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
     if roof is not None:
         out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -776,7 +847,7 @@ def measure_stages(model, x, A, B, D, H):
     return out
 
 
-PMC_ROUND = "r03"
+PMC_ROUND = "r04"
 
 
 def _pmc_rows(kind, A, B, D, H):

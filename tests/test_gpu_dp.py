@@ -164,13 +164,18 @@ def test_two_ranks_in_the_bf16_configuration_on_bf16_storage(tmp_path):
     assert np.isfinite(res["1"][0]["params"]).all() and res["1"][0]["losses"][0] == res["0"][0]["losses"][0]
 
 
-def test_train_dp_entry_runs_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--no-augmentation", "--hard", "False", "--loss_mode", "MSE", "--n_epoch_p", "0",
+                                        "--min_con", "0.99", "--max_prun_it", "0"]],
+                         ids=["augmenter_on_as_the_reference_default", "no_augmenter_hard"])
+def test_train_dp_entry_runs_two_ranks_on_one_gpu(tmp_path, extra):
     """tools/train_dp.py spawns its ranks before touching a GPU and never re-execs; with Philox noise (different streams per
-    rank would be wrong here: the replicas must stay identical, which they do because only gradients are averaged)."""
+    rank would be wrong here: the replicas must stay identical, which they do because only gradients are averaged).  The
+    flag set is the reference's (train.py:172-267): ``--augmentation`` defaults to True (random-init Augmenter_smartseq in
+    front of every step: the pretrained file is not shipped), ``--hard False`` is True (``type=bool``)."""
     out = str(tmp_path / "o")
     cmd = [sys.executable, os.path.join(ROOT, "tools", "train_dp.py"), "--gpus", "2", "--share-gpu", "--cells", "2048",
            "--genes", "256", "--fc_dim", "32", "--latent_dim", "6", "--n_categories", "12", "--batch_size", "128",
-           "--n_epoch", "2", "--good-enuf-consensus", "2.0", "--out", out]
+           "--n_epoch", "2", "--good-enuf-consensus", "2.0", "--out", out] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     a, b = torch.load(os.path.join(out, "rank0.pt"), weights_only=False), torch.load(os.path.join(out, "rank1.pt"), weights_only=False)

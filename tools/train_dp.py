@@ -50,6 +50,26 @@ def parse_args(argv=None):
     p.add_argument("--s_drop", type=float, default=0.0)
     p.add_argument("--optimizer", type=str, default="adam", choices=["adam", "adamw"])
     p.add_argument("--gpus", type=int, default=1)
+    # the rest of the reference's flag set (train.py:172-267), with its defaults and its type quirks: ``type=bool`` flags are
+    # True for ANY non-empty value ("--hard False" is True), exactly as argparse gives them to the reference
+    p.add_argument("--n_epoch_p", default=0, type=int, help="epochs of the pruning phase (train.py:196-200; disabled upstream)")
+    p.add_argument("--min_con", default=0.99, type=float, help="minimum consensus (train.py:202)")
+    p.add_argument("--max_prun_it", default=0, type=int, help="train.py:203-208")
+    p.add_argument("--variational", default=True, type=bool, help="train.py:213-215")
+    p.add_argument("--augmentation", default=True, type=bool,
+                   help="VAE-GAN augmenter in front of every step (train.py:216-217; the production default).  The pretrained "
+                        "file is not shipped: --aug_file names a checkpoint in the reference's layout, else the architecture "
+                        "runs on random-init weights (results unpinned, the arithmetic and the cost are the production path's)")
+    p.add_argument("--aug_file", default="", type=str, help="augmenter checkpoint (mmidas.toml 'aug'; cpl_mixvae.py:128-149)")
+    p.add_argument("--no-augmentation", dest="augmentation", action="store_const", const=False,
+                   help="not in the reference: the only way to switch a type=bool flag off from the command line")
+    p.add_argument("--ref_pc", default=False, type=bool, help="train.py:225-227 (rejected by loss(), nn_model.py:578)")
+    p.add_argument("--pretrained_model", default=False, type=bool, help="train.py:229-231: start from --trained_model")
+    p.add_argument("--trained_model", default="", type=str, help="checkpoint for --pretrained_model (mmidas.toml 'trained')")
+    p.add_argument("--n_pr", default=0, type=int, help="train.py:232-237")
+    p.add_argument("--loss_mode", default="MSE", type=str, help="train.py:241-243 (ZINB is rejected by forward, nn_model.py:315)")
+    p.add_argument("--hard", default=False, type=bool, help="train.py:245: straight-through one-hot samples")
+    p.add_argument("--log-dir", dest="log_dir", default="", help="directory for the ranks' rank<r>.err files")
     p.add_argument("--gemm-dtype", default="fp32", choices=["fp32", "bf16", "fp32_mfma"])
     p.add_argument("--good-enuf-consensus", type=float, default=0.75)
     # data
@@ -96,17 +116,27 @@ def main(rank: int, ws: int, args, port: int) -> None:
     n, d = data.shape
     if rank == 0:
         print(f"# cells: {n}, # genes: {d}, world size: {ws}", flush=True)
-    trainer = cpl_mixVAE(args.saving_folder, "", dev, save_flag=bool(args.saving_folder) and rank == 0)
+    trainer = cpl_mixVAE(args.saving_folder, args.aug_file if args.augmentation else "", dev,
+                         save_flag=bool(args.saving_folder) and rank == 0)
+    if args.augmentation and not args.aug_file:
+        # the authors' pretrained augmenter is not shipped (mmidas.toml:27): the Augmenter_smartseq architecture on
+        # random-init weights, identical on every rank (it is frozen: no gradient ever reaches it)
+        from distributed_vae_amd.augmentation import Augmenter_smartseq
+        torch.manual_seed(SEED)
+        trainer.set_augmenter(Augmenter_smartseq(50, 10, d, 500))
     train_loader, test_loader, _ = get_loaders(dataset=data, seed=SEED, batch_size=args.batch_size, world_size=ws,
                                                rank=rank, use_dist_sampler=True, device=dev)
     torch.manual_seed(SEED + rank)     # replicas start different on purpose: rank 0's parameters win the broadcast in train()
     trainer.init_model(n_categories=args.n_categories, state_dim=args.state_dim, input_dim=d, fc_dim=args.fc_dim,
                        lowD_dim=args.latent_dim, x_drop=args.p_drop, s_drop=args.s_drop, lr=args.lr, n_arm=args.n_arm,
-                       temp=args.temp, tau=args.tau, lam=args.lam, lam_pc=args.lam_pc, beta=args.beta,
-                       gemm_dtype=args.gemm_dtype)
+                       temp=args.temp, hard=args.hard, tau=args.tau, lam=args.lam, lam_pc=args.lam_pc, beta=args.beta,
+                       ref_prior=args.ref_pc, variational=args.variational,
+                       trained_model=args.trained_model if args.pretrained_model else "", n_pr=args.n_pr,
+                       mode=args.loss_mode, gemm_dtype=args.gemm_dtype)
     if args.optimizer == "adamw":      # train.py:146-147
         trainer.optimizer = torch.optim.AdamW(trainer.model.parameters(), lr=args.lr)
-    hist = trainer.train(train_loader=train_loader, test_loader=None, n_epoch=args.n_epoch, rank=rank, ws=ws,
+    hist = trainer.train(train_loader=train_loader, test_loader=None, n_epoch=args.n_epoch, n_epoch_p=args.n_epoch_p,
+                         min_con=args.min_con, max_prun_it=args.max_prun_it, rank=rank, ws=ws,
                          good_enuf_consensus=args.good_enuf_consensus)
     torch.cuda.synchronize()
     if args.out:
@@ -124,6 +154,8 @@ def launch(args) -> int:
     """Start the ranks (no GPU call has been made in this process) and return the exit status to leave with."""
     import multiprocessing as mp
     import socket
+    import tempfile
+    import time
 
     ws = args.gpus
     if ws <= 1:
@@ -138,14 +170,50 @@ def launch(args) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=main, args=(r, ws, args, port)) for r in range(ws)]
+    log_dir = args.log_dir or tempfile.mkdtemp(prefix="mmvae_train_dp_")
+    os.makedirs(log_dir, exist_ok=True)
+    procs = [ctx.Process(target=_rank_entry, args=(r, ws, args, port, log_dir)) for r in range(ws)]
     for p in procs:
         p.start()
+    # supervise: the first rank that exits non-zero stops the others (they would otherwise wait in their next collective
+    # until the process-group timeout); only the children started here are signalled, by handle
     rc = 0
+    while True:
+        codes = [p.exitcode for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, c = bad[0]
+            rc = abs(c) or 1
+            tail = ""
+            try:
+                tail = "\n".join(open(os.path.join(log_dir, f"rank{r}.err"), errors="replace").read().splitlines()[-30:])
+            except OSError:
+                pass
+            print(f"rank {r} exited with status {c}; stopping the other ranks.  Its stderr tail:\n{tail}", file=sys.stderr, flush=True)
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
     for p in procs:
-        p.join()
-        rc = max(rc, abs(p.exitcode or 0))
+        if p.exitcode is None:
+            p.terminate()
+    for p in procs:
+        p.join(5)
+        if p.exitcode is None:
+            p.kill()
+            p.join()
     return rc
+
+
+def _rank_entry(rank: int, ws: int, args, port: int, log_dir: str) -> None:
+    """A rank's stderr goes to <log_dir>/rank<r>.err (the parent prints its tail when the rank fails)."""
+    fd = os.open(os.path.join(log_dir, f"rank{rank}.err"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.dup2(fd, 2)
+    os.close(fd)
+    if os.environ.get("MMVAE_TRAIN_FAIL_RANK") == str(rank):   # test hook
+        print(f"rank {rank}: MMVAE_TRAIN_FAIL_RANK set, exiting 1", file=sys.stderr, flush=True)
+        sys.exit(1)
+    main(rank, ws, args, port)
 
 
 if __name__ == "__main__":
