@@ -671,7 +671,10 @@ def augmenter_forward(args, batches, A, B, D, with_cpu):
     out = {"value": B / ms * 1e3, "unit": "cells/s", "ms_per_batch": ms, "batch": B, "arms": A,
            "workload": f"Augmenter_smartseq eval forward, D={D}, n_dim={ND}, noise {NZ}, latent {Z}, x shared by {A} arms",
            "gflop_executed": fl_exec / 1e9, "gflop_reference_pattern": fl_ref / 1e9,
-           "tflops": fl_exec / ms / 1e9, "frac_of_fp32_mfma_peak": fl_exec / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+           "tflops": fl_exec / ms / 1e9, "frac_of_fp32_mfma_peak": fl_exec / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS,
+           # the fp32x3 engine's ceiling: 2.5 PFLOP/s of bf16 MFMAs / 6 slice products per product
+           "engine": "fp32x3: planes x planes GEMM (csrc/gemm_pp.hip), every layer's epilogue writes the next layer's slice planes",
+           "frac_of_engine_peak": fl_exec / ms / 1e9 / (PEAK_BF16_MFMA_TFLOPS / 6.0)}
     # the production loop with augmentation: augmenter of batch i+1 on a side stream beside train step i
     from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
     tr = cpl_mixVAE(saving_folder="", device=batches[0].device, save_flag=False)
@@ -715,7 +718,9 @@ def augmenter_forward(args, batches, A, B, D, with_cpu):
                 n += 1
         e1.record()
         e1.synchronize()
-        out["bf16_config"] = {"ms_per_batch": ms16, "tflops": fl_exec / ms16 / 1e9, "augmented_step_ms_pipelined": e0.elapsed_time(e1) / n,
+        out["bf16_config"] = {"ms_per_batch": ms16, "tflops": fl_exec / ms16 / 1e9,
+                              "frac_of_engine_peak": fl_exec / ms16 / 1e9 / PEAK_BF16_MFMA_TFLOPS,
+                              "augmented_step_ms_pipelined": e0.elapsed_time(e1) / n,
                               "augmented_cells_per_s": B / (e0.elapsed_time(e1) / n) * 1e3}
     except Exception as e:   # noqa: BLE001
         out["bf16_config"] = {"error": f"{type(e).__name__}: {e}"}

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmvae_hip.so")
-SOURCES = ["api.hip", "gemm_big.hip", "gemm_fast.hip", "gemm_bf16.hip", "chain.hip", "rowwise.hip", "consensus.hip", "augment.hip", "datapath.hip", "dp.hip"]
+SOURCES = ["api.hip", "gemm_big.hip", "gemm_fast.hip", "gemm_bf16.hip", "gemm_pp.hip", "chain.hip", "rowwise.hip", "consensus.hip", "augment.hip", "datapath.hip", "dp.hip"]
 HEADERS = ["common.hpp", "couple.hpp", "tune.h", os.path.join("..", "..", "include", "mmvae.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register file); without it
 # hipcc parks loop-carried accumulators in AGPRs and copies all 64 of them out and back every K tile.
@@ -27,7 +27,7 @@ EXTRA = {"gemm_bf16.hip": ["-fno-slp-vectorize"]}
 # gemm_bf16.hip is compiled WITHOUT -amdgpu-mfma-vgpr-form: its accumulators are touched by MFMAs only (and once by the
 # epilogue), so they can live in the accumulator half of the register file and leave the 256 architectural VGPRs to
 # operand fragments in flight
-DROP = {"gemm_bf16.hip": ["-amdgpu-mfma-vgpr-form=1"]}
+DROP = {"gemm_bf16.hip": ["-amdgpu-mfma-vgpr-form=1"], "gemm_pp.hip": ["-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:

@@ -193,6 +193,7 @@ struct AugLayer {         // offsets in floats into the packed buffer
     int N, K, ldw;
     int64_t pl;           // the weight's three bf16 slice planes [3][Np][Kp] (fp32x3 engine; gemm_bf16.hip), Np = N padded to
     int Np, Kp;           // whole 128-row tiles, Kp = ldw padded to whole K tiles of 32
+    int64_t tp;           // the same three slices as TILED planes (gemm_pp.hip: [3][ceil(ldw / 16)][N rounded up to 256][16] bf16)
 };
 struct AugPacked {
     AugLayer g[10];          // fc1 fc2 fc3 fc4 fc5[:, :n]  fc7 fc8 fc9 fc10 fc11
@@ -222,6 +223,7 @@ static AugPacked aug_packed_layout(const mmvae_aug_dims& d) {
         g.Np = (g.N + 127) / 128 * 128;
         g.Kp = (g.ldw + 31) / 32 * 32;
         g.pl = take((int64_t)3 * g.Np * g.Kp / 2);     // bf16: two per float
+        g.tp = take(3 * tp_plane_elems(g.N, g.ldw) / 2);
     }
     p.noise_w = take((int64_t)NZ * NZ); p.z_sc = take(NZ); p.z_sh = take(NZ);
     p.w5b = take((int64_t)N5 * NZ); p.sc5 = take(N5); p.sh5 = take(N5);
@@ -232,7 +234,12 @@ static AugPacked aug_packed_layout(const mmvae_aug_dims& d) {
     return p;
 }
 
-struct AugWs { int64_t h1, h2, h3, h4, P, H6, h7, h8, h9, h10, total; int ld1, ld3, ld5; };
+struct AugWs {
+    int64_t h1, h2, h3, h4, P, H6, h7, h8, h9, h10, total; int ld1, ld3, ld5;
+    // planes x planes engine (gemm_pp.hip): the activations as tiled slice planes (three planes' room each; the bf16
+    // configuration fills one), written by the producing layer's epilogue; slab scratch for K splits
+    int64_t tx, t1, t2, t3, t4, t6, t7, t8, t9, t10, scratch, scratch_floats;
+};
 static AugWs aug_ws_layout(const mmvae_aug_dims& d, int trunk_rows) {
     AugWs w{};
     int64_t off = 0;
@@ -241,6 +248,11 @@ static AugWs aug_ws_layout(const mmvae_aug_dims& d, int trunk_rows) {
     const int64_t T = trunk_rows, R = (int64_t)d.A * d.B;
     w.h1 = take(T * w.ld1); w.h2 = take(T * w.ld1); w.h3 = take(T * w.ld3); w.h4 = take(T * w.ld3); w.P = take(T * w.ld5);
     w.H6 = take(R * w.ld5); w.h7 = take(R * w.ld3); w.h8 = take(R * w.ld3); w.h9 = take(R * w.ld1); w.h10 = take(R * w.ld1);
+    auto tpl = [&](int rows, int K) { return take(3 * tp_plane_elems(rows, K) / 2); };
+    w.tx = tpl((int)T, d.D); w.t1 = tpl((int)T, d.N1); w.t2 = tpl((int)T, d.N1); w.t3 = tpl((int)T, d.N3); w.t4 = tpl((int)T, d.N3);
+    w.t6 = tpl((int)R, d.N5); w.t7 = tpl((int)R, d.N3); w.t8 = tpl((int)R, d.N3); w.t9 = tpl((int)R, d.N1); w.t10 = tpl((int)R, d.N1);
+    w.scratch_floats = 4 * T * (int64_t)rup(d.N1, 8);      // K-split slabs of the trunk's long-K layers
+    w.scratch = take(w.scratch_floats);
     w.total = off;
     return w;
 }
@@ -461,6 +473,8 @@ int mmvae_aug_pack(const mmvae_aug_dims* d, const mmvae_aug_tensors* t, float* p
         // slice planes of the packed (zero-padded) weight for the fp32x3 engine
         if (int rc = launch_presplit_one(s, packed + g.w, g.ldw, g.N, g.ldw, g.Np, g.Kp, reinterpret_cast<unsigned short*>(packed + g.pl)))
             return rc;
+        if (int rc = launch_tp_from_f32(s, packed + g.w, g.ldw, g.N, g.ldw, 3, tp_make(reinterpret_cast<unsigned short*>(packed + g.tp), g.N, g.ldw)))
+            return rc;
         if (mi == 4) continue;                                  // fc5's affine is applied in the latent kernel
         if (mi == 10) packa(t->b[10], nullptr, nullptr, nullptr, nullptr, 0.f, g.N, g.sc, g.sh);
         else packa(t->b[mi], t->bn_mean[mi], t->bn_var[mi], nullptr, nullptr, eps, g.N, g.sc, g.sh);
@@ -500,6 +514,52 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     float* w = reinterpret_cast<float*>(ws);
     const int ft = gemm_bf16 == 2 ? 98 : gemm_bf16 ? 99 : (ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0);
     int rc;
+    const int tune_tile = ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0;
+    if (gemm_bf16 && tune_tile != 90) {
+        // planes x planes engine (gemm_pp.hip): every layer's epilogue writes the next layer's operand as tiled slice planes
+        // (three exact slices: fp32x3; one rounded plane: the bf16 configuration).  MMVAE_AUG_TILE=90: the tile engine of
+        // gemm_bf16.hip as before (A/B timing); 1..3 (+ 10 KS): forced tile / K split for every layer.
+        const int NP = gemm_bf16 == 2 ? 3 : 1;
+        auto tpa = [&](int64_t off, int rows, int K) { return tp_make(reinterpret_cast<unsigned short*>(w + off), rows, K); };
+        auto tpw = [&](int i) {
+            return tp_make(const_cast<unsigned short*>(reinterpret_cast<const unsigned short*>(packed + L.g[i].tp)), L.g[i].N, L.g[i].ldw);
+        };
+        const TPlanes X = tpa(W.tx, T, d->D), H1 = tpa(W.t1, T, d->N1), H2 = tpa(W.t2, T, d->N1), H3 = tpa(W.t3, T, d->N3),
+                      H4 = tpa(W.t4, T, d->N3), H6 = tpa(W.t6, R, d->N5), H7 = tpa(W.t7, R, d->N3), H8 = tpa(W.t8, R, d->N3),
+                      H9 = tpa(W.t9, R, d->N1), H10 = tpa(W.t10, R, d->N1);
+        float* const scr = w + W.scratch;
+        auto layer = [&](int i, const TPlanes& in, int M, bool relu, bool affine, float* out32, int64_t ld32, int nc32, const TPlanes* outp) {
+            // the input's K steps cover its real width rounded up to 16; the weight planes' cover ldw (>= K, zero beyond K)
+            TPlanes b = tpw(i);
+            TPlanes a = in;
+            if (a.KT > b.KT) a.KT = b.KT; else b.KT = a.KT;     // (equal unless the producer's width was padded differently)
+            return launch_pp_gemm(s, NP, a, b, M, L.g[i].N, packed + L.g[i].sc, packed + L.g[i].sh, affine, relu, out32, ld32, nc32, outp,
+                                  scr, W.scratch_floats, tune_tile);
+        };
+        if ((rc = launch_tp_from_f32(s, x, d->D, T, d->D, NP, X))) return rc;
+        if ((rc = layer(0, X, T, true, true, nullptr, 0, 0, &H1))) return rc;
+        if ((rc = layer(1, H1, T, true, true, nullptr, 0, 0, &H2))) return rc;
+        if ((rc = layer(2, H2, T, true, true, nullptr, 0, 0, &H3))) return rc;
+        if ((rc = layer(3, H3, T, true, true, nullptr, 0, 0, &H4))) return rc;
+        if ((rc = layer(4, H4, T, false, false, w + W.P, W.ld5, W.ld5, nullptr))) return rc;
+        {
+            const size_t shm = aug_latent_lds_bytes(*d);
+            if (shm > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aug_latent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            // (two rows per wave; one workgroup per CU with five rows per wave measured 69 against 45 us: the rows' dot-product
+            // loops, not the 43 KB of weights every workgroup stages, are what the kernel spends its time on)
+            const int blocks = (int)imin64(cdiv64(R, AL_NW * 2), 1024);
+            hipLaunchKernelGGL(k_aug_latent, dim3(blocks), dim3(64 * AL_NW), shm, s, packed, L, d->A, d->B, d->N5, d->Z, d->NZ,
+                               shared ? 1 : 0, w + W.P, W.ld5, z0, eps_n, scale, s_out, w + W.H6);
+            HIP_LAUNCH_CHECK("k_aug_latent");
+        }
+        if ((rc = launch_tp_from_f32(s, w + W.H6, W.ld5, R, d->N5, NP, H6))) return rc;
+        if ((rc = layer(5, H6, R, true, true, nullptr, 0, 0, &H7))) return rc;
+        if ((rc = layer(6, H7, R, true, true, nullptr, 0, 0, &H8))) return rc;
+        if ((rc = layer(7, H8, R, true, true, nullptr, 0, 0, &H9))) return rc;
+        if ((rc = layer(8, H9, R, true, true, nullptr, 0, 0, &H10))) return rc;
+        return layer(9, H10, R, true, true, x_aug, d->D, d->D, nullptr);
+    }
     // trunk: once per cell when the arms share x
     // (the first layer may split K into slabs: the buffers of the last two hidden layers, h9 and h10, are adjacent and not in use yet)
     if ((rc = aug_gemm(s, ft, true, true, x, d->D, T, packed, L.g[0], w + W.h1, W.ld1, w + W.h9, W.total - W.h9))) return rc;

@@ -873,6 +873,16 @@ int launch_bf16_affine(hipStream_t s, bool relu, bool affine, const float* A, in
                        float* scratch = nullptr, int64_t scratch_floats = 0 /*room for split-K slabs of layers with few tiles and a long K*/);
 // fp32 [R][C] (row pitch ld) -> three bf16 slice planes [3][Rp][Cp], zero-padded (fp32x3 engine)
 int launch_presplit_one(hipStream_t s, const float* src, int64_t ld, int R, int C, int Rp, int Cp, unsigned short* dst);
+// planes x planes GEMM (gemm_pp.hip): tiled slice planes of a matrix X [R][K] -- NP planes (3 exact slices / 1 rounded), each
+// [KT = ceil(K / 16)][Rp = R rounded up to 256][16] bf16, zero for k >= K
+struct TPlanes { unsigned short* p; int64_t plane; int Rp, KT; };
+inline int tp_rp(int R) { return rup(R, 256); }
+inline int tp_kt(int K) { return cdiv(K, 16); }
+inline int64_t tp_plane_elems(int R, int K) { return (int64_t)tp_kt(K) * tp_rp(R) * 16; }
+inline TPlanes tp_make(unsigned short* p, int R, int K) { return TPlanes{p, tp_plane_elems(R, K), tp_rp(R), tp_kt(K)}; }
+int launch_tp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst);
+int launch_pp_gemm(hipStream_t s, int NP, TPlanes a, TPlanes b, int M, int N, const float* scale, const float* shift, bool affine, bool relu,
+                   float* out32, int64_t ld32, int ncols32, const TPlanes* outp, float* scratch, int64_t scratch_floats, int force = 0);
 // evaluation labels / consensus (consensus.hip)
 int launch_classify(const float* cc, int64_t n_cells, int C, int32_t* labels, hipStream_t s);
 int launch_confmat(const int32_t* labels, int A, int64_t n, int C, int64_t* counts, hipStream_t s);

@@ -4,7 +4,8 @@
 // G = arms x (workgroups per arm) workgroups of 256 threads (four waves; wave w owns columns [32 w, 32 w + 32) of a 100-wide layer),
 // all resident.  Per "layer" every workgroup adds its block sums of 100 columns to its arm's accumulator set and then needs the
 // COMPLETE sums of its own columns before it can go on.
-//   counter   round 3's protocol (chain.hip k_enc_fwd_fused): 6 slots per column by agent-scope atomics, s_waitcnt vmcnt(0),
+//   counter   round 3's protocol (with `replicas` copies of the set: workgroup b adds to copy b % replicas, the reader sums them)
+//             round 3's protocol (chain.hip k_enc_fwd_fused): 6 slots per column by agent-scope atomics, s_waitcnt vmcnt(0),
 //             __syncthreads, one atomic on the arm's done counter, one lane polls it, __syncthreads, the slots are read (sc1 loads)
 //   counted   the count travels IN the data: every slot is (piece << 12) + 1, eight 36-bit pieces per column (two sums x four),
 //             a wave polls the eight slots of its own columns until every low field reads (workgroups per arm); no counter, no
@@ -27,7 +28,7 @@ __device__ __forceinline__ void spin(unsigned long long cycles) {
 // sets: [nsets][arms][SLOTS][ACC_W] int64, zeroed; done: [nsets][arms][32] u32
 template <int MODE>
 __global__ __launch_bounds__(256) void k_xchg(long long* sets, unsigned* done, int per_arm, int layers, int iters, unsigned long long delay,
-                                              unsigned* bad, unsigned* abort_) {
+                                              unsigned* bad, unsigned* abort_, int R) {
     constexpr int SLOTS = MODE == 0 ? 6 : 8;
     const int arms = gridDim.x / per_arm, arm = blockIdx.x / per_arm, blk = blockIdx.x % per_arm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = wv * 32 + (lane & 31);
@@ -38,12 +39,14 @@ __global__ __launch_bounds__(256) void k_xchg(long long* sets, unsigned* done, i
     for (int it = 0; it < iters && ok; ++it)
         for (int l = 0; l < layers && ok; ++l) {
             const size_t si = (size_t)(it * layers + l) * arms + arm;
-            long long* set = sets + si * SLOTS * ACC_W;
+            long long* set = sets + si * 16 * SLOTS * ACC_W;     // up to 16 replicas of a set (MODE 0: workgroup blk adds to replica blk % R)
             const long long v = (long long)(blk + col + 1);
             if (MODE == 0) {
-                if (mine)
+                if (mine) {
+                    long long* rs = set + (size_t)(blk % R) * SLOTS * ACC_W;
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) __hip_atomic_fetch_add(set + s * ACC_W + col, v + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int s = 0; s < SLOTS; ++s) __hip_atomic_fetch_add(rs + s * ACC_W + col, v + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 spin(delay);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -62,11 +65,16 @@ __global__ __launch_bounds__(256) void k_xchg(long long* sets, unsigned* done, i
                 ok = sh_ok != 0;
                 if (mine && ok) {
                     const long long want0 = (long long)per_arm * (col + 1) + (long long)per_arm * (per_arm - 1) / 2;
+                    long long q[SLOTS];
 #pragma unroll
-                    for (int s = 0; s < SLOTS; ++s) {
-                        const long long q = __hip_atomic_load(set + s * ACC_W + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (q != want0 + (long long)per_arm * s) ++nerr;
-                    }
+                    for (int s = 0; s < SLOTS; ++s) q[s] = 0;
+                    for (int r = 0; r < R; ++r)
+#pragma unroll
+                        for (int s = 0; s < SLOTS; ++s)
+                            q[s] += __hip_atomic_load(set + ((size_t)r * SLOTS + s) * ACC_W + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int s = 0; s < SLOTS; ++s)
+                        if (q[s] != want0 + (long long)per_arm * s) ++nerr;
                 }
             } else {
                 if (mine)
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void k_xchg(long long* sets, unsigned* done, i
 
 template <int MODE>
 static int run(const char* name, int per_arm, int arms, int layers, int iters, unsigned long long delay, long long* sets, size_t set_bytes,
-               unsigned* done, size_t done_bytes, unsigned* bad, unsigned* abort_) {
+               unsigned* done, size_t done_bytes, unsigned* bad, unsigned* abort_, int R) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
@@ -114,7 +122,7 @@ static int run(const char* name, int per_arm, int arms, int layers, int iters, u
         CK(hipMemset(sets, 0, set_bytes)); CK(hipMemset(done, 0, done_bytes)); CK(hipMemset(bad, 0, 4)); CK(hipMemset(abort_, 0, 4));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_xchg<MODE>, dim3(per_arm * arms), dim3(256), 0, 0, sets, done, per_arm, layers, iters, delay, bad, abort_);
+        hipLaunchKernelGGL(k_xchg<MODE>, dim3(per_arm * arms), dim3(256), 0, 0, sets, done, per_arm, layers, iters, delay, bad, abort_, R);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -124,7 +132,7 @@ static int run(const char* name, int per_arm, int arms, int layers, int iters, u
         CK(hipMemcpy(&a, abort_, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost));
         ab |= a; nb += b;
     }
-    printf("%-8s per_arm=%3d arms=%d delay=%5llu cycles  %6.2f us per layer%s   wrong values: %u\n", name, per_arm, arms, delay,
+    printf("%-8s per_arm=%3d arms=%d replicas=%2d delay=%5llu cycles  %6.2f us per layer%s   wrong values: %u\n", name, per_arm, arms, R, delay,
            best * 1e3f / (iters * layers), ab ? "  (ABORTED)" : "", nb);
     return 0;
 }
@@ -140,11 +148,12 @@ int main(int argc, char** argv) {
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc1, k_xchg<1>, 256, 0));
     if (per_arm * arms > cus * (pc0 < pc1 ? pc0 : pc1) / 2) { printf("grid may not be co-resident\n"); return 1; }
     const size_t nsets = (size_t)iters * layers * arms;
-    const size_t set_bytes = nsets * 8 * ACC_W * 8, done_bytes = nsets * 32 * 4;
+    const size_t set_bytes = nsets * 16 * 8 * ACC_W * 8, done_bytes = nsets * 32 * 4;
     long long* sets; unsigned *done, *bad, *abort_;
     CK(hipMalloc(&sets, set_bytes)); CK(hipMalloc(&done, done_bytes)); CK(hipMalloc(&bad, 128)); CK(hipMalloc(&abort_, 128));
     // clock rate of s_memtime: 100 MHz constant on this part, so `delay` is in 10 ns units
-    if (run<0>("counter", per_arm, arms, layers, iters, delay, sets, set_bytes, done, done_bytes, bad, abort_)) return 1;
-    if (run<1>("counted", per_arm, arms, layers, iters, delay, sets, set_bytes, done, done_bytes, bad, abort_)) return 1;
+    for (int R = 1; R <= 16; R *= 2)
+        if (run<0>("counter", per_arm, arms, layers, iters, delay, sets, set_bytes, done, done_bytes, bad, abort_, R)) return 1;
+    if (run<1>("counted", per_arm, arms, layers, iters, delay, sets, set_bytes, done, done_bytes, bad, abort_, 1)) return 1;
     return 0;
 }
