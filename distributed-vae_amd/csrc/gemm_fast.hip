@@ -1373,7 +1373,7 @@ int launch_fc1_fwd_fast(const Ctx& c, const float* params, const float* x, int64
     const bool use_mask = c.h.training && c.h.x_drop > 0.f;
     const int KS = c.lay.sp.ks_fc1;
     const int ablate = c.tune(MMVAE_TUNE_ABLATE);   // timing experiments only
-    const int padlds = c.tune(MMVAE_TUNE_PADLDS);   // occupancy experiments
+    const int padlds = 0;
     dim3 grid(cdiv(d.B, 128), KS, d.A);
     const uint32_t* bits = reinterpret_cast<const uint32_t*>(c.ws + c.lay.xbits);
     if (d.H == 100) {

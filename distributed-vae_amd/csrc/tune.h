@@ -10,7 +10,7 @@ enum {
     MMVAE_TUNE_AUG_TILE = 3,       // augmenter GEMM tile 11 12 21 22 (1 = 64, 2 = 128)
     MMVAE_TUNE_ABLATE_C = 4,       // chain kernels: timing ablations / cycle stamps (bit 3: stamps; results wrong with bits 0..2)
     MMVAE_TUNE_ABLATE = 5,         // fc1 forward ablations (fp32 matrix-instruction kernels)
-    MMVAE_TUNE_PADLDS = 6,         // fc1 forward: extra dynamic LDS (occupancy experiments)
+    // 6: retired (was MMVAE_TUNE_PADLDS, extra dynamic LDS of the fp32 fc1 kernels)
     MMVAE_TUNE_CHAIN_ROWS_FWD = 7, // cells per workgroup of the forward chain launches: 0 = 64 (as the backward chains), > 0 = this
                                    // many (multiple of 8, <= 64; measured: no gain from smaller blocks, api.hip make_layout)
     MMVAE_TUNE_DW11_LDS = 9,       // dW11 beside the backward chain: KB of dynamic LDS added to its workgroups (40 fills the CU: kernels
