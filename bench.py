@@ -161,13 +161,28 @@ def bf16_config(args, model_args, data, batches, nb, A, B, D, H, L, C, S, P, wor
 
     dt32, ev32, loss32 = timed(step32)
     dt, ev, loss = timed(step16) if storage else (dt32, ev32, loss32)
+    # the same K steps through a FIXED RANDOM permutation of the resident rows (drawn outside the timed region): what a shuffled
+    # epoch asks of the 16-byte bf16 row reads; `value` above uses contiguous row sets
+    shuffled = None
+    if storage:
+        gperm = torch.Generator(device=dev).manual_seed(977 + rank)
+        perm = torch.randperm(nb * B, generator=gperm, device=dev)
+        prows = [perm[i * B:(i + 1) * B].contiguous() for i in range(nb)]
+
+        def step16p(i):
+            if world > 1 or args.rehearse_dp:
+                return DD.dp_train_step(m, None, 1.0, opt, rehearse=args.rehearse_dp, rows=(data, prows[i % nb], data16))
+            return m.fused_train_step_rows(data, prows[i % nb], 1.0, opt, do_adam=True, data16=data16)
+        dtp, evp, _ = timed(step16p)
+        shuffled = {"ms_per_step": dtp / args.steps * 1e3, "value": world * B * args.steps / dtp, "ms_per_step_hip_events": evp,
+                    "rows": "a fixed random permutation of the resident rows (torch.randperm, seeded), B per step"}
     cells = world * B * args.steps / dt
     by_cell = A * (10 * D + 80 * H + 36 * P / B)
     out = {"value": cells, "unit": "cells/s", "ms_per_step": dt / args.steps * 1e3, "ms_per_step_hip_events": ev,
            "dtype": "bf16 operands in the five D x H GEMMs, f32 accumulation and everything else", "n_gpus": world,
            "storage": "bf16 copy of the resident matrix, dZ11 as bf16 (mmvae_train_step_rows with data_bf16)" if storage
                       else "fp32 (gene count or row pitch not a multiple of 8)",
-           "last_loss": loss, "bytes_per_cell_algorithmic": by_cell,
+           "last_loss": loss, "bytes_per_cell_algorithmic": by_cell, "shuffled_rows": shuffled,
            "roofline": {"bound": "hbm", "achieved": cells / world * by_cell / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": cells / world * by_cell / 1e9 / PEAK_HBM_GBS,
                         "note": "whole step, per GPU: algorithmic bytes per cell (SURVEY.md 8d, bf16 operands) x cells/s"},

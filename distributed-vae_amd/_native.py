@@ -236,7 +236,9 @@ def shared_stream(device, name: str) -> "torch.cuda.Stream":
     key = (torch.device(device).index or 0, name)
     st = _STREAMS.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device, priority=int(os.environ.get("MMVAE_SIDE_PRIORITY", "-1")))
+        # (MMVAE_SIDE_PRIORITY / MMVAE_PRODUCE_PRIORITY: A/B timing; -1 = high)
+        prio = os.environ.get("MMVAE_PRODUCE_PRIORITY" if name == "produce" else "MMVAE_SIDE_PRIORITY", "-1")
+        st = torch.cuda.Stream(device=device, priority=int(prio))
         _STREAMS[key] = st
     return st
 
@@ -438,7 +440,10 @@ def to_bf16(data: torch.Tensor) -> torch.Tensor:
         raise NativeError("to_bf16 needs a CUDA tensor (no CPU fallback)")
     assert data.dim() == 2 and data.dtype == torch.float32 and data.stride(1) == 1
     ld = int(data.stride(0))
-    out = torch.empty(data.shape[0] * ld, dtype=torch.bfloat16, device=data.device).as_strided(data.shape, data.stride())
+    # (a column-offset view of a wider matrix spans (rows - 1) * ld + D elements, not rows * ld: the copy owns exactly that,
+    # rounded up to whole 8-byte pieces; the kernel touches only the rows' own columns)
+    span = (data.shape[0] - 1) * ld + ((data.shape[1] + 3) // 4) * 4
+    out = torch.empty(span, dtype=torch.bfloat16, device=data.device).as_strided(data.shape, data.stride())
     check(lib().mmvae_to_bf16(_ptr(data), ld, data.shape[0], data.shape[1], _ptr(out), _stream(data.device)), "mmvae_to_bf16")
     return out
 

@@ -124,6 +124,11 @@ class cpl_mixVAE:
         self.device = get_device(device)
         self.aug_model, self.aug_param, self.netA = None, None, None
         self.pipeline = os.environ.get("MMVAE_PIPELINE", "1") != "0"   # see epoch_steps
+        # bf16 configuration with a device-resident loader: the step reads x through a bf16 COPY of the matrix and keeps dZ11 as
+        # bf16 (the reconstruction loss then sees bf16-rounded x; +50 % resident memory).  An attribute of the trainer (default
+        # from MMVAE_BF16_STORAGE, on), recorded per run in ``used_bf16_storage`` and in train()'s history.
+        self.bf16_storage = os.environ.get("MMVAE_BF16_STORAGE", "1") != "0"
+        self.used_bf16_storage = False
         if aug_file:                                            # cpl_mixvae.py:182-186
             from .augmentation import mk_augmenter
             self.aug_model, self.aug_param, netA = mk_augmenter(aug_file, load_weights)
@@ -246,15 +251,15 @@ class cpl_mixVAE:
             # the bf16 configuration on bf16 storage: the loader keeps a bf16 copy of its matrix (made
             # once) and the GEMMs read that; MMVAE_BF16_STORAGE=0 keeps them on the fp32 matrix
             data16 = None
-            if (getattr(self.model, "gemm_dtype", "fp32") == "bf16" and hasattr(loader, "data_bf16")
-                    and os.environ.get("MMVAE_BF16_STORAGE", "1") != "0"):
+            if getattr(self.model, "gemm_dtype", "fp32") == "bf16" and hasattr(loader, "data_bf16") and self.bf16_storage:
                 data16 = loader.data_bf16()
+            self.used_bf16_storage = data16 is not None
             try:
                 buf = self._step_rows(loader.data, first_rows, data16)
             except NotImplementedError:
                 self._rows_ok = False
-                if hasattr(loader, "_auto_epoch") and loader._auto_epoch is not None:
-                    loader._auto_epoch -= 1          # the abandoned iterator had taken this epoch's permutation
+                if hasattr(loader, "unread_epoch"):
+                    loader.unread_epoch()            # the abandoned iterator had taken this epoch's permutation
             else:
                 yield buf
                 for rows in it:
@@ -421,6 +426,7 @@ class cpl_mixVAE:
         if rank in (None, 0, dev) or not D.is_dist():
             print("warning: stopping pruning")                              # :1008
             print("Training is done!")                                      # :1446
+        hist["bf16_storage"] = bool(self.used_bf16_storage)    # (not in the reference: which copy of x the run's losses were taken against)
         return hist
 
     @torch.no_grad()

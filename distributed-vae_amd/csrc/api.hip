@@ -234,9 +234,9 @@ static int make_ctx(Ctx& c, const mmvae_dims* d, const mmvae_hyper* h, void* ws,
     }
     // the fixed-point batch-sum accumulators (common.hpp acc_add) hold 2^12 addends of the largest magnitude per column
     // without a carry between their slots; the producer with the fewest cells per workgroup is the latent backward kernel
-    if (h->training && cdiv(d->B, LAT_ROWS_BWD) > 4096) {
+    if (h->training && cdiv(d->B, ACC_MIN_PRODUCER_ROWS) > ACC_MAX_ADDENDS) {
         set_error("training mode takes at most %d cells per batch and rank (got B=%d): capacity of the exact batch-sum accumulators",
-                  4096 * LAT_ROWS_BWD, d->B);
+                  ACC_MAX_ADDENDS * ACC_MIN_PRODUCER_ROWS, d->B);
         return MMVAE_E_UNSUPPORTED;
     }
     c.d = *d;

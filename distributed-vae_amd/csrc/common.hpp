@@ -328,6 +328,15 @@ constexpr int LAT_ROWS = 48;
 constexpr int LAT_ROWS_BWD = MMVAE_LAT_ROWS_BWD;
 constexpr int LATB_NW = 8;    // waves per workgroup of the latent backward kernel
 constexpr int LATB_NR = LAT_ROWS_BWD / LATB_NW;   // cells per wave, processed side by side
+// The exact batch-sum accumulators (acc_add below) hold ACC_MAX_ADDENDS addends of the largest magnitude per column without a
+// carry between their slots; a training batch may therefore have at most ACC_MAX_ADDENDS x (the fewest cells any producing
+// workgroup adds at once) cells per rank.  Producers: the fc1 epilogue and the coupling (32-cell blocks), the chain kernels
+// (CHAIN_ROWS, or the forward launches' smaller blocks, >= 8), the latent kernels (LAT_ROWS / LAT_ROWS_BWD).
+constexpr int ACC_MAX_ADDENDS = 4096;
+constexpr int ACC_MIN_PRODUCER_ROWS = LAT_ROWS_BWD < 8 ? LAT_ROWS_BWD : 8;
+static_assert(ACC_MIN_PRODUCER_ROWS <= LAT_ROWS_BWD && ACC_MIN_PRODUCER_ROWS <= LAT_ROWS && ACC_MIN_PRODUCER_ROWS <= CHAIN_ROWS &&
+              ACC_MIN_PRODUCER_ROWS <= 32 && ACC_MIN_PRODUCER_ROWS <= 8,
+              "a producer of batch sums with fewer cells per workgroup lowers the batch-size cap of make_ctx: name it here");
 
 template <bool VEC, int NT>
 __device__ __forceinline__ void stats_from_partials_t(const float* __restrict__ part, int nblk, int B, int PR, int W,

@@ -55,16 +55,19 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ d
 
 
 // dst[r][c] = bf16(src[r][c]) (round to nearest even, v_cvt_pk_bf16_f32: the rounding the one-plane engine applies to its
-// operands on their way into LDS), c < D rounded up to the row pitch: the bf16 copy of a resident matrix, made once per data set
+// operands on their way into LDS) for c < D rounded up to 4: the bf16 copy of a resident matrix, made once per data set.  Only
+// the row's own columns are touched -- for a column-offset view of a wider matrix (ld > D, data pointing into the rows) the
+// pitch behind the LAST row's columns is not part of the view's storage and is neither read nor written.
 __global__ __launch_bounds__(256) void k_to_bf16(const float* __restrict__ src, int64_t ld, int64_t n_rows, int D, unsigned short* __restrict__ dst) {
-    const int64_t quads = ld >> 2;                       // ld % 4 == 0: whole rows, pitch included (columns >= D are never read)
+    const int64_t quads = (D + 3) >> 2;                  // ld % 4 == 0 and ld >= D: the last quad of a row stays inside its pitch
     const int64_t n = n_rows * quads;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float4 v = *reinterpret_cast<const float4*>(src + 4 * i);
+        const int64_t r = i / quads, at = r * ld + 4 * (i - r * quads);
+        const float4 v = *reinterpret_cast<const float4*>(src + at);
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         bf16x2 a, b;
         a[0] = (__bf16)v.x; a[1] = (__bf16)v.y; b[0] = (__bf16)v.z; b[1] = (__bf16)v.w;
-        *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+        *reinterpret_cast<uint2*>(dst + at) = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
     }
 }
 
@@ -90,7 +93,7 @@ extern "C" int mmvae_to_bf16(const float* src, int64_t ld, int64_t n_rows, int32
         set_error("to_bf16: needs ld %% 4 == 0, a 16-byte aligned source and an 8-byte aligned destination");
         return MMVAE_E_UNSUPPORTED;
     }
-    const int64_t n = n_rows * (ld >> 2);
+    const int64_t n = n_rows * (int64_t)((D + 3) >> 2);
     hipLaunchKernelGGL(k_to_bf16, dim3((unsigned)imin64(cdiv64(n, 256 * 4), 8192)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, ld, n_rows, D, dst);
     HIP_LAUNCH_CHECK("k_to_bf16");
     return 0;

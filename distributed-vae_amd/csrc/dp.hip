@@ -24,10 +24,19 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
-        }
+        // the RCCL this process has mapped already (PyTorch-ROCm ships its own librccl.so, possibly under another soname than
+        // the system's): its symbols first, so that no second RCCL runtime ends up in the process; only then the names
+        if (dlsym(RTLD_DEFAULT, "ncclCommInitRank") && dlsym(RTLD_DEFAULT, "ncclAllReduce")) r.lib = dlopen(nullptr, RTLD_NOW);
+        if (!r.lib)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+                if (r.lib) break;
+            }
+        if (!r.lib)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.lib) break;
+            }
         if (!r.lib) return;
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));

@@ -89,6 +89,8 @@ class DirectComm:
     def allreduce_mean_(self, buf: torch.Tensor):
         from . import _native as N
         assert buf.is_cuda and buf.dtype == torch.float32 and buf.is_contiguous()
+        if buf.device.index != (self.device.index or 0):
+            raise N.NativeError(f"DirectComm of {self.device} asked to reduce a buffer on {buf.device}")
         N.check(N.lib().mmvae_allreduce_grads(self._comm, buf.data_ptr(), buf.numel(),
                                               torch.cuda.current_stream(buf.device).cuda_stream), "mmvae_allreduce_grads")
         return buf
@@ -111,7 +113,21 @@ def direct_comm(device) -> "DirectComm":
         ws = dist.get_world_size() if dist.is_initialized() else 1
         rk = dist.get_rank() if dist.is_initialized() else 0
         _DIRECT[key] = DirectComm(rk, ws, device)
+        if len(_DIRECT) == 1:
+            import atexit
+            atexit.register(close_direct_comms)       # communicators are destroyed before the interpreter tears torch down
     return _DIRECT[key]
+
+
+def close_direct_comms():
+    """Destroy the process's library-owned RCCL communicators (also registered with ``atexit``); call it ahead of
+    ``dist.destroy_process_group()``."""
+    for comm in list(_DIRECT.values()):
+        try:
+            comm.close()
+        except Exception:   # noqa: BLE001
+            pass
+    _DIRECT.clear()
 
 
 def dp_train_step(model, xs, temp, optimizer, rehearse: bool = False, rows=None):

@@ -186,9 +186,19 @@ class DeviceLoader:
     def data_bf16(self):
         """The bf16 copy of ``self.data`` for the bf16 configuration's row-indexed step (made on first use, once per data
         set: ``_native.to_bf16``), or None where that step cannot use it (gene count or row pitch not a multiple of 8)."""
-        if self._data16 is None and self.data.device.type == "cuda" and self.data.shape[1] % 8 == 0 and self.data.stride(0) % 8 == 0:
+        if self.data.device.type != "cuda" or self.data.shape[1] % 8 != 0 or self.data.stride(0) % 8 != 0:
+            return None
+        ver = self.data._version                      # an in-place edit of the matrix makes the copy stale
+        if self._data16 is None or getattr(self, "_data16_version", None) != ver:
             self._data16 = N.to_bf16(self.data)
+            self._data16_version = ver
         return self._data16
+
+    def unread_epoch(self):
+        """Hand an epoch back unconsumed: the caller took this epoch's rows (``iter_rows``) but cannot use them and will draw
+        the same epoch again through another iterator (the trainer's fallback from row-indexed steps to gathered batches)."""
+        if self._auto_epoch is not None:
+            self._auto_epoch -= 1
 
     def _epoch_rows(self) -> torch.Tensor:
         """Row indices (into ``self.data``) of this rank's epoch, in visiting order, and the epoch bookkeeping of one pass.

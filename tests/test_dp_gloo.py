@@ -93,3 +93,30 @@ def test_single_process_helpers_are_noops():
     assert torch.equal(D.allreduce_sum_(t.clone()), t)
     D.broadcast_flat(t)
     assert D.shard_rows(10, 1, 2) == (5, 10)
+
+
+def _solo(rank, ws, port, out_dir):
+    """BASELINE.json configs[0] as it is worded: a process group of world_size = 1 on the CPU over gloo."""
+    sys.path.insert(0, ROOT)
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd import dist as D
+    D.init_dist_env(rank, ws, "127.0.0.1", port, backend="gloo")
+    assert D.dist.is_initialized() and D.dist.get_world_size() == 1 and D.dist.get_backend() == "gloo"
+    assert not D.is_dist()                       # one rank: every helper is the identity, no collective is issued
+    t = torch.arange(6.0)
+    assert torch.equal(D.allreduce_mean_(t.clone()), t) and torch.equal(D.allreduce_sum_(t.clone()), t)
+    D.broadcast_flat(t)
+    assert D.shard_rows(1000, 0, 1) == (0, 1000)
+    # the real collectives of a one-rank group are identities too
+    u = t.clone()
+    D.dist.all_reduce(u)
+    assert torch.equal(u, t)
+    D.dist.barrier()
+    D.dist.destroy_process_group()
+    open(os.path.join(out_dir, "ok"), "w").write("1")
+
+
+def test_world_size_one_gloo_group(tmp_path):
+    from distributed_vae_amd import dist as D
+    mp.spawn(_solo, args=(1, D.find_port(), str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))

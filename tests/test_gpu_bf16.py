@@ -161,9 +161,11 @@ def test_bf16_augmenter_layers_reproduce_bf16_rounded_products(cfg):
     s, xa = m(x.to(DEV).expand(A, -1, -1), True, 0.1)
     # the host restatement rounds activations that differ from the device's by fp32 accumulation noise: a value that
     # sits on a bf16 rounding boundary may round the other way, which is one bf16 ulp (2^-8) of ONE operand element
-    # -- and every such flip propagates through the remaining layers (a chaotic comparison by construction): 2e-3 at the
-    # small shape, 6e-3 across ten layers with K up to 5032, against ~1e-2 between the bf16 and fp32 configurations
-    tol = 2e-3 if D < 2000 else 6e-3
+    # -- and every such flip propagates through the remaining layers (a chaotic comparison by construction): 4e-3 at the
+    # small shape (2.4e-3 measured on the planes x planes engine of round 4, whose fp32 accumulation order -- 256 x 256 tiles, K
+    # steps of 16 -- differs from the 128 x 128 tile engine's 0.9e-3), 6e-3 across ten layers with K up to 5032, against ~1e-2
+    # between the bf16 and fp32 configurations
+    tol = 4e-3 if D < 2000 else 6e-3
     e_s, e_x = _rel(s.cpu().double(), s_ref), _rel(xa.cpu().double(), x_ref)
     print("bf16 augmenter vs bf16-rounded oracle: s %.2e  x_aug %.2e" % (e_s, e_x))
     assert e_s < tol and e_x < tol, (e_s, e_x)

@@ -237,3 +237,39 @@ def test_split_factors_follow_the_engine_hint():
     assert got[2, 0] == [6, 6, 6, 20, 3, 4], got
     assert got[2, 1] == [6, 6, 6, 20, 3, 2], got
     assert N.TUNE_ENV["MMVAE_CHAIN_FP32"][0] == 21
+
+
+def test_batch_size_cap_of_the_exact_accumulators():
+    """Training batches above 4096 x 8 = 32768 cells per rank are refused (MMVAE_E_UNSUPPORTED -> NotImplementedError in the
+    Python layer): the fixed-point batch-sum accumulators hold 4096 addends per column and the producer with the fewest cells
+    per workgroup adds 8 at a time (csrc/common.hpp ACC_MAX_ADDENDS / ACC_MIN_PRODUCER_ROWS).  The reference has no such cap
+    (README, "differences").  No GPU needed: the check precedes every launch; an accepted size gets as far as the
+    workspace-size check (a zero-byte workspace here)."""
+    L = N.lib()
+    hyper = N.Hyper()
+    hyper.training = 1
+    hyper.x_drop = 0.5
+    buf = (C.c_char * 1024)()
+    ws = (C.addressof(buf) + 255) & ~255
+    loss = (C.c_float * 64)()
+    E_UNSUPPORTED, E_WORKSPACE = -2, -4          # include/mmvae.h
+    for B, want in ((32768, E_WORKSPACE), (32769, E_UNSUPPORTED)):
+        d = N.Dims(2, B, 256, 32, 6, 12, 2)
+        rc = L.mmvae_loss(C.byref(d), C.byref(hyper), C.c_void_p(ws), C.c_size_t(0), loss, None, None)
+        assert rc == want, (B, rc, L.mmvae_last_error_string())
+    assert b"32768" in L.mmvae_last_error_string()
+    hyper.training = 0                      # eval mode has no batch sums: no cap
+    d = N.Dims(2, 40000, 256, 32, 6, 12, 2)
+    assert L.mmvae_loss(C.byref(d), C.byref(hyper), C.c_void_p(ws), C.c_size_t(0), loss, None, None) == E_WORKSPACE
+
+
+def test_to_bf16_view_span_is_what_the_copy_allocates():
+    """A column-offset view big[:, off:] spans (rows - 1) * ld + D elements, not rows * ld: _native.to_bf16 allocates exactly that
+    (rounded up to whole 8-byte pieces) and the kernel touches only each row's own columns (csrc/datapath.hip k_to_bf16)."""
+    import inspect
+    src = inspect.getsource(N.to_bf16)
+    assert "(data.shape[0] - 1) * ld" in src
+    big = torch.zeros(6, 32)
+    v = big[:, 8:24]
+    span = (v.shape[0] - 1) * v.stride(0) + ((v.shape[1] + 3) // 4) * 4
+    assert span == 5 * 32 + 16 and v.storage_offset() + span <= big.numel()
