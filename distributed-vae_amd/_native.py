@@ -77,12 +77,9 @@ N_TUNE = 24
 # environment switch that sets each one: the LIBRARY reads
 # no environment variables, this module translates them (experiments and A/B timing only; none is needed in production)
 TUNE_ENV = {
-    "MMVAE_EVAL_CHAIN": (0, lambda v: int(int(v) == 0)), "MMVAE_DW11_AT": (1, int), "MMVAE_SIDE_SMALL": (2, int),
-    "MMVAE_AUG_TILE": (3, int), "MMVAE_ABLATE_C": (4, int), "MMVAE_ABLATE": (5, int), 
-    "MMVAE_CHAIN_ROWS_FWD": (7, int), "MMVAE_DW11_LDS": (9, int), "MMVAE_COUPLE_LATE": (10, int), "MMVAE_JOIN_LAST": (11, int), "MMVAE_FC11_ZG": (8, lambda v: int(int(v) == 0)),
-    "MMVAE_ABLATE_L": (14, int), "MMVAE_LAT_FULLWAVE": (15, int), "MMVAE_ABLATE_B": (16, int),
-    "MMVAE_BN_PARTIALS": (19, int), "MMVAE_PRESPLIT_ALL": (20, int), "MMVAE_CHAIN_FP32": (21, int),
-    "MMVAE_REDUCE11_MAIN": (22, int), "MMVAE_FUSED_CHAIN": (23, int),  "MMVAE_FORK_RECORD": (12, int), "MMVAE_COUPLE_SIDE": (13, int), "MMVAE_BF16_NARROW_FP32": (18, int),
+    "MMVAE_EVAL_CHAIN": (0, lambda v: int(int(v) == 0)), "MMVAE_AUG_TILE": (3, int), "MMVAE_ABLATE_C": (4, int), "MMVAE_ABLATE": (5, int),
+    "MMVAE_FC11_ZG": (8, lambda v: int(int(v) == 0)), "MMVAE_COUPLE_SIDE": (13, int), "MMVAE_ABLATE_L": (14, int), "MMVAE_ABLATE_B": (16, int),
+    "MMVAE_BF16_NARROW_FP32": (18, int), "MMVAE_BN_PARTIALS": (19, int), "MMVAE_PRESPLIT_ALL": (20, int), "MMVAE_CHAIN_FP32": (21, int),
 }
 TUNE_ENGINE = 17    # MMVAE_TUNE_ENGINE: the GEMM engine the caller runs (the layout's split factors are chosen for it)
 

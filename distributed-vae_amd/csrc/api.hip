@@ -141,17 +141,11 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.nblk32 = cdiv(d.B, 32);
     L.nblk64 = cdiv(d.B, 64);
     L.nblkc = cdiv(d.B, CHAIN_ROWS);
-    {
-        // cells per workgroup of the forward chain launches.  Measured at A = 2, B = 5000 (round 3): 64 cells (158 workgroups)
-        // 0.693 ms per step, 48 (210) 0.692, 40 (250: one per CU) 0.695, 32 (314) 0.753 -- a chain launch is a latency chain of
-        // fixed costs (statistics read, weight planes, barriers, the exchange), not of per-row work, so smaller blocks on the idle
-        // CUs buy nothing.  MMVAE_TUNE_CHAIN_ROWS_FWD > 0 sets another block for experiments (accumulator form only).
-        int rows = CHAIN_ROWS;
-        if (ex && ex->tune[MMVAE_TUNE_CHAIN_ROWS_FWD] > 0 && !ex->tune[MMVAE_TUNE_BN_PARTIALS])
-            rows = max(8, min(CHAIN_ROWS, (ex->tune[MMVAE_TUNE_CHAIN_ROWS_FWD] / 8) * 8));
-        L.chain_rows_fwd = rows;
-        L.nblkf = cdiv(d.B, rows);
-    }
+    // cells per workgroup of the forward chain launches.  Measured at A = 2, B = 5000 (round 3): 64 cells (158 workgroups) 0.693 ms per
+    // step, 48 (210) 0.692, 40 (250: one per CU) 0.695, 32 (314) 0.753 -- a chain launch is a latency chain of fixed costs (statistics
+    // read, weight planes, barriers, the exchange), not of per-row work, so smaller blocks on the idle CUs buy nothing.
+    L.chain_rows_fwd = CHAIN_ROWS;
+    L.nblkf = cdiv(d.B, CHAIN_ROWS);
     L.nblkl = cdiv(d.B, LAT_ROWS);
     L.sp = default_splits(d, ex);
     int64_t off = 0;
@@ -173,10 +167,8 @@ Layout make_layout(const mmvae_dims& d, const mmvae_exec* ex) {
     L.fc1_slab = take((int64_t)L.sp.ks_fc1 * A * B * NP);
     L.n11 = (L.nblk64 + 2) * (max(L.sp.ns_fc11, L.sp.ks_gd10) + 1) + cdiv(d.D, 64);
     L.fc11_part = take(A * (int64_t)L.n11 * 2 + 64);   // + diagnostic stamp counters
-    L.sync_arm_words = rup(4 * rup(max(L.nblkc, L.nblkf), 32) + 2 * 4 * 32, 64);
-    L.sync_fwd = take(A * (int64_t)L.sync_arm_words);
-    L.acc = take((int64_t)ACC_NSETS * A * ACC_SET_FLOATS);   // behind fc11_part and sync_fwd: one zero fill at the start of a forward pass
-    L.sync_bwd = take(A * (int64_t)L.sync_arm_words);       // directly behind the backward accumulator sets: one zero fill
+    L.acc = take((int64_t)ACC_NSETS * A * ACC_SET_FLOATS);   // directly behind fc11_part: one zero fill at the start of a forward pass
+    L.acc_end = off;                                        // (the backward sets are the last ones: one zero fill at the start of a backward pass)
     L.GD10_slab = take((int64_t)max(L.sp.ns_fc11, L.sp.ks_gd10) * A * B * H);
     L.DZ11 = take(A * B * D);
     L.couple_part = take(nb * 2);
@@ -334,20 +326,18 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     if ((rc = launch_bn_eval_stats(c, bn_running))) return rc;
     if (!c.h.training && !c.tune(MMVAE_TUNE_EVAL_CHAIN_OFF)) {
         if ((rc = launch_chain_fwd_enc_eval(c, params))) return rc;
-    } else if (enc_fused_ok(c)) {
-        if ((rc = launch_chain_fwd_enc_fused(c, params, bn_running, nbt))) return rc;
     } else {
         for (int layer = 2; layer <= 5; ++layer)
             if ((rc = launch_chain_fwd_enc(c, layer, params, bn_running, nbt))) return rc;
     }
-    // fork events ride on the kernels in front of the forks (the latent forward here, the fused fc11 kernel below)
-    const bool ride = !c.tune(MMVAE_TUNE_FORK_RECORD);
-    const bool t_early_ = fast && couple_done && c.side() && loss_out && !latent_only && fc11_split_path(c, params, x, xs);
+    // fork events ride on the kernels in front of the forks (the latent forward here, the fused fc11 kernel below): a recorded
+    // event is a barrier packet of its own, 6 - 7 us of idle main stream (round 3: 686 -> 681 us per step)
+    const bool t_early = fast && couple_done && c.side() && loss_out && !latent_only && fc11_split_path(c, params, x, xs);
     c.stop_used = false;
     // the coupling terms as a role of the decoder chain's launch: no fork behind the latent forward at all
-    const bool couple_role = t_early_ && !c.tune(MMVAE_TUNE_COUPLE_LATE) && dec_couple_ok(c);
+    const bool couple_role = t_early && dec_couple_ok(c);
     c.couple_in_dec = false;
-    if (ride && couple_done && c.side() && !latent_only && !couple_role && !(t_early_ && c.tune(MMVAE_TUNE_COUPLE_LATE))) c.stop_ev = c.ev(EV_LAT);
+    if (couple_done && c.side() && !latent_only && !couple_role) c.stop_ev = c.ev(EV_LAT);
     if ((rc = launch_lat_fwd(c, nz, params, bn_running, nbt, labels))) return rc;
     c.stop_ev = nullptr;
     const bool lat_rode = c.stop_used;
@@ -355,27 +345,18 @@ static int do_forward(const Ctx& c, const mmvae_noise* nz, const float* params, 
     if (latent_only) return 0;   // evaluation labels need c only: no decoder, no fc11
     Ctx cs = c;
     cs.stream = c.side();
-    // The fused step on the fast path: the coupling terms AND the T sums of the latent backward (which need nothing but
+    // The fused step on the fast path (t_early): the coupling terms AND the T sums of the latent backward (which need nothing but
     // the coupling kernel's output) run on the side stream from here, beside the decoder chain and fc11; the loss scalars
     // (which need fc11's partials) follow dW11 on the side stream in do_backward -- no fork between fc11 and the backward
-    // pass, and dW11 starts as soon as fc11 has finished.
-    const bool t_early = t_early_;
-    // the fused step forks dW11 right behind fc11 (do_backward, MMVAE_TUNE_DW11_AT == 0): EV_FORK rides on the fc11 kernel
+    // pass, and dW11 starts as soon as fc11 has finished: EV_FORK rides on the fc11 kernel.
     auto fc11_with_fork = [&]() -> int {
-        if (ride && need_grad && c.tune(MMVAE_TUNE_DW11_AT) == 0) c.stop_ev = c.ev(EV_FORK);
+        if (need_grad) c.stop_ev = c.ev(EV_FORK);
         const int r = launch_fc11_fast(c, params, x, xs, x_rec, need_grad);
         c.stop_ev = nullptr;
         c.fork_on_fc11 = c.stop_used;
         c.stop_used = false;
         return r;
     };
-    if (t_early && c.tune(MMVAE_TUNE_COUPLE_LATE)) {
-        // experiment: no fork here -- do_backward puts the coupling kernel and the T sums in front of dW11, behind ITS fork
-        *couple_done = true;
-        if ((rc = launch_chain_fwd_dec(c, params))) return rc;
-        if (need_grad && (rc = launch_x3_planes(c, params, 2))) return rc;
-        return fc11_with_fork();
-    }
     if (couple_role) {
         *couple_done = true;
         c.couple_in_dec = true;
@@ -413,30 +394,25 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
                        float* scalars_out = nullptr) {
     int rc;
     const bool fast = fast_path_ok(c, params, x, xs);
-    // dW11 depends only on dZ11 and d10 (both final after forward): overlap it with the backward chain.  Where it is
-    // forked matters: beside it the latent backward takes 82 us instead of 28 and the decoder chain 70 instead of 55.
-    // MMVAE_TUNE_DW11_AT: 0 = fork at the start of backward, 1 = after the decoder chain, 2 = after the latent backward.
-    const int dw11_at = c.tune(MMVAE_TUNE_DW11_AT);
+    // dW11 depends only on dZ11 and d10 (both final after forward): it runs on the side stream beside the backward chain, forked at
+    // the START of the backward pass -- the later it starts, the more of it lands on the MFMA-bound dW1 (measured again in round 4,
+    // profiles/r04_dw11_placement_sweep.txt: behind the decoder chain + 30 us per step, behind the latent backward + 15, not
+    // forked + 75; fewer or more workgroups than the default split + 5 .. 10).
     bool forked = false;
     const bool use_side = fast && c.side();
     const bool early = use_side && !adam && c.ex.early_grad_event != nullptr;
-    const bool side_red = use_side && adam && dw11_at == 0 && !c.tune(MMVAE_TUNE_REDUCE11_MAIN);
+    const bool side_red = use_side && adam;
     if (c.ex_out) c.ex_out->early_recorded = 0;
     Ctx cs = c;
     cs.stream = c.side();
-    auto fork_dw11 = [&]() -> int {
-        if (int r = (c.fork_on_fc11 ? fork_wait_only(c, EV_FORK) : fork_to_side(c, EV_FORK))) return r;
+    if (use_side) {
+        if ((rc = (c.fork_on_fc11 ? fork_wait_only(c, EV_FORK) : fork_to_side(c, EV_FORK)))) return rc;
         c.fork_on_fc11 = false;
-        if (scalars_out && wait_loss && c.tune(MMVAE_TUNE_COUPLE_LATE)) {
-            if (int r = launch_couple(cs)) return r;
-            if (int r = launch_loss_finalize(cs, scalars_out, 1)) return r;
-            if (int r = record_on_side(c, EV_COUPLE)) return r;
-        }
-        if (int r = launch_dw_big_fast(cs, x, xs, 2)) return r;
+        if ((rc = launch_dw_big_fast(cs, x, xs, 2))) return rc;
         if (early) {
             // data parallel: fc11.weight / fc11.bias (47 % of the parameters) are final here; reduce their slabs now
             // and tell the caller, who starts their all-reduce beside the rest of backward
-            if (int r = launch_reduce_grads(cs, grads, grad_scale, nullptr, true, 1)) return r;
+            if ((rc = launch_reduce_grads(cs, grads, grad_scale, nullptr, true, 1))) return rc;
             if (hipEventRecord(reinterpret_cast<hipEvent_t>(c.ex.early_grad_event), c.side()) != hipSuccess) {
                 set_error("event record failed");
                 return MMVAE_E_LAUNCH;
@@ -446,59 +422,31 @@ static int do_backward(const Ctx& c, const mmvae_noise* nz, const float* params,
         if (side_red) {
             // fused Adam: fc11.weight / fc11.bias (47 % of the parameters) are reduced and updated here, behind their GEMM on
             // the side stream -- nothing reads W11 again in this step, and the side stream is idle from here to the join
-            if (int r = launch_reduce_grads(cs, grads, grad_scale, adam, true, 1)) return r;
+            if ((rc = launch_reduce_grads(cs, grads, grad_scale, adam, true, 1))) return rc;
         }
-        if (scalars_out) {
-            if (int r = launch_loss_finalize(cs, scalars_out, 2)) return r;
-        }
-        if (int r = record_on_side(c, EV_JOIN)) return r;
+        if (scalars_out && (rc = launch_loss_finalize(cs, scalars_out, 2))) return rc;
+        if ((rc = record_on_side(c, EV_JOIN))) return rc;
         forked = true;
-        return 0;
-    };
-    if (use_side && dw11_at == 0 && (rc = fork_dw11())) return rc;
+    }
     // fp32x3 engine: a backward pass that is its own call writes the small layers' weight planes again (the fused step's
     // forward pass has left them in place)
     if (fast && !c.small_planes && (rc = launch_x3_planes(c, params, 8))) return rc;
     const int nslab = fc11_split_path(c, params, x, xs) ? c.lay.sp.ks_gd10 : c.lay.sp.ns_fc11;
     if ((rc = launch_chain_bwd_dec(c, params, nslab))) return rc;
-    if (use_side && dw11_at == 1 && (rc = fork_dw11())) return rc;
-    // Experiment kept behind a switch (default off): the small-layer dW GEMMs (occupancy-bound, 34 TF) on the side
-    // stream behind dW11 -- decoder layers beside the encoder backward chain, encoder side beside the dW1 GEMM.
-    // Measured at the benchmark shape: 1.010 ms per step against 1.006 ms with them after dW1 on the main stream
-    // (A/B/A/B on one box): what they would hide behind is itself short of CUs.
-    const bool small_on_side = forked && c.tune(MMVAE_TUNE_SIDE_SMALL);
-    if (small_on_side) {
-        if ((rc = fork_to_side(c, EV_DEC))) return rc;
-        if ((rc = launch_dw_small(cs, 1))) return rc;
-    }
     // T (sum of G log c, from the loss finalisation) is first needed here
     if (wait_loss && !c.couple_in_dec && (rc = join_from_side(c, EV_COUPLE))) return rc;
     if ((rc = launch_lat_bwd(c, nz, params))) return rc;
-    if (use_side && dw11_at == 2 && (rc = fork_dw11())) return rc;   // (3: not forked -- dW11 behind dW1 on the main stream)
-    if (enc_bwd_fused_ok(c)) {
-        if ((rc = launch_chain_bwd_enc_fused(c, params))) return rc;
-    } else {
-        for (int layer = 5; layer >= 2; --layer)
-            if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
-    }
+    for (int layer = 5; layer >= 2; --layer)
+        if ((rc = launch_chain_bwd_enc(c, layer, params))) return rc;
     if ((rc = launch_bn_bwd_apply1(c))) return rc;
-    if (small_on_side) {
-        if ((rc = fork_to_side(c, EV_ENC))) return rc;
-        if ((rc = launch_dw_small(cs, 2))) return rc;
-        if ((rc = record_on_side(c, EV_JOIN))) return rc;
-    }
     if (fast) {
         if ((rc = launch_x3_planes(c, params, 4))) return rc;            // fp32x3: slice planes of dZ1 (dW1)
         if ((rc = launch_dw_big_fast(c, x, xs, forked ? 1 : 3))) return rc;
     } else if ((rc = launch_dw_big(c, nz, x, xs))) {
         return rc;
     }
-    if (!small_on_side && (rc = launch_dw_small(c))) return rc;
+    if ((rc = launch_dw_small(c))) return rc;
     const bool fc11_on_side = (early || side_red) && forked;
-    if (fc11_on_side && c.tune(MMVAE_TUNE_JOIN_LAST)) {   // experiment: nothing the last reduction reads comes from the side stream
-        if ((rc = launch_reduce_grads(c, grads, grad_scale, adam, fast, 2))) return rc;
-        return join_from_side(c, EV_JOIN);
-    }
     if (forked && (rc = join_from_side(c, EV_JOIN))) return rc;
     if (scalars_out && !forked && (rc = launch_loss_finalize(c, scalars_out, 2))) return rc;
     return launch_reduce_grads(c, grads, grad_scale, adam, fast, fc11_on_side ? 2 : 3);
@@ -762,12 +710,6 @@ int mmvae_debug_stage(const mmvae_dims* d, const mmvae_hyper* h, const mmvae_noi
         case 9: return launch_make_xbits(c, nz);
         case 20: return launch_chain_fwd_enc(c, 3, params, nullptr, nullptr);   // one encoder layer (fc3)
         case 21: return launch_chain_bwd_enc(c, 3, params);
-        // the encoder chains as one launch each (timing only: replayed on their own they add to the accumulator sets a complete
-        // pass has left behind)
-        case 22: if (!enc_fused_ok(c)) { set_error("stage 22 needs the one-launch encoder chain"); return MMVAE_E_UNSUPPORTED; }
-                 return launch_chain_fwd_enc_fused(c, params, nullptr, nullptr);
-        case 23: if (!enc_bwd_fused_ok(c)) { set_error("stage 23 needs the one-launch encoder chain"); return MMVAE_E_UNSUPPORTED; }
-                 return launch_chain_bwd_enc_fused(c, params);
         // single kernels of the fast path (per-kernel roofline timing)
         case 10: case 11: case 12: case 13: case 14:
             if (!fast_path_ok(c, params, x, x_arm_stride)) { set_error("stage %d needs the fast path", stage); return MMVAE_E_UNSUPPORTED; }

@@ -542,386 +542,6 @@ __global__ __launch_bounds__(CH_NT) void k_chain_fwd_couple(const ChainFwdArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
-// Train-mode encoder chain fc2..fc5 as ONE launch (round 3).
-//
-// BatchNorm needs the whole batch between two layers, which used to cost a launch boundary per layer (17.6 us per layer at
-// B = 5000 for 7 us of work: the boundary, a fresh round trip for weights + input tile + batch sums, the re-split of the
-// tile).  What actually crosses workgroups between two layers is 2 x N batch sums -- and those already travel through the
-// exact fixed-point accumulator sets (common.hpp acc_add), i.e. through agent-scope integer atomics, which need neither
-// an L2 write-back nor an L1 invalidate to be seen by agent-scope (sc1) loads anywhere on the chip.  A grid barrier of that
-// kind costs 1.6 us at 158 workgroups (tools/micro/gridsync2.hip, profiles/r03_gridsync2_microbench.txt: below a launch
-// boundary's 2.3 us; round 2's 25 us came from system-scope acquires and 512-thread fences).  So here a workgroup carries
-// its 64 cells through all four layers: its activations stay in registers across the barrier (the epilogue's values are
-// normalised with the batch statistics once those are complete and go straight into the next layer's LDS planes), the next
-// layer's weight planes travel during the current layer's GEMM, epilogue and barrier wait.
-//
-// No co-residency assumption (a spinning grid barrier deadlocks when two such launches from different queues each get
-// part of the chip): the work items are (layer, row block), every one claimed exactly once through an atomic exchange.  A
-// workgroup claims the four items of ITS row block at the start; while it waits for a layer to complete it looks for
-// unclaimed items of that layer -- row blocks whose workgroups are not resident yet -- and processes them from global
-// memory (the post-ReLU activations R_l are stored for the backward pass anyway, write-through, so any workgroup can
-// pick a block up at any layer).  A workgroup that becomes resident late finds its items taken and exits.  Every wait is
-// for items held by RUNNING workgroups, so every spin ends; it is bounded all the same (MAX_SPIN polls: the output
-// accumulator set's flag word is raised, every consumer then returns NaN).
-// Reference arithmetic: nn_model.py:264-268 (Linear -> ReLU -> BatchNorm1d(affine=False), momentum update of the running buffers).
-constexpr int ENC_NL = 4;
-constexpr unsigned MAX_SPIN = 1u << 22;
-struct EncFusedArgs {
-    int64_t b_off[ENC_NL];          // bias of fc(l+2) inside one arm's parameter segment
-    int64_t r_off[ENC_NL + 1];      // workspace [A,B,.]: r_off[0] = R1 (input), r_off[l + 1] = output of item layer l
-    int N[ENC_NL];                  // output widths (H, H, H, L)
-    int pl_slot[ENC_NL];
-    int64_t bn_mean_off[ENC_NL], bn_rstd_off[ENC_NL];   // workspace [A,H]: statistics of the layer's INPUT BatchNorm (for backward)
-    int64_t run_mean_off[ENC_NL], run_var_off[ENC_NL];  // inside bn_running
-    int64_t run_arm_stride;
-    int64_t acc_off[ENC_NL + 1];    // accumulator sets ([A] sets each): acc_off[l] the input's batch sums, acc_off[l + 1] the output's
-    int64_t sync_off;               // workspace: per arm sync_arm_words uint32 (zeroed before the launch)
-    int sync_arm_words, nblk_pad;
-    int64_t wpl_off;
-    float bn_eps, bn_momentum;
-    int B, H, ld, wrows, nblk;
-    int rows;                       // cells per row block (Layout::chain_rows_fwd, as the per-layer launches)
-    int64_t per_arm;
-    int skip_mod;                   // tests only: workgroups with blockIdx.x % skip_mod == 1 exit at once, as if they never became resident
-    int64_t dbg_off;                // >= 0: diagnostic stamp counters (MMVAE_TUNE_ABLATE_C bit 3), int64 [16] in the workspace
-};
-// sync words of one arm: claimed[ENC_NL][nblk_pad], then per layer one 32-word line each for the claim count and the
-// done count
-__host__ __device__ inline int enc_sync_words(int nblk_pad) { return ENC_NL * nblk_pad + 2 * ENC_NL * 32; }
-
-__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// acc_mean_m2 with agent-scope loads: the sets are read in the launch that adds to them
-__device__ __forceinline__ void acc_mean_m2_agent(const long long* set, int col, int B, float& mean, float& m2) {
-    long long q[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) q[k] = __hip_atomic_load(set + k * ACC_W + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long bad = __hip_atomic_load(set + 6 * ACC_W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double s1 = ((double)q[0] * 0x1p92 + (double)q[1] * 0x1p46 + (double)q[2]) * 0x1p-84;
-    double s2 = ((double)q[3] * 0x1p92 + (double)q[4] * 0x1p46 + (double)q[5]) * 0x1p-84;
-    if (bad) { s1 = __builtin_nan(""); s2 = s1; }
-    const double mu = s1 / (double)B;
-    mean = (float)mu;
-    m2 = (float)fmax(s2 - s1 * mu, 0.0);
-    if (s1 != s1) m2 = mean;
-}
-
-__global__ __launch_bounds__(CH_NT) void k_enc_fwd_fused(const EncFusedArgs a_in, const float* __restrict__ params,
-                                                        float* __restrict__ ws, float* __restrict__ bn_running,
-                                                        int64_t* __restrict__ nbt) {
-    const EncFusedArgs a = a_in;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned* const Xp = reinterpret_cast<unsigned*>(smem);                 // [3][CHAIN_ROWS][ld]
-    unsigned* const Wp = Xp + 3 * CHAIN_ROWS * a.ld;                        // [3][wrows][ld]
-    float* const mean_s = reinterpret_cast<float*>(Wp + 3 * a.wrows * a.ld);   // [128]
-    float* const rstd_s = mean_s + 128;                                     // [128]
-    float* const red = rstd_s + 128;                                        // [CH_RT * 2][128]
-    int* const sh = reinterpret_cast<int*>(red + CH_RT * 2 * 128);          // [4] selected item
-    const int ld = a.ld, xpl = CHAIN_ROWS * ld, wpl = a.wrows * ld;
-    const int arm = blockIdx.y, my = blockIdx.x, nblk = a.nblk, B = a.B, K = a.H;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rt = wv >> 2, ct = wv & 3;
-    const float* P = params + (int64_t)arm * a.per_arm;
-    unsigned* const sync = reinterpret_cast<unsigned*>(ws + a.sync_off) + (int64_t)arm * a.sync_arm_words;
-    unsigned* const claimed = sync;
-    unsigned* const cnt = sync + ENC_NL * a.nblk_pad;            // cnt[l * 32]
-    unsigned* const done = cnt + ENC_NL * 32;                    // done[l * 32]
-    const unsigned short* const WPL = reinterpret_cast<const unsigned short*>(ws + a.wpl_off) + (int64_t)arm * PL_SMALL_SLOTS * 3 * PLS;
-    if (a.skip_mod > 0 && my % a.skip_mod == 1) return;
-
-    // ---- requested before anything waits: the claims of this row block's four items, the first layer's weight planes
-    //      and (speculatively: the claim almost always succeeds) the block's input rows
-    unsigned own_mask = 0;
-    if (wv == 0) {
-        unsigned got[ENC_NL];
-#pragma unroll
-        for (int l = 0; l < ENC_NL; ++l)
-            got[l] = lane == 0 ? __hip_atomic_exchange(claimed + l * a.nblk_pad + my, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-#pragma unroll
-        for (int l = 0; l < ENC_NL; ++l) {
-            if (lane == 0 && got[l] == 0u) __hip_atomic_fetch_add(cnt + l * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            own_mask |= (__builtin_amdgcn_readfirstlane(got[l]) == 0u ? 1u : 0u) << l;
-        }
-    }
-    u32x4c wq3[WP_N];
-    int wq_layer = 0, wp_lds = -1;   // the layer whose planes are in wq3 / in LDS
-    wp_load(wq3, WPL + (int64_t)a.pl_slot[0] * 3 * PLS, a.N[0], K);
-    const int part = tid & 7, srow = tid >> 3;                  // input staging: 64 rows x 8 sixteen-byte parts x 4
-    const int xc4n = rup(K, 16) >> 2;
-    float4 xq[4];
-    int xq_block = my;
-    {
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(ws + a.r_off[0] + (int64_t)arm * B * K), 0, (int)((int64_t)B * K * 4), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = (part + 8 * j) * 4;
-            const bool ok = col < K;
-            xq[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && srow < a.rows) ? ((my * a.rows + srow) * K + col) * 4 : -16, 0, 0));
-        }
-    }
-    float vals[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) vals[r] = 0.f;
-    // selection state (wave 0; uniform)
-    int lo = 0;                 // next own layer
-    bool have = false;          // vals[] hold the output of (lo - 1, my)
-    unsigned passed = 0, full = 0;   // layers seen complete / fully claimed
-    bool failed = false;
-    const bool stamps = a.dbg_off >= 0;
-    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int i) {
-        if (stamps) {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            ph[i] += now - tprev;
-            tprev = now;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if (stamps) { tprev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-
-
-    for (;;) {
-        // ================================ select the next item ================================
-        if (wv == 0) {
-            int il = -1, ib = 0, ifast = 0;
-            unsigned spins = 0;
-            for (;;) {
-                int Lw;
-                if (lo < ENC_NL) {
-                    if (!((own_mask >> lo) & 1u)) { ++lo; have = false; continue; }
-                    if (lo == 0 || ((passed >> (lo - 1)) & 1u)) { il = lo; ib = my; ifast = (have && lo > 0) ? 1 : 0; ++lo; have = true; break; }
-                    Lw = lo - 1;
-                } else {
-                    Lw = -1;
-                    for (int l = 0; l < ENC_NL; ++l)
-                        if (!((full >> l) & 1u)) { Lw = l; break; }
-                    if (Lw < 0) break;                                   // everything is claimed: done (il = -1)
-                }
-                // refresh what is known about layer Lw (and its predecessor)
-                if (!((passed >> Lw) & 1u) && ld_agent(done + Lw * 32) >= (unsigned)nblk) passed |= 1u << Lw;
-                if (!((full >> Lw) & 1u) && ld_agent(cnt + Lw * 32) >= (unsigned)nblk) full |= 1u << Lw;
-                if (lo < ENC_NL && ((passed >> Lw) & 1u)) continue;       // the barrier is open: take the own item
-                if (lo >= ENC_NL && ((full >> Lw) & 1u)) continue;        // tail: look at the next layer
-                bool ready = Lw == 0 || ((passed >> (Lw - 1)) & 1u);
-                if (!ready && ld_agent(done + (Lw - 1) * 32) >= (unsigned)nblk) { passed |= 1u << (Lw - 1); ready = true; }
-                if (!((full >> Lw) & 1u) && ready) {
-                    // an unclaimed row block of layer Lw (its workgroup is not resident): claim it
-                    int found = -1;
-                    for (int base = 0; base < nblk && found < 0; base += 64) {
-                        const int i = base + lane;
-                        const unsigned v = i < nblk ? ld_agent(claimed + Lw * a.nblk_pad + i) : 1u;
-                        unsigned long long m = __ballot(v == 0u);
-                        while (m && found < 0) {
-                            const int cand = base + __builtin_ctzll(m);
-                            m &= m - 1;
-                            unsigned old = 1u;
-                            if (lane == 0) old = __hip_atomic_exchange(claimed + Lw * a.nblk_pad + cand, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (__builtin_amdgcn_readfirstlane(old) == 0u) {
-                                if (lane == 0) __hip_atomic_fetch_add(cnt + Lw * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                found = cand;
-                            }
-                        }
-                    }
-                    if (found >= 0) { il = Lw; ib = found; ifast = 0; have = false; break; }
-                }
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > MAX_SPIN) { failed = true; break; }
-            }
-            if (lane == 0) { sh[0] = failed ? -2 : il; sh[1] = ib; sh[2] = ifast; }
-        }
-        __syncthreads();
-        stamp(0);
-        const int l = sh[0], b = sh[1];
-        const bool fast = sh[2] != 0;
-        // Who reads this item's stored output?  An item of the workgroup's OWN row block: only this workgroup (it holds the
-        // claims of the block's later layers), so plain stores do.  A picked-up item: whoever takes the block's next layer
-        // -- another workgroup, possibly on another XCD -- so its stores are write-through (sc1; 4-byte write-through
-        // stores cost 6 us per layer, which is why the own items do not use them).
-        const bool own_item = b == my;
-        if (l < 0) {
-            if (l == -2 && tid == 0)   // a wait did not end: poison the output statistics (every consumer returns NaN)
-                __hip_atomic_fetch_add(reinterpret_cast<long long*>(ws + a.acc_off[ENC_NL]) + (int64_t)arm * ACC_SET_I64 + 6 * ACC_W, 1ll,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        // ================================ item (l, b) ================================
-        const int N = a.N[l], b0 = b * a.rows, nvalid = min(a.rows, B - b0);
-        const int col = ct * 32 + (lane & 31);
-        // the input rows of a picked-up block come from global memory (stored write-through by whoever computed them)
-        if (!fast && !(l == 0 && xq_block == b)) {
-            if (l > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(ws + a.r_off[l] + (int64_t)arm * B * K), 0, (int)((int64_t)B * K * 4), 0x00020000);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = (part + 8 * j) * 4;
-                const int off = (c < K && srow < a.rows) ? ((b0 + srow) * K + c) * 4 : -16;
-                xq[j] = l > 0 ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 16))
-                              : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-            }
-        }
-        xq_block = -1;
-        // ---- statistics of the input's BatchNorm from its accumulator set (complete: the layer barrier is behind us)
-        if (tid < 128) {
-            float mean = 0.f, rstd = 0.f;
-            if (tid < K) {
-                float m2;
-                acc_mean_m2_agent(reinterpret_cast<const long long*>(ws + a.acc_off[l]) + (int64_t)arm * ACC_SET_I64, tid, B, mean, m2);
-                rstd = 1.0f / sqrtf(m2 / (float)B + a.bn_eps);
-                if (b == 0) {
-                    ws[a.bn_mean_off[l] + (int64_t)arm * K + tid] = mean;
-                    ws[a.bn_rstd_off[l] + (int64_t)arm * K + tid] = rstd;
-                    if (bn_running) {
-                        float* rm = bn_running + a.run_mean_off[l] + arm * a.run_arm_stride;
-                        float* rv = bn_running + a.run_var_off[l] + arm * a.run_arm_stride;
-                        rm[tid] = (1.f - a.bn_momentum) * rm[tid] + a.bn_momentum * mean;
-                        rv[tid] = (1.f - a.bn_momentum) * rv[tid] + a.bn_momentum * (m2 / (float)max(B - 1, 1));
-                    }
-                    if (nbt && tid == 0) nbt[arm * MMVAE_N_BN + l] += 1;
-                }
-            }
-            mean_s[tid] = mean;
-            rstd_s[tid] = rstd;
-        }
-        lds_barrier();
-        stamp(1);
-        // ---- the layer's input planes: BatchNorm(previous output), zero beyond K (up to the next multiple of 16) and
-        //      beyond nvalid rows
-        if (fast) {
-            const float m = mean_s[min(col, 127)], rs = rstd_s[min(col, 127)];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * 32 + acc_row(r, lane);
-                const float xin = (col < K && row < nvalid) ? (vals[r] - m) * rs : 0.f;
-                const float nbv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, xin), 0xF5, 0xF, 0xF, false));
-                if (!(lane & 1) && col < rup(K, 16)) {
-                    unsigned w3[3];
-                    split3(xin, nbv, w3);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) Xp[pl * xpl + row * ld + (col >> 1)] = w3[pl];
-                }
-            }
-        } else {
-            const bool rok = srow < nvalid;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = part + 8 * j;
-                if (c < xc4n) {
-                    const int cc = min(c, 31) * 4;
-                    const float4 m4 = *reinterpret_cast<const float4*>(&mean_s[cc]);
-                    const float4 r4 = *reinterpret_cast<const float4*>(&rstd_s[cc]);
-                    float4 o = xq[j];
-                    o.x = (rok && cc < K) ? (o.x - m4.x) * r4.x : 0.f;
-                    o.y = (rok && cc + 1 < K) ? (o.y - m4.y) * r4.y : 0.f;
-                    o.z = (rok && cc + 2 < K) ? (o.z - m4.z) * r4.z : 0.f;
-                    o.w = (rok && cc + 3 < K) ? (o.w - m4.w) * r4.w : 0.f;
-                    unsigned w0[3], w1[3];
-                    split3(o.x, o.y, w0);
-                    split3(o.z, o.w, w1);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        *reinterpret_cast<uint2*>(Xp + pl * xpl + srow * ld + c * 2) = make_uint2(w0[pl], w1[pl]);
-                }
-            }
-        }
-        stamp(2);
-        // ---- the layer's weight planes: already in LDS (stored behind the previous item's epilogue, under its drain), or
-        //      requested now for a picked-up item of another layer
-        if (wp_lds != l) {
-            if (wq_layer != l) wp_load(wq3, WPL + (int64_t)a.pl_slot[l] * 3 * PLS, N, K);
-            wp_store(Wp, wpl, ld, wq3, N, K);
-            wp_lds = l;
-            wq_layer = -1;
-        }
-        const bool active = ct * 32 < rup(N, 32);
-        const float bias = (active && col < N) ? P[a.b_off[l] + col] : 0.f;
-        lds_barrier();
-        stamp(3);
-        if (l + 1 < ENC_NL && wq_layer != l + 1) {   // travels under the GEMM and the epilogue
-            wp_load(wq3, WPL + (int64_t)a.pl_slot[l + 1] * 3 * PLS, a.N[l + 1], K);
-            wq_layer = l + 1;
-        }
-        f32x16 acc = zero16();
-        if (active) mma_nt_x3(acc, Xp, xpl, Wp, wpl, ld, rt * 32, ct * 32, rup(K, 16) >> 4);
-        if (stamps) asm volatile("" :: "v"(acc[0]));
-        lds_barrier();
-        stamp(4);
-        // ---- epilogue: bias, ReLU, the post-ReLU activations to the workspace (write-through: any workgroup may pick the
-        //      block up at the next layer), their block statistics into the output's accumulator set
-        {
-            // (agent-scope atomic stores = global_store_dword sc1.  A raw_buffer_store with an out-of-range offset for the
-            // masked elements was miscompiled in the backward kernel: all sixteen stores took the first register.)
-            float* const out = ws + a.r_off[l + 1] + (int64_t)arm * B * N;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * 32 + acc_row(r, lane);
-                float v = 0.f;
-                const bool ok = active && col < N && row < nvalid;
-                if (ok) {
-                    v = relu_keep_nan(acc[r] + bias);
-                    if (own_item) out[(int64_t)(b0 + row) * N + col] = v;
-                    else __hip_atomic_store(out + (int64_t)(b0 + row) * N + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                vals[r] = v;
-            }
-            stamp(7);
-            const int nv = max(0, min(32, nvalid - rt * 32));
-            if (active) {
-                float s = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += vals[r];
-                s += __shfl_xor(s, 32, 64);
-                const float mean = nv > 0 ? s / (float)nv : 0.f;
-                float m2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rt * 32 + acc_row(r, lane);
-                    if (row < nvalid) { const float dl = vals[r] - mean; m2 += dl * dl; }
-                }
-                m2 += __shfl_xor(m2, 32, 64);
-                if (lane < 32) { red[(rt * 2 + 0) * 128 + col] = mean; red[(rt * 2 + 1) * 128 + col] = m2; }
-            }
-            lds_barrier();
-            stamp(8);
-            if (rt == 0 && active && lane < 32 && col < N) {
-                float n = 0.f, mu = 0.f, M2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < CH_RT; ++k) {
-                    const float nb = (float)max(0, min(32, nvalid - k * 32));
-                    if (nb > 0.f) {
-                        const float nn = n + nb, dl = red[(k * 2 + 0) * 128 + col] - mu;
-                        mu += dl * (nb / nn);
-                        M2 += red[(k * 2 + 1) * 128 + col] + dl * dl * (n * nb / nn);
-                        n = nn;
-                    }
-                }
-                acc_add_stats(reinterpret_cast<long long*>(ws + a.acc_off[l + 1]) + (int64_t)arm * ACC_SET_I64, col, n, mu, M2);
-            }
-        }
-        stamp(5);
-        // the next layer's weight planes into LDS (the weight tile is free behind the GEMM barrier) while the stores and atomics drain
-        if (l + 1 < ENC_NL && wq_layer == l + 1) {
-            wp_store(Wp, wpl, ld, wq3, a.N[l + 1], K);
-            wp_lds = l + 1;
-            wq_layer = -1;
-        }
-        // ---- the item is done once every store and atomic of this workgroup has been acknowledged
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        stamp(6);
-        if (tid == 0) __hip_atomic_fetch_add(done + l * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (stamps && tid == 0) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ws + a.dbg_off);
-        for (int i = 0; i < 7; ++i) atomicAdd(dbg + i, ph[i]);
-        atomicAdd(dbg + 8, ph[7]);
-        atomicAdd(dbg + 9, ph[8]);
-        atomicAdd(dbg + 7, 1ull);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 struct BwdLayer {
     int64_t w_off;      // [N][K]
     int64_t dz_off;     // workspace [A,B,N]: dZ of this layer (stored)
@@ -1243,307 +863,6 @@ __global__ __launch_bounds__(CH_NT) void k_chain_bwd(const ChainBwdArgs a_in, co
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Backward of the train-mode encoder chain, fc5 .. fc2, as ONE launch (see k_enc_fwd_fused for the scheme: work items
-// (layer, row block) claimed by atomic exchange, the batch sums through the accumulator sets, a workgroup keeps its row
-// block's gradient tile in registers from layer to layer).  Item bl = 0..3 is layer 5 - bl:
-//   dZ_layer = BatchNormBackward(G_layer; sums of G and G * xhat over the batch) .* relu'(R_layer)      (stored: the small dW GEMMs read it)
-//   G_{layer-1} = dZ_layer W_layer        (stored write-through: k_bn_bwd_apply reads G_1; a picked-up row block reads the others)
-//   block sums of G_{layer-1} and G_{layer-1} * xhat_{layer-1} into the accumulator set of BatchNorm layer-1
-struct EncBwdFusedArgs {
-    int N[ENC_NL];                   // width of dZ of the item's layer (L for fc5, H otherwise); K = H for all
-    int pl_slot[ENC_NL];             // transposed weight planes
-    int64_t g_off[ENC_NL + 1];       // G[layer] for item bl, g_off[bl + 1] = G[layer - 1] = its output
-    int64_t r_off[ENC_NL + 1];       // R of the item's layer output (r_off[bl] = R[layer - 1]); r_off[bl + 1] = the BatchNorm input below
-    int64_t dz_off[ENC_NL];
-    int64_t bn_mean_off[ENC_NL + 1], bn_rstd_off[ENC_NL + 1];   // statistics of BatchNorm `layer` (index bl) and of the one below (bl + 1)
-    int64_t acc_off[ENC_NL + 1];     // acc_off[bl] = batch sums of BatchNorm `layer`'s backward (read), acc_off[bl + 1] (added to)
-    int64_t sync_off;
-    int sync_arm_words, nblk_pad;
-    int64_t wpl_off;
-    int B, H, ld, wrows, nblk;
-    int skip_mod;
-};
-
-// four consecutive floats of row-major [rows][N] through a buffer resource (zero outside the buffer / beyond N)
-template <bool VEC>
-__device__ __forceinline__ float4 ldbuf4(__amdgpu_buffer_rsrc_t rs, int row, int col, int N, bool sc1) {
-    if constexpr (VEC) {
-        const int off = col < N ? (row * N + col) * 4 : -16;
-        return sc1 ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16))
-                   : __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-    } else {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int off = col + e < N ? (row * N + col + e) * 4 : -4;
-            v[e] = sc1 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 16))
-                       : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
-        }
-        return make_float4(v[0], v[1], v[2], v[3]);
-    }
-}
-
-__global__ __launch_bounds__(CH_NT) void k_enc_bwd_fused(const EncBwdFusedArgs a_in, float* __restrict__ ws) {
-    const EncBwdFusedArgs a = a_in;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned* const Gp = reinterpret_cast<unsigned*>(smem);                 // [3][CHAIN_ROWS][ld]
-    unsigned* const Wp = Gp + 3 * CHAIN_ROWS * a.ld;                        // [3][wrows][ld]   rows k, contraction n
-    float* const sums_s = reinterpret_cast<float*>(Wp + 3 * a.wrows * a.ld);   // [4][128]: sum G, sum G * xhat, mean, rstd of this BatchNorm
-    float* const red = sums_s + 512;                                        // [CH_RT * 2][128]
-    int* const sh = reinterpret_cast<int*>(red + CH_RT * 2 * 128);
-    const int ld = a.ld, xpl = CHAIN_ROWS * ld, wpl = a.wrows * ld;
-    const int arm = blockIdx.y, my = blockIdx.x, nblk = a.nblk, B = a.B, K = a.H;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rt = wv >> 2, ct = wv & 3;
-    unsigned* const sync = reinterpret_cast<unsigned*>(ws + a.sync_off) + (int64_t)arm * a.sync_arm_words;
-    unsigned* const claimed = sync;
-    unsigned* const cnt = sync + ENC_NL * a.nblk_pad;
-    unsigned* const done = cnt + ENC_NL * 32;
-    const unsigned short* const WPL = reinterpret_cast<const unsigned short*>(ws + a.wpl_off) + (int64_t)arm * PL_SMALL_SLOTS * 3 * PLS;
-    if (a.skip_mod > 0 && my % a.skip_mod == 1) return;
-
-    unsigned own_mask = 0;
-    if (wv == 0) {
-        unsigned got[ENC_NL];
-#pragma unroll
-        for (int l = 0; l < ENC_NL; ++l)
-            got[l] = lane == 0 ? __hip_atomic_exchange(claimed + l * a.nblk_pad + my, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-#pragma unroll
-        for (int l = 0; l < ENC_NL; ++l) {
-            if (lane == 0 && got[l] == 0u) __hip_atomic_fetch_add(cnt + l * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            own_mask |= (__builtin_amdgcn_readfirstlane(got[l]) == 0u ? 1u : 0u) << l;
-        }
-    }
-    u32x4c wq3[WP_N];
-    int wq_layer = 0, wp_lds = -1;
-    wp_load(wq3, WPL + (int64_t)a.pl_slot[0] * 3 * PLS, K, a.N[0]);   // [K][N]: rows k, contraction n
-    const int part = tid & 7, srow = tid >> 3;
-    f32x16 acc = zero16();            // an item's G tile (this thread's 16 rows of column col); the next item's fast path reads it
-    float pre[16];                    // the BatchNorm input under it
-    float mu_c = 0.f, rs_c = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pre[r] = 0.f;
-    int lo = 0;
-    bool have = false;
-    unsigned passed = 0, full = 0;
-    bool failed = false;
-
-    for (;;) {
-        if (wv == 0) {
-            int il = -1, ib = 0, ifast = 0;
-            unsigned spins = 0;
-            for (;;) {
-                int Lw;
-                if (lo < ENC_NL) {
-                    if (!((own_mask >> lo) & 1u)) { ++lo; have = false; continue; }
-                    if (lo == 0 || ((passed >> (lo - 1)) & 1u)) { il = lo; ib = my; ifast = (have && lo > 0) ? 1 : 0; ++lo; have = true; break; }
-                    Lw = lo - 1;
-                } else {
-                    Lw = -1;
-                    for (int l = 0; l < ENC_NL; ++l)
-                        if (!((full >> l) & 1u)) { Lw = l; break; }
-                    if (Lw < 0) break;
-                }
-                if (!((passed >> Lw) & 1u) && ld_agent(done + Lw * 32) >= (unsigned)nblk) passed |= 1u << Lw;
-                if (!((full >> Lw) & 1u) && ld_agent(cnt + Lw * 32) >= (unsigned)nblk) full |= 1u << Lw;
-                if (lo < ENC_NL && ((passed >> Lw) & 1u)) continue;
-                if (lo >= ENC_NL && ((full >> Lw) & 1u)) continue;
-                bool ready = Lw == 0 || ((passed >> (Lw - 1)) & 1u);
-                if (!ready && ld_agent(done + (Lw - 1) * 32) >= (unsigned)nblk) { passed |= 1u << (Lw - 1); ready = true; }
-                if (!((full >> Lw) & 1u) && ready) {
-                    int found = -1;
-                    for (int base = 0; base < nblk && found < 0; base += 64) {
-                        const int i = base + lane;
-                        const unsigned v = i < nblk ? ld_agent(claimed + Lw * a.nblk_pad + i) : 1u;
-                        unsigned long long m = __ballot(v == 0u);
-                        while (m && found < 0) {
-                            const int cand = base + __builtin_ctzll(m);
-                            m &= m - 1;
-                            unsigned old = 1u;
-                            if (lane == 0) old = __hip_atomic_exchange(claimed + Lw * a.nblk_pad + cand, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (__builtin_amdgcn_readfirstlane(old) == 0u) {
-                                if (lane == 0) __hip_atomic_fetch_add(cnt + Lw * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                found = cand;
-                            }
-                        }
-                    }
-                    if (found >= 0) { il = Lw; ib = found; ifast = 0; have = false; break; }
-                }
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > MAX_SPIN) { failed = true; break; }
-            }
-            if (lane == 0) { sh[0] = failed ? -2 : il; sh[1] = ib; sh[2] = ifast; }
-        }
-        __syncthreads();
-        const int bl = sh[0], b = sh[1];
-        const bool fast = sh[2] != 0;
-        const bool own_item = b == my;    // see k_enc_fwd_fused: only a picked-up item's output is read by other workgroups
-        if (bl < 0) {
-            if (bl == -2 && tid == 0)
-                __hip_atomic_fetch_add(reinterpret_cast<long long*>(ws + a.acc_off[ENC_NL]) + (int64_t)arm * ACC_SET_I64 + 6 * ACC_W, 1ll,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        // ================================ item (bl, b): layer 5 - bl ================================
-        const int N = a.N[bl], b0 = b * CHAIN_ROWS, nvalid = min(CHAIN_ROWS, B - b0);
-        const int col = ct * 32 + (lane & 31);
-        const float invB = 1.f / (float)B;
-        // a picked-up block (and every block's first item): its gradient rows and the activation that gates ReLU' come from
-        // global memory.  The first sixteen-byte column group of a row is requested here, in front of the batch sums (layer
-        // 5 is L <= 32 wide: all of it); the others one group at a time behind them (few registers: this is the rare path)
-        const bool vec = (N & 3) == 0;
-        const int c4n = rup(N, 16) >> 2;
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(ws + a.g_off[bl] + (int64_t)arm * B * N, 0, (int)((int64_t)B * N * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(ws + a.r_off[bl] + (int64_t)arm * B * N, 0, (int)((int64_t)B * N * 4), 0x00020000);
-        float4 gq0 = make_float4(0.f, 0.f, 0.f, 0.f), avq0 = gq0;
-        if (!fast) {
-            if (bl > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (vec) { gq0 = ldbuf4<true>(rg, b0 + srow, part * 4, N, bl > 0); avq0 = ldbuf4<true>(ra, b0 + srow, part * 4, N, false); }
-            else { gq0 = ldbuf4<false>(rg, b0 + srow, part * 4, N, bl > 0); avq0 = ldbuf4<false>(ra, b0 + srow, part * 4, N, false); }
-        }
-        // ---- batch sums of this BatchNorm's backward (complete: the layer barrier, or the previous kernel, is behind us)
-        if (tid < 128) {
-            double s1 = 0.0, s2 = 0.0;
-            if (tid < N) {
-                const long long* set = reinterpret_cast<const long long*>(ws + a.acc_off[bl]) + (int64_t)arm * ACC_SET_I64;
-                long long q[6];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) q[k] = __hip_atomic_load(set + k * ACC_W + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long bad = __hip_atomic_load(set + 6 * ACC_W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s1 = ((double)q[0] * 0x1p92 + (double)q[1] * 0x1p46 + (double)q[2]) * 0x1p-84;
-                s2 = ((double)q[3] * 0x1p92 + (double)q[4] * 0x1p46 + (double)q[5]) * 0x1p-84;
-                if (bad) { s1 = __builtin_nan(""); s2 = s1; }
-            }
-            sums_s[tid] = (float)s1;
-            sums_s[128 + tid] = (float)s2;
-            sums_s[256 + tid] = tid < N ? ws[a.bn_mean_off[bl] + (int64_t)arm * N + tid] : 0.f;
-            sums_s[384 + tid] = tid < N ? ws[a.bn_rstd_off[bl] + (int64_t)arm * N + tid] : 0.f;
-        }
-        lds_barrier();
-        // ---- dZ of the layer: stored, and as three slice planes in LDS
-        float* const dz = ws + a.dz_off[bl] + (int64_t)arm * B * N;
-        if (fast) {
-            const float m1 = sums_s[min(col, 127)], m2 = sums_s[128 + min(col, 127)];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * 32 + acc_row(r, lane);
-                const bool ok = col < N && row < nvalid;
-                const float g = bn_bwd_val(acc[r], pre[r], mu_c, rs_c, m1, m2, invB);
-                const float v = (ok && pre[r] > 0.f) ? g : 0.f;
-                if (ok) dz[(int64_t)(b0 + row) * N + col] = v;
-                const float nbv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xF5, 0xF, 0xF, false));
-                if (!(lane & 1) && col < rup(N, 16)) {
-                    unsigned w3[3];
-                    split3(v, nbv, w3);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) Gp[pl * xpl + row * ld + (col >> 1)] = w3[pl];
-                }
-            }
-        } else {
-            const bool rok = srow < nvalid;
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                const int c = part + 8 * j, cc = c * 4;
-                if (j * 8 >= c4n) break;
-                float4 g = gq0, av = avq0;
-                if (j > 0) {
-                    if (vec) { g = ldbuf4<true>(rg, b0 + srow, cc, N, bl > 0); av = ldbuf4<true>(ra, b0 + srow, cc, N, false); }
-                    else { g = ldbuf4<false>(rg, b0 + srow, cc, N, bl > 0); av = ldbuf4<false>(ra, b0 + srow, cc, N, false); }
-                }
-                if (c < c4n) {
-                    const int cs = min(c, 31) * 4;
-                    const float4 s1 = *reinterpret_cast<const float4*>(&sums_s[cs]);
-                    const float4 s2 = *reinterpret_cast<const float4*>(&sums_s[128 + cs]);
-                    const float4 mm = *reinterpret_cast<const float4*>(&sums_s[256 + cs]), rr = *reinterpret_cast<const float4*>(&sums_s[384 + cs]);
-                    g.x = bn_bwd_val(g.x, av.x, mm.x, rr.x, s1.x, s2.x, invB);
-                    g.y = bn_bwd_val(g.y, av.y, mm.y, rr.y, s1.y, s2.y, invB);
-                    g.z = bn_bwd_val(g.z, av.z, mm.z, rr.z, s1.z, s2.z, invB);
-                    g.w = bn_bwd_val(g.w, av.w, mm.w, rr.w, s1.w, s2.w, invB);
-                    float4 v;
-                    v.x = (rok && cc < N && av.x > 0.f) ? g.x : 0.f;
-                    v.y = (rok && cc + 1 < N && av.y > 0.f) ? g.y : 0.f;
-                    v.z = (rok && cc + 2 < N && av.z > 0.f) ? g.z : 0.f;
-                    v.w = (rok && cc + 3 < N && av.w > 0.f) ? g.w : 0.f;
-                    unsigned w0[3], w1[3];
-                    split3(v.x, v.y, w0);
-                    split3(v.z, v.w, w1);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        *reinterpret_cast<uint2*>(Gp + pl * xpl + srow * ld + c * 2) = make_uint2(w0[pl], w1[pl]);
-                    if (rok) {
-                        float* o = dz + (int64_t)(b0 + srow) * N + cc;
-                        if (vec && cc + 3 < N) *reinterpret_cast<float4*>(o) = v;
-                        else {
-                            if (cc < N) o[0] = v.x;
-                            if (cc + 1 < N) o[1] = v.y;
-                            if (cc + 2 < N) o[2] = v.z;
-                            if (cc + 3 < N) o[3] = v.w;
-                        }
-                    }
-                }
-            }
-        }
-        // ---- the layer's transposed weight planes
-        if (wp_lds != bl) {
-            if (wq_layer != bl) wp_load(wq3, WPL + (int64_t)a.pl_slot[bl] * 3 * PLS, K, N);
-            wp_store(Wp, wpl, ld, wq3, K, N);
-            wp_lds = bl;
-            wq_layer = -1;
-        }
-        lds_barrier();
-        if (bl + 1 < ENC_NL && wq_layer != bl + 1) { wp_load(wq3, WPL + (int64_t)a.pl_slot[bl + 1] * 3 * PLS, K, a.N[bl + 1]); wq_layer = bl + 1; }
-        // the epilogue's operands, requested in front of the GEMM: the BatchNorm input below (for xhat and, in the next item,
-        // ReLU') and its statistics
-        const bool cok = ct * 32 < rup(K, 32) && col < K;
-        {
-            const float* rp = ws + a.r_off[bl + 1] + (int64_t)arm * B * K;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * 32 + acc_row(r, lane);
-                pre[r] = (cok && row < nvalid) ? rp[(int64_t)(b0 + row) * K + col] : 0.f;
-            }
-            mu_c = cok ? ws[a.bn_mean_off[bl + 1] + (int64_t)arm * K + col] : 0.f;
-            rs_c = cok ? ws[a.bn_rstd_off[bl + 1] + (int64_t)arm * K + col] : 0.f;
-        }
-        acc = zero16();
-        if (ct * 32 < rup(K, 32)) mma_nt_x3(acc, Gp, xpl, Wp, wpl, ld, rt * 32, ct * 32, rup(N, 16) >> 4);
-        lds_barrier();
-        // ---- epilogue: G of the layer below (write-through), its block sums into the accumulator set of that BatchNorm
-        {
-            float* const go = ws + a.g_off[bl + 1] + (int64_t)arm * B * K;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rt * 32 + acc_row(r, lane);
-                if (cok && row < nvalid) {
-                    if (own_item) go[(int64_t)(b0 + row) * K + col] = acc[r];
-                    else __hip_atomic_store(go + (int64_t)(b0 + row) * K + col, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    s1 += acc[r];
-                    s2 = bn_bwd_xhat_acc(acc[r], pre[r], mu_c, rs_c, s2);
-                }
-            }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) { red[(rt * 2 + 0) * 128 + col] = s1; red[(rt * 2 + 1) * 128 + col] = s2; }
-            lds_barrier();
-            if (tid < K) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < CH_RT; ++k) { t1 += red[(k * 2 + 0) * 128 + tid]; t2 += red[(k * 2 + 1) * 128 + tid]; }
-                acc_add_sums(reinterpret_cast<long long*>(ws + a.acc_off[bl + 1]) + (int64_t)arm * ACC_SET_I64, tid, t1, t2);
-            }
-        }
-        if (bl + 1 < ENC_NL && wq_layer == bl + 1) {   // the next layer's planes into LDS while the stores and atomics drain
-            wp_store(Wp, wpl, ld, wq3, K, a.N[bl + 1]);
-            wp_lds = bl + 1;
-            wq_layer = -1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(done + bl * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // DZ1 = BNbackward(G1) .* relu'(R1).  grid (ceil(B/32), A): every row block reads the batch sums (accumulator set, or
 // part: [A][npart][2][W] from fc2's backward, recombined here) and applies them to its 32 rows.
 // planes != null (fp32x3 engine, W even): the kernel also writes the three bf16 slice planes of dZ1 that the dW1 GEMM
@@ -1696,53 +1015,6 @@ int launch_chain_fwd_enc(const Ctx& c, int layer, const float* params, float* bn
     return launch_fwd(c, a, max(d.H, N), params, bn_running, nbt, "k_chain_fwd<enc>");
 }
 
-// training mode, fc2..fc5 in one launch (k_enc_fwd_fused).  The claim / done words live in Layout::sync_fwd, inside the range
-// the head of a forward pass zeroes; a stage replayed on its own zeroes them here.
-bool enc_fused_ok(const Ctx& c) {
-    return c.h.training && c.use_acc() && c.small_planes && chain_x3_ok(c) && c.d.H <= 128 && (c.d.H & 3) == 0 &&
-           c.tune(MMVAE_TUNE_FUSED_CHAIN) != 0 && (max(c.lay.nblkc, c.lay.nblkf) * c.d.A <= 256 || c.tune(MMVAE_TUNE_FUSED_CHAIN) == 3) &&
-           c.tune(MMVAE_TUNE_FUSED_CHAIN) != 5;
-}
-int launch_chain_fwd_enc_fused(const Ctx& c, const float* params, float* bn_running, int64_t* nbt) {
-    const mmvae_dims& d = c.d;
-    const Layout& L = c.lay;
-    EncFusedArgs a{};
-    for (int l = 0; l < ENC_NL; ++l) {
-        const int layer = l + 2;
-        a.b_off[l] = c.po.o[2 * (layer - 1) + 1];
-        a.N[l] = (layer == 5) ? d.L : d.H;
-        a.pl_slot[l] = l;
-        a.bn_mean_off[l] = L.bn_mean[l];
-        a.bn_rstd_off[l] = L.bn_rstd[l];
-        a.run_mean_off[l] = c.po.bn_mean[l];
-        a.run_var_off[l] = c.po.bn_var[l];
-    }
-    for (int l = 0; l <= ENC_NL; ++l) { a.r_off[l] = L.R[l]; a.acc_off[l] = acc_set_off(L, d.A, l); }
-    a.run_arm_stride = c.po.bn_per_arm;
-    a.sync_off = L.sync_fwd;
-    a.nblk_pad = rup(L.nblkf, 32);
-    a.sync_arm_words = L.sync_arm_words;
-    a.wpl_off = L.pl_small;
-    a.bn_eps = c.h.eps;
-    a.bn_momentum = c.h.bn_momentum;
-    a.B = d.B; a.H = d.H; a.nblk = L.nblkf; a.rows = L.chain_rows_fwd;
-    a.ld = x3_ld(max(d.H, d.L));
-    a.wrows = 128;
-    a.per_arm = c.po.per_arm;
-    a.skip_mod = c.tune(MMVAE_TUNE_FUSED_CHAIN) == 2 ? 3 : 0;
-    a.dbg_off = (c.tune(MMVAE_TUNE_ABLATE_C) & 8) ? L.loss_scratch + 2048 : -1;
-    if (!c.fwd_zeroed) {
-        hipError_t e = hipMemsetAsync(c.ws + L.sync_fwd, 0, sizeof(unsigned) * (size_t)d.A * a.sync_arm_words, c.stream);
-        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
-    }
-    const size_t shm = (size_t)(3 * CHAIN_ROWS * a.ld + 3 * a.wrows * a.ld + 256 + CH_RT * 2 * 128 + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_enc_fwd_fused, dim3(L.nblkf, d.A), dim3(CH_NT), shm, c.stream, a, params, c.ws, bn_running, nbt);
-    HIP_LAUNCH_CHECK("k_enc_fwd_fused");
-    return 0;
-}
-
-// eval mode: the BatchNorm statistics are fixed (running buffers), so fc2..fc5 need no launch boundary between them:
-// one launch, the activations of a row block stay in LDS from layer to layer (four launches of ~16 us -> one)
 int launch_chain_fwd_enc_eval(const Ctx& c, const float* params) {
     const mmvae_dims& d = c.d;
     const Layout& L = c.lay;
@@ -1905,51 +1177,6 @@ int launch_chain_bwd_enc(const Ctx& c, int layer, const float* params) {
     a.per_arm = c.po.per_arm;
     a.L[0].pl_slot = 9 + layer - 2;
     return launch_bwd(c, a, max(d.H, N), params, "k_chain_bwd<enc>");
-}
-
-// training mode, backward of fc5..fc2 in one launch (k_enc_bwd_fused); the claim / done words live in Layout::sync_bwd,
-// zeroed with the backward accumulator sets by the first kernel of the pass (a stage replayed on its own: here)
-bool enc_bwd_fused_ok(const Ctx& c) {
-    const int t = c.tune(MMVAE_TUNE_FUSED_CHAIN);   // diagnostics: 4 = forward chain only, 5 = backward chain only
-    if (t == 4) return false;
-    if (t == 5) { Ctx c2 = c; c2.ex.tune[MMVAE_TUNE_FUSED_CHAIN] = 1; return enc_fused_ok(c2); }
-    return enc_fused_ok(c);
-}
-int launch_chain_bwd_enc_fused(const Ctx& c, const float* params) {
-    (void)params;
-    const mmvae_dims& d = c.d;
-    const Layout& L = c.lay;
-    EncBwdFusedArgs a{};
-    for (int bl = 0; bl < ENC_NL; ++bl) {
-        const int layer = 5 - bl;
-        a.N[bl] = (layer == 5) ? d.L : d.H;
-        a.pl_slot[bl] = 9 + layer - 2;
-        a.dz_off[bl] = L.DZ[layer];
-    }
-    for (int bl = 0; bl <= ENC_NL; ++bl) {
-        const int layer = 5 - bl;              // bl = 4: layer 1 (the output side of the last item)
-        a.g_off[bl] = L.G[layer];
-        a.r_off[bl] = L.R[layer - 1];
-        a.bn_mean_off[bl] = L.bn_mean[layer - 1];
-        a.bn_rstd_off[bl] = L.bn_rstd[layer - 1];
-        a.acc_off[bl] = acc_set_off(L, d.A, ACC_BWD + layer - 1);
-    }
-    a.sync_off = L.sync_bwd;
-    a.nblk_pad = rup(L.nblkc, 32);
-    a.sync_arm_words = L.sync_arm_words;
-    a.wpl_off = L.pl_small;
-    a.B = d.B; a.H = d.H; a.nblk = L.nblkc;
-    a.ld = x3_ld(max(d.H, d.L));
-    a.wrows = 128;
-    a.skip_mod = c.tune(MMVAE_TUNE_FUSED_CHAIN) == 2 ? 3 : 0;
-    if (!c.bwd_zeroed) {
-        hipError_t e = hipMemsetAsync(c.ws + L.sync_bwd, 0, sizeof(unsigned) * (size_t)d.A * a.sync_arm_words, c.stream);
-        if (e != hipSuccess) { set_error("memset: %s", hipGetErrorString(e)); return MMVAE_E_LAUNCH; }
-    }
-    const size_t shm = (size_t)(3 * CHAIN_ROWS * a.ld + 3 * a.wrows * a.ld + 512 + CH_RT * 2 * 128 + 16) * sizeof(float);
-    hipLaunchKernelGGL(k_enc_bwd_fused, dim3(L.nblkc, d.A), dim3(CH_NT), shm, c.stream, a, c.ws);
-    HIP_LAUNCH_CHECK("k_enc_bwd_fused");
-    return 0;
 }
 
 int launch_bn_bwd_apply1(const Ctx& c) {

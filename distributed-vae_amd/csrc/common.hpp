@@ -84,11 +84,7 @@ struct Layout {
     // BatchNorm backward, l = 1..5.  Sets 0..4 are zeroed by the first kernel of a forward pass, 5..9 by the first
     // kernel of a backward pass.
     int64_t acc;
-    // claim / done words of the one-launch encoder chains (chain.hip k_enc_fwd_fused / k_enc_bwd_fused): uint32, [A] blocks of
-    // enc_sync_words(rup(nblkc, 32)).  sync_fwd lies between fc11_part and acc (inside the range the head of a forward pass
-    // zeroes), sync_bwd directly behind acc (inside the range the first kernel of a backward pass zeroes).
-    int64_t sync_fwd, sync_bwd;
-    int sync_arm_words;
+    int64_t acc_end;               // end of the accumulator sets (the backward pass zeroes [ACC_BWD sets, acc_end))
     int64_t rowmap;                // uint32 [B + MAP_PAD]: element offsets of the batch's rows in the resident matrix (mmvae_train_step_rows)
     int64_t loss_scratch;          // small
     int64_t total;
@@ -751,7 +747,7 @@ struct Ctx {
     // (through the coupling's T set: the fused step's coupling runs inside the decoder chain's launch and finds it zeroed; the
     // coupling's own launcher zeroes it again, it may run more than once per forward pass)
     int64_t fwd_zero_floats() const { return acc_set_off(lay, d.A, ACC_BWD) - lay.fc11_part; }
-    int64_t bwd_zero_floats() const { return lay.sync_bwd + (int64_t)d.A * lay.sync_arm_words - acc_set_off(lay, d.A, ACC_BWD); }
+    int64_t bwd_zero_floats() const { return lay.acc_end - acc_set_off(lay, d.A, ACC_BWD); }
     mutable bool bwd_zeroed = false;   // set by the launcher of the first kernel of a backward pass (it zeroes that range)
     // mmvae_train_step_rows: the batch is rows x_rows[0 .. B) (device, int64) of the resident matrix [x_nrows][x_ld] that the
     // call's `x` points at; the head launch of the step turns them into the row map (Layout::rowmap) and sets rowmap_ready
@@ -795,11 +791,6 @@ int launch_fc1_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, con
 int launch_bn_eval_stats(const Ctx& c, const float* bn_running);   // eval mode: all five layers, one launch
 int launch_chain_fwd_enc(const Ctx& c, int layer /*2..5*/, const float* params, float* bn_running, int64_t* nbt);
 int launch_chain_fwd_enc_eval(const Ctx& c, const float* params);   // eval mode: fc2..fc5 in one launch
-// training mode: fc2..fc5 in one launch with a barrier per BatchNorm (fp32x3 form, accumulator sets; chain.hip)
-bool enc_fused_ok(const Ctx& c);
-int launch_chain_fwd_enc_fused(const Ctx& c, const float* params, float* bn_running, int64_t* nbt);
-bool enc_bwd_fused_ok(const Ctx& c);
-int launch_chain_bwd_enc_fused(const Ctx& c, const float* params);
 int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, float* bn_running, int64_t* nbt,
                    int32_t* labels = nullptr /*eval: argmax of c per cell and arm*/);
 int launch_chain_fwd_dec(const Ctx& c, const float* params, bool with_couple = false /*the coupling terms as a role of the launch*/);

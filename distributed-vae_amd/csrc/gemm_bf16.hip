@@ -2082,12 +2082,7 @@ int launch_dw_big_bf16(const Ctx& c, const float* x, int64_t xs, int which) {
         g.so = SlabOut{c.ws + L.dw11_slab, (int64_t)d.A * d.D * DW11_LD, (int64_t)d.D * DW11_LD, DW11_LD, d.D, d.H + 1};
         if (split3_gemms(c)) {   // one tile wide: the two tiles of a block share the [d10 | 1] tile
             use_planes(c, g.b, PL_D10);
-            const int pad = c.tune(MMVAE_TUNE_DW11_LDS) * 1024;
-            if (pad > 0) {
-                static bool once = false;
-                if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_x3_gemm<true, true, 0, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 40960); once = true; }
-            }
-            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), pad > 0 ? pad : 0, c.stream, g);
+            hipLaunchKernelGGL((k_x3_gemm<true, true, 0, 2, true>), dim3(cdiv(cdiv(d.D, BT), 2), g.KS, d.A), dim3(512), 0, c.stream, g);
         } else if (c.dz16) {        // bf16 storage: the fused fc11 kernel of this step wrote dZ11 as bf16
             g.a.src16 = 1;
             g.a_arm = (int64_t)d.B * d.D / 2;

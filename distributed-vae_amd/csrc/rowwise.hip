@@ -1500,7 +1500,7 @@ int launch_lat_fwd(const Ctx& c, const mmvae_noise* nz, const float* params, flo
     a.labels = labels;
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    const int fullwave = c.tune(MMVAE_TUNE_LAT_FULLWAVE);   // A/B timing
+    const int fullwave = 0;
     if (!fullwave && a.dbg_off < 0 && c.d.C <= 32 * LH_CPL && c.d.L <= 32 && 2 * c.d.S <= 32) {
         launch_k(c, k_lat_fwd_h, dim3(c.lay.nblkl, c.d.A), dim3(64 * LH_NW), shm, a, nd, params, c.ws, bn_running, nbt);
         HIP_LAUNCH_CHECK("k_lat_fwd_h");
@@ -1560,7 +1560,7 @@ int launch_lat_bwd(const Ctx& c, const mmvae_noise* nz, const float* params) {
     LatArgs a = make_lat_args(c);
     NoiseDev nd = make_noise_dev(nz, c.h);
     const size_t shm = (size_t)(c.d.C * c.d.L + 2 * c.d.S * (c.d.L + c.d.C)) * sizeof(float);
-    const int fullwave = c.tune(MMVAE_TUNE_LAT_FULLWAVE);   // A/B timing
+    const int fullwave = 0;
     if (!fullwave && c.d.C <= 32 * LH_CPL && c.d.L <= 32 && 2 * c.d.S <= 32) {
         hipLaunchKernelGGL(k_lat_bwd_h, dim3(cdiv(c.d.B, LAT_ROWS_BWD), c.d.A), dim3(64 * LBH_NW), shm, c.stream, a, nd, params, c.ws);
         HIP_LAUNCH_CHECK("k_lat_bwd_h");

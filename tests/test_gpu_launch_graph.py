@@ -1,13 +1,11 @@
-"""-m gpu: the train-mode encoder chains as ONE launch each (csrc/chain.hip k_enc_fwd_fused / k_enc_bwd_fused) against the
-one-launch-per-layer kernels they replace -- same arithmetic, so every result must be BIT-identical:
+"""-m gpu: launch-graph variants of the fused train step that must not change a bit of its results.
 
-  * the default path (every workgroup carries its own row block through all layers, activations in registers);
-  * with every third workgroup exiting at once, as if it had never become resident (MMVAE_TUNE_FUSED_CHAIN = 2): the
-    running workgroups pick its row blocks up layer by layer from global memory -- the path that makes the in-launch
-    barrier independent of co-residency (two processes on one GPU, grids larger than the chip);
-  * a grid larger than the chip for real (A = 5 at B = 5000: 395 workgroups of 138 KB LDS on 256 CUs, switch value 3).
+  * the coupling terms as a ROLE of the decoder chain's launch (csrc/chain.hip k_chain_fwd_couple, the default from four arms
+    up) against the coupling kernel on the side stream (the default below): same arithmetic (couple.hpp), bit-identical.
 
-Reference arithmetic: nn_model.py:264-268 (Linear -> ReLU -> BatchNorm1d, running statistics) and its autograd.
+(The one-launch encoder chains this file also covered in round 3 -- bit-identical, no faster -- left the tree in round 4:
+tools/experiments/fused_chain_one_launch.removed.patch.txt.)
+Reference arithmetic: nn_model.py:558-569 (coupling terms) and its autograd.
 """
 import pytest
 import torch
@@ -16,8 +14,6 @@ from oracle import restatement as R
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TUNE_FUSED = 23        # include/mmvae.h MMVAE_TUNE_FUSED_CHAIN: 0 one launch per layer (default), 1 one launch per chain
-TUNE_FORK_RECORD = 12  # csrc/tune.h MMVAE_TUNE_FORK_RECORD: 1 = fork events recorded behind the kernel instead of riding on it
 TUNE_COUPLE = 13       # csrc/tune.h MMVAE_TUNE_COUPLE_SIDE: 1 coupling kernel on the side stream, 3 as a role of the decoder chain's launch
 
 
@@ -31,7 +27,6 @@ def _step(h, B, seed, fused_switch, steps=2, tune=None):
     m = U.build_model(h, sd)
     m.train()
     ex = N.exec_from_env(N.gemm_mode("fp32") & 0xFF)
-    ex.tune[TUNE_FUSED] = fused_switch
     for idx, val in (tune or {}).items():
         ex.tune[idx] = val
     m._exec = ex
@@ -67,30 +62,6 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("shape", SHAPES)
-def test_one_launch_chain_equals_one_launch_per_layer(shape):
-    A, B, D, H, L, C = shape
-    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=2, lowD_dim=L, n_arm=A)
-    ref = _step(h, B, 11, 0)
-    _same(_step(h, B, 11, 1), ref)
-
-
-@pytest.mark.parametrize("shape", SHAPES)
-def test_row_blocks_of_absent_workgroups_are_picked_up(shape):
-    A, B, D, H, L, C = shape
-    h = R.Hyper(input_dim=D, fc_dim=H, n_categories=C, state_dim=2, lowD_dim=L, n_arm=A)
-    ref = _step(h, B, 12, 0)
-    _same(_step(h, B, 12, 2), ref)
-
-
-def test_grid_larger_than_the_chip():
-    """A = 5 at B = 5000: 395 workgroups, at most 256 resident -- the rest of the row blocks are picked up by the running
-    workgroups or processed by their own workgroups when those become resident; either way bit-identical results."""
-    h = R.Hyper(input_dim=1000, n_arm=5)
-    ref = _step(h, 5000, 13, 0, steps=1)
-    _same(_step(h, 5000, 13, 3, steps=1), ref)
-
-
 @pytest.mark.parametrize("shape", SHAPES + [(5, 700, 256, 100, 10, 92), (4, 64, 128, 32, 6, 33)])
 def test_coupling_as_a_role_of_the_decoder_launch_equals_the_side_stream_kernel(shape):
     """k_chain_fwd_couple (the fused step's coupling terms inside the decoder chain's launch, default from four arms up) against
@@ -101,12 +72,3 @@ def test_coupling_as_a_role_of_the_decoder_launch_equals_the_side_stream_kernel(
     ref = _step(h, B, 13, 0, tune={TUNE_COUPLE: 1})
     _same(_step(h, B, 13, 0, tune={TUNE_COUPLE: 3}), ref)
     _same(_step(h, B, 13, 0), ref)      # the default choice, whichever it is for this arm count
-
-
-def test_fork_events_on_kernels_equal_recorded_events():
-    """The fused step's fork events ride on the latent forward / fused fc11 kernel as hipExtLaunchKernel stop events (csrc/common.hpp
-    launch_k); with MMVAE_TUNE_FORK_RECORD they are recorded behind the kernels as before.  Same launches, same order: bit-identical
-    results -- and a wrong event (a side stream that starts early) would show as a wrong dW11 or loss vector."""
-    h = R.Hyper(input_dim=1000, fc_dim=100, n_categories=92, state_dim=2, lowD_dim=10, n_arm=2)
-    ref = _step(h, 5000, 14, 0, steps=3, tune={TUNE_FORK_RECORD: 1})
-    _same(_step(h, 5000, 14, 0, steps=3), ref)

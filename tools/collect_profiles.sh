@@ -15,11 +15,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_mfma -- $BEN
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_bf16 -- $BENCH --gemm-dtype bf16 > $OUT/kstats_bf16.json 2> $OUT/kstats_bf16.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_bf16f -- $BENCH --gemm-dtype bf16 --bf16-fp32-storage > $OUT/kstats_bf16f.json 2> $OUT/kstats_bf16f.err
 cp $(find $OUT/kstats_fp32 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv
-# one step's kernel timeline (start offset, duration, queue): default launch sequence, and with the encoder chains as one launch each
+# one step's kernel timeline (start offset, duration, queue)
 python3 $ROOT/tools/step_timeline.py $OUT/kstats_fp32 > $OUT/${R}_step_timeline.txt
-MMVAE_FUSED_CHAIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_fused -- $BENCH > $OUT/kstats_fused.json 2> $OUT/kstats_fused.err
-python3 $ROOT/tools/step_timeline.py $OUT/kstats_fused > $OUT/${R}_step_timeline_fused_chain.txt
-cp $(find $OUT/kstats_fused -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_fused_chain_kernel_stats.csv
 cp $(find $OUT/kstats_mfma -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_fp32mfma_kernel_stats.csv
 cp $(find $OUT/kstats_bf16 -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_bf16_kernel_stats.csv
 cp $(find $OUT/kstats_bf16f -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_bf16_fp32storage_kernel_stats.csv
@@ -50,5 +47,5 @@ json.dump({"sources_sha256": {s: hashlib.sha256(open(s, "rb").read()).hexdigest(
            "command": "tools/collect_profiles.sh $R"}, open("$OUT/${R}_pmc_meta.json", "w"), indent=1)
 PY
 # drop the bulky raw traces from what travels back (keep the summaries)
-rm -rf $OUT/aug_fp32 $OUT/aug_bf16 $OUT/kstats_fp32 $OUT/kstats_mfma $OUT/kstats_bf16 $OUT/kstats_bf16f $OUT/kstats_fused $OUT/pmc_* $OUT/pmcb_*
+rm -rf $OUT/aug_fp32 $OUT/aug_bf16 $OUT/kstats_fp32 $OUT/kstats_mfma $OUT/kstats_bf16 $OUT/kstats_bf16f $OUT/pmc_* $OUT/pmcb_*
 ls -la $OUT
