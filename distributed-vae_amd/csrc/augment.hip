@@ -237,7 +237,7 @@ static AugPacked aug_packed_layout(const mmvae_aug_dims& d) {
 struct AugWs {
     int64_t h1, h2, h3, h4, P, H6, h7, h8, h9, h10, total; int ld1, ld3, ld5;
     // planes x planes engine (gemm_pp.hip): the activations as tiled slice planes (three planes' room each; the bf16
-    // configuration fills one), written by the producing layer's epilogue; slab scratch for K splits
+    // configuration fills one), written by the producing layer's epilogue; scratch of the stream-K grid (flags + partial tiles)
     int64_t tx, t1, t2, t3, t4, t6, t7, t8, t9, t10, scratch, scratch_floats;
 };
 static AugWs aug_ws_layout(const mmvae_aug_dims& d, int trunk_rows) {
@@ -251,7 +251,7 @@ static AugWs aug_ws_layout(const mmvae_aug_dims& d, int trunk_rows) {
     auto tpl = [&](int rows, int K) { return take(3 * tp_plane_elems(rows, K) / 2); };
     w.tx = tpl((int)T, d.D); w.t1 = tpl((int)T, d.N1); w.t2 = tpl((int)T, d.N1); w.t3 = tpl((int)T, d.N3); w.t4 = tpl((int)T, d.N3);
     w.t6 = tpl((int)R, d.N5); w.t7 = tpl((int)R, d.N3); w.t8 = tpl((int)R, d.N3); w.t9 = tpl((int)R, d.N1); w.t10 = tpl((int)R, d.N1);
-    w.scratch_floats = 4 * T * (int64_t)rup(d.N1, 8);      // K-split slabs of the trunk's long-K layers
+    w.scratch_floats = pp_scratch_floats();
     w.scratch = take(w.scratch_floats);
     w.total = off;
     return w;
@@ -518,7 +518,7 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     if (gemm_bf16 && tune_tile != 90) {
         // planes x planes engine (gemm_pp.hip): every layer's epilogue writes the next layer's operand as tiled slice planes
         // (three exact slices: fp32x3; one rounded plane: the bf16 configuration).  MMVAE_AUG_TILE=90: the tile engine of
-        // gemm_bf16.hip as before (A/B timing); 1..3 (+ 10 KS): forced tile / K split for every layer.
+        // gemm_bf16.hip as before (A/B timing); 1..3 (+ 10 x workgroups): forced tile / grid for every layer.
         const int NP = gemm_bf16 == 2 ? 3 : 1;
         auto tpa = [&](int64_t off, int rows, int K) { return tp_make(reinterpret_cast<unsigned short*>(w + off), rows, K); };
         auto tpw = [&](int i) {
@@ -534,8 +534,9 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
             TPlanes a = in;
             if (a.KT > b.KT) a.KT = b.KT; else b.KT = a.KT;     // (equal unless the producer's width was padded differently)
             return launch_pp_gemm(s, NP, a, b, M, L.g[i].N, packed + L.g[i].sc, packed + L.g[i].sh, affine, relu, out32, ld32, nc32, outp,
-                                  scr, W.scratch_floats, tune_tile);
+                                  scr, W.scratch_floats, i, tune_tile);
         };
+        if ((rc = launch_pp_zero_flags(s, scr))) return rc;
         if ((rc = launch_tp_from_f32(s, x, d->D, T, d->D, NP, X))) return rc;
         if ((rc = layer(0, X, T, true, true, nullptr, 0, 0, &H1))) return rc;
         if ((rc = layer(1, H1, T, true, true, nullptr, 0, 0, &H2))) return rc;

@@ -105,6 +105,32 @@ def test_production_shape_against_oracle(D):
     assert _rel(xa2[0], xa[0].cpu()) < 5e-6
 
 
+@pytest.mark.parametrize("code", [21, 41, 81, 32, 52, 43, 83, 4, 24, 34, 84])
+def test_k_split_combined_in_the_launch(code):
+    """With a K split the KS workgroups of a tile combine their accumulators inside the launch (csrc/gemm_pp.hip: every part
+    publishes the accumulator tiles it does not finish through write-through partial slots and a flag, polls its partners and
+    adds their pieces of its own tiles).  Forced tile shapes and splits (MMVAE_AUG_TILE = tile + 10 x KS; tiles 1 .. 4 = 256 x 256,
+    256 x 128, 128 x 128, 160 x 256) at a small shape -- splits that leave parts without a K step, splits that do not divide the
+    accumulator tiles evenly, every tile shape -- must agree with the oracle like the default choice, and with it to fp32
+    summation order."""
+    NZ, Z, D, ND, A, B = 50, 10, 1000, 500, 2, 300
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=7)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(B, D, generator=g) < 0.3).float() * torch.randn(B, D, generator=g).abs() * 3
+    z0, eps = torch.randn(A, B, NZ, generator=g), torch.randn(A, B, Z, generator=g)
+    s_ref, x_ref = OA.forward_eval(sd, x.expand(A, -1, -1), z0, eps, 0.1)
+    outs = []
+    for c in (0, code):
+        m = _model(NZ, Z, D, ND, sd)
+        m._exec().tune[3] = c                       # MMVAE_TUNE_AUG_TILE
+        m.set_explicit_noise(z0, eps)
+        s, xa = m(x.to(DEV).expand(A, -1, -1), True, 0.1)
+        assert _rel(s, s_ref) < TOL and _rel(xa, x_ref) < TOL, c
+        assert bool(torch.isfinite(xa).all())
+        outs.append(xa.cpu())
+    assert _rel(outs[1], outs[0]) < 5e-6
+
+
 def test_device_noise_statistics_and_determinism():
     """Without the explicit hook the module draws torch.randn on the device like the reference: same seed, same
     output; different arms differ; s has the spread the noise implies."""
