@@ -651,6 +651,28 @@ def data_path(data, A, B, D):
             e1.synchronize()
             res[key] = e0.elapsed_time(e1) / n
         res["row_indexed_steps"] = bool(getattr(tr, "_rows_ok", True))
+        # the same shuffled epoch on the production path (augmenter in front of every step, pipelined): the augmenter's first
+        # layer reads the epoch's rows out of the loader's slice planes (made once per data set; Augmenter_smartseq.forward_rows),
+        # against gathered batches converted per batch (MMVAE_ROWS=0)
+        from distributed_vae_amd.augmentation import Augmenter_smartseq
+        torch.manual_seed(546)
+        tr.set_augmenter(Augmenter_smartseq(50, 10, D, 500).to(data.device).eval())
+        tr.pipeline = True
+        for key, rows in (("augmented_shuffled_epoch_ms_per_step", "1"), ("augmented_shuffled_epoch_ms_per_step_gathered", "0")):
+            os.environ["MMVAE_ROWS"] = rows
+            for _ in tr.epoch_steps(ld):
+                pass
+            if rows == "1":
+                res["augmenter_reads_rows"] = bool(getattr(tr, "used_aug_rows", False))
+            e0.record()
+            n = 0
+            for _ in range(3):
+                for _b in tr.epoch_steps(ld):
+                    n += 1
+            e1.record()
+            e1.synchronize()
+            res[key] = e0.elapsed_time(e1) / n
+        tr.set_augmenter(None)
     finally:
         if prev is None:
             os.environ.pop("MMVAE_ROWS", None)

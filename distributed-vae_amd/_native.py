@@ -166,10 +166,14 @@ def lib():
     L.mmvae_aug_pack.argtypes = [C.POINTER(AugDims), C.POINTER(AugTensors), vp, vp]
     L.mmvae_augment.argtypes = [C.POINTER(AugDims), vp, vp, i64, vp, vp, f32, vp, C.c_size_t, vp, vp, i32, ex, vp]
     L.mmvae_gather_rows.argtypes = [vp, i64, i64, vp, i64, i32, vp, vp]
+    L.mmvae_tp_planes_bytes.argtypes = [i64, i32, i32]
+    L.mmvae_tp_planes_bytes.restype = C.c_size_t
+    L.mmvae_tp_planes.argtypes = [vp, i64, i64, i32, i32, vp, vp]
+    L.mmvae_augment_rows.argtypes = [C.POINTER(AugDims), vp, vp, i64, i32, vp, vp, vp, f32, vp, C.c_size_t, vp, vp, i32, ex, vp]
     for fn in ("mmvae_check_dims", "mmvae_param_layout", "mmvae_splits", "mmvae_forward", "mmvae_loss",
                "mmvae_backward", "mmvae_adam_step", "mmvae_train_step", "mmvae_dump_noise", "mmvae_debug_stage",
                "mmvae_eval_classify", "mmvae_classify", "mmvae_confmat_accumulate", "mmvae_consensus", "mmvae_aug_pack",
-               "mmvae_augment", "mmvae_gather_rows"):
+               "mmvae_augment", "mmvae_gather_rows", "mmvae_tp_planes", "mmvae_augment_rows"):
         getattr(L, fn).restype = C.c_int
     L.mmvae_dp_unique_id.argtypes = [vp]
     L.mmvae_dp_init.argtypes = [vp, i32, i32, C.POINTER(C.c_void_p)]
@@ -442,6 +446,22 @@ def to_bf16(data: torch.Tensor) -> torch.Tensor:
     span = (data.shape[0] - 1) * ld + ((data.shape[1] + 3) // 4) * 4
     out = torch.empty(span, dtype=torch.bfloat16, device=data.device).as_strided(data.shape, data.stride())
     check(lib().mmvae_to_bf16(_ptr(data), ld, data.shape[0], data.shape[1], _ptr(out), _stream(data.device)), "mmvae_to_bf16")
+    return out
+
+
+def tp_planes(data: torch.Tensor, n_planes: int) -> Optional[torch.Tensor]:
+    """A resident float32 matrix as the planes x planes GEMM engine's tiled bf16 slice planes (mmvae_tp_planes; made once per
+    data set: 3 planes = the exact slices of the fp32x3 engine, 1 = the matrix rounded to bf16) for the augmenter's row-indexed
+    forward (mmvae_augment_rows).  Returns an opaque uint16 device tensor, or None where the library does not offer it."""
+    if data.device.type != "cuda":
+        raise NativeError("tp_planes needs a CUDA tensor (no CPU fallback)")
+    assert data.dim() == 2 and data.dtype == torch.float32 and data.stride(1) == 1
+    nbytes = int(lib().mmvae_tp_planes_bytes(data.shape[0], data.shape[1], n_planes))
+    if nbytes == 0:
+        return None
+    out = torch.zeros(nbytes // 2, dtype=torch.int16, device=data.device)     # (padding rows of the planes are read, never used)
+    check(lib().mmvae_tp_planes(_ptr(data), int(data.stride(0)), data.shape[0], data.shape[1], n_planes, _ptr(out),
+                                _stream(data.device)), "mmvae_tp_planes")
     return out
 
 

@@ -153,6 +153,49 @@ class Augmenter_smartseq(nn.Module):
         return (s, out) if batched else (s[0], out[0])
 
 
+    # ------------------------------------------------------------------ row-indexed forward (no reference counterpart)
+    def planes_needed(self) -> int:
+        """Slice planes per matrix element the row-indexed forward wants from ``DeviceLoader.data_planes`` for the current
+        ``gemm_dtype``: 3 (fp32: the exact fp32x3 slices), 1 (bf16), 0 = not offered (the fp32 matrix-instruction engine)."""
+        mode = N.gemm_mode(self.gemm_dtype) & 0xFF
+        return 3 if mode == 2 else (1 if mode == 1 else 0)
+
+    @torch.no_grad()
+    def forward_rows(self, planes, n_rows, rows, n_arm, scale=1.0, out=None):
+        """``forward(data[rows].expand(n_arm, -1, -1), True, scale)`` for a batch that is rows of a resident matrix held as
+        the GEMM engine's slice planes (``_native.tp_planes(data, self.planes_needed())``): the first layer reads the rows in
+        place -- no gathered batch, no per-batch conversion; same results bit for bit.  rows: int64 [B] on the device."""
+        if self.training:
+            raise NotImplementedError("the HIP augmenter implements eval mode only")
+        D, n1, n3, n5, Z, NZ = self._dims
+        A, B = int(n_arm), int(rows.shape[0])
+        dev = rows.device
+        dims = self._aug_dims(A, B)
+        if self._packed is None or self._packed.device != dev:
+            self._pack(dims)
+        if self._explicit is not None:
+            z0, eps = (t.to(dev).float().contiguous() for t in self._explicit)
+            assert z0.shape == (A, B, NZ) and eps.shape == (A, B, Z)
+        else:
+            z0 = torch.randn(A, B, NZ, device=dev)          # udagan.py:283-289
+            eps = torch.randn(A, B, Z, device=dev)          # reparam_trick, aug_utils.py:64
+        need = int(N.lib().mmvae_aug_workspace_bytes(C.byref(dims), 1))
+        if self._ws is None or self._ws.numel() * 4 < need or self._ws.device != dev:
+            self._ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
+        if out is not None:
+            s, out = out
+            assert s.shape == (A, B, Z) and out.shape == (A, B, D) and s.is_contiguous() and out.is_contiguous()
+        else:
+            s = torch.empty(A, B, Z, dtype=torch.float32, device=dev)
+            out = torch.empty(A, B, D, dtype=torch.float32, device=dev)
+        rows = rows.to(torch.int64).contiguous()
+        N.check(N.lib().mmvae_augment_rows(C.byref(dims), N._ptr(self._packed), N._ptr(planes), int(n_rows), self.planes_needed(),
+                                           N._ptr(rows), N._ptr(z0), N._ptr(eps), float(scale), N._ptr(self._ws),
+                                           self._ws.numel() * 4, N._ptr(s), N._ptr(out), N.gemm_mode(self.gemm_dtype),
+                                           C.byref(self._exec()), N._stream(dev)), "mmvae_augment_rows")
+        return s, out
+
+
 def mk_augmenter(pretrained: str, load: bool = True):
     """cpl_mixvae.py:128-149: the checkpoint holds ``parameters`` (num_n, num_z, n_features) and ``netA``.  Loaded with
     ``weights_only=True`` (tensors and plain containers only)."""

@@ -280,7 +280,19 @@ class cpl_mixVAE:
             return
         main = torch.cuda.current_stream(self.device)
         side = N.shared_stream(self.device, "produce")
-        it = iter(loader)
+        # With an augmenter in front of the step and a device-resident loader the batch is not assembled either: the loader keeps
+        # its matrix as the augmenter engine's slice planes (made once) and the augmenter's first layer reads the epoch's rows in
+        # place (Augmenter_smartseq.forward_rows: no row gather, no per-batch conversion; same results bit for bit).
+        # MMVAE_ROWS=0 keeps gathered batches.
+        planes, np_aug = None, 0
+        if (self.netA is not None and hasattr(loader, "iter_rows") and hasattr(loader, "data_planes")
+                and getattr(loader, "data", None) is not None and os.environ.get("MMVAE_ROWS", "1") != "0"
+                and hasattr(self.netA, "planes_needed")):
+            np_aug = self.netA.planes_needed()
+            if np_aug and loader.data.shape[1] == self.netA._dims[0]:
+                planes = loader.data_planes(np_aug)
+        self.used_aug_rows = planes is not None
+        it = loader.iter_rows() if planes is not None else iter(loader)
         aug_out = {}
         done = {}                                               # step index -> main-stream event at its end
         count = [0]
@@ -292,6 +304,16 @@ class cpl_mixVAE:
             b = next(it, None)
             if b is None:
                 return None
+            if planes is not None:
+                key = (k % aug_ring, b.shape[0])
+                if key not in aug_out:
+                    aug_out[key] = (torch.empty(A, b.shape[0], self.netA._dims[4], device=self.device),
+                                    torch.empty(A, b.shape[0], loader.data.shape[1], device=self.device))
+                xs = self.netA.forward_rows(planes, loader.data.shape[0], b, A, 0.1, out=aug_out[key])[1]   # cpl_mixvae.py:422-423
+                count[0] += 1
+                ev = torch.cuda.Event()
+                ev.record(side)
+                return xs, b, ev
             x = first(b).to(self.device, non_blocking=True)
             xs = x.expand(A, -1, -1)
             if self.netA is not None:

@@ -239,6 +239,7 @@ struct AugWs {
     // planes x planes engine (gemm_pp.hip): the activations as tiled slice planes (three planes' room each; the bf16
     // configuration fills one), written by the producing layer's epilogue; scratch of the stream-K grid (flags + partial tiles)
     int64_t tx, t1, t2, t3, t4, t6, t7, t8, t9, t10, scratch, scratch_floats;
+    int64_t rowmap; int rowmap_n;     // uint32 [trunk rows rounded up to 256]: the batch's rows in the resident matrix' planes (mmvae_augment_rows)
 };
 static AugWs aug_ws_layout(const mmvae_aug_dims& d, int trunk_rows) {
     AugWs w{};
@@ -253,6 +254,8 @@ static AugWs aug_ws_layout(const mmvae_aug_dims& d, int trunk_rows) {
     w.t6 = tpl((int)R, d.N5); w.t7 = tpl((int)R, d.N3); w.t8 = tpl((int)R, d.N3); w.t9 = tpl((int)R, d.N1); w.t10 = tpl((int)R, d.N1);
     w.scratch_floats = pp_scratch_floats();
     w.scratch = take(w.scratch_floats);
+    w.rowmap_n = tp_rp((int)T);
+    w.rowmap = take(w.rowmap_n);
     w.total = off;
     return w;
 }
@@ -496,11 +499,14 @@ int mmvae_aug_pack(const mmvae_aug_dims* d, const mmvae_aug_tensors* t, float* p
     return 0;
 }
 
-int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, int64_t x_arm_stride, const float* z0,
-                  const float* eps_n, float scale, void* ws, size_t ws_bytes, float* s_out, float* x_aug,
-                  int gemm_bf16, const mmvae_exec* ex, void* stream) {
+// xp: the resident matrix as tiled slice planes (mmvae_tp_planes) and the batch's rows in it -- the first layer's DMA then
+// reads the rows in place (no gathered batch, no per-batch conversion) --, or null: x is the batch itself
+static int augment_impl(const mmvae_aug_dims* d, const float* packed, const float* x, int64_t x_arm_stride, const TPlanes* xp,
+                        int64_t xp_rows, const int64_t* rows, const float* z0,
+                        const float* eps_n, float scale, void* ws, size_t ws_bytes, float* s_out, float* x_aug,
+                        int gemm_bf16, const mmvae_exec* ex, void* stream) {
     if (int rc = aug_check_dims(d)) return rc;
-    if (!packed || !x || !z0 || !eps_n || !ws || !s_out || !x_aug) { set_error("augment: null argument"); return MMVAE_E_BADARG; }
+    if (!packed || (!x && !xp) || !z0 || !eps_n || !ws || !s_out || !x_aug) { set_error("augment: null argument"); return MMVAE_E_BADARG; }
     const bool shared = x_arm_stride == 0;
     if (!shared && x_arm_stride != (int64_t)d->B * d->D) {
         set_error("augment: x must be [B,D] shared by the arms (stride 0) or contiguous [A,B,D]");
@@ -515,6 +521,7 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     const int ft = gemm_bf16 == 2 ? 98 : gemm_bf16 ? 99 : (ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0);
     int rc;
     const int tune_tile = ex ? ex->tune[MMVAE_TUNE_AUG_TILE] : 0;
+    if (xp && !(gemm_bf16 && tune_tile != 90)) { set_error("augment_rows: needs the planes engine (gemm_bf16 1 or 2)"); return MMVAE_E_UNSUPPORTED; }
     if (gemm_bf16 && tune_tile != 90) {
         // planes x planes engine (gemm_pp.hip): every layer's epilogue writes the next layer's operand as tiled slice planes
         // (three exact slices: fp32x3; one rounded plane: the bf16 configuration).  MMVAE_AUG_TILE=90: the tile engine of
@@ -528,17 +535,24 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
                       H4 = tpa(W.t4, T, d->N3), H6 = tpa(W.t6, R, d->N5), H7 = tpa(W.t7, R, d->N3), H8 = tpa(W.t8, R, d->N3),
                       H9 = tpa(W.t9, R, d->N1), H10 = tpa(W.t10, R, d->N1);
         float* const scr = w + W.scratch;
-        auto layer = [&](int i, const TPlanes& in, int M, bool relu, bool affine, float* out32, int64_t ld32, int nc32, const TPlanes* outp) {
+        unsigned* const rmap = reinterpret_cast<unsigned*>(w + W.rowmap);
+        auto layer = [&](int i, const TPlanes& in, int M, bool relu, bool affine, float* out32, int64_t ld32, int nc32, const TPlanes* outp,
+                         bool mapped = false) {
             // the input's K steps cover its real width rounded up to 16; the weight planes' cover ldw (>= K, zero beyond K)
             TPlanes b = tpw(i);
             TPlanes a = in;
             if (a.KT > b.KT) a.KT = b.KT; else b.KT = a.KT;     // (equal unless the producer's width was padded differently)
             return launch_pp_gemm(s, NP, a, b, M, L.g[i].N, packed + L.g[i].sc, packed + L.g[i].sh, affine, relu, out32, ld32, nc32, outp,
-                                  scr, W.scratch_floats, i, tune_tile);
+                                  scr, W.scratch_floats, i, tune_tile, mapped ? rmap : nullptr, mapped ? W.rowmap_n : 0);
         };
         if ((rc = launch_pp_zero_flags(s, scr))) return rc;
-        if ((rc = launch_tp_from_f32(s, x, d->D, T, d->D, NP, X))) return rc;
-        if ((rc = layer(0, X, T, true, true, nullptr, 0, 0, &H1))) return rc;
+        if (xp) {
+            if ((rc = launch_pp_rowmap(s, rows, T, xp_rows, rmap, W.rowmap_n))) return rc;
+            if ((rc = layer(0, *xp, T, true, true, nullptr, 0, 0, &H1, true))) return rc;
+        } else {
+            if ((rc = launch_tp_from_f32(s, x, d->D, T, d->D, NP, X))) return rc;
+            if ((rc = layer(0, X, T, true, true, nullptr, 0, 0, &H1))) return rc;
+        }
         if ((rc = layer(1, H1, T, true, true, nullptr, 0, 0, &H2))) return rc;
         if ((rc = layer(2, H2, T, true, true, nullptr, 0, 0, &H3))) return rc;
         if ((rc = layer(3, H3, T, true, true, nullptr, 0, 0, &H4))) return rc;
@@ -583,5 +597,40 @@ int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, 
     if ((rc = aug_gemm(s, ft, true, true, w + W.h9, W.ld1, R, packed, L.g[8], w + W.h10, W.ld1))) return rc;
     return aug_gemm(s, ft, true, true, w + W.h10, W.ld1, R, packed, L.g[9], x_aug, d->D);
 }
+
+
+int mmvae_augment(const mmvae_aug_dims* d, const float* packed, const float* x, int64_t x_arm_stride, const float* z0,
+                  const float* eps_n, float scale, void* ws, size_t ws_bytes, float* s_out, float* x_aug,
+                  int gemm_bf16, const mmvae_exec* ex, void* stream) {
+    return augment_impl(d, packed, x, x_arm_stride, nullptr, 0, nullptr, z0, eps_n, scale, ws, ws_bytes, s_out, x_aug, gemm_bf16, ex, stream);
+}
+
+size_t mmvae_tp_planes_bytes(int64_t n_rows, int32_t K, int32_t n_planes) {
+    if (n_rows < 1 || n_rows > ((int64_t)1 << 27) || K < 4 || (K & 3) || (n_planes != 1 && n_planes != 3)) return 0;
+    if (tp_plane_elems((int)n_rows, K) * 2 >= ((int64_t)1 << 32)) return 0;      // (a lane's 32-bit offset spans one plane)
+    return (size_t)n_planes * (size_t)tp_plane_elems((int)n_rows, K) * 2;
+}
+
+int mmvae_tp_planes(const float* src, int64_t ld, int64_t n_rows, int32_t K, int32_t n_planes, uint16_t* dst, void* stream) {
+    if (!src || !dst || ld < K || !mmvae_tp_planes_bytes(n_rows, K, n_planes)) {
+        set_error("tp_planes: needs ld >= K, K a multiple of 4, one or three planes and less than 4 GB per plane");
+        return MMVAE_E_BADARG;
+    }
+    return launch_rp_from_f32(reinterpret_cast<hipStream_t>(stream), src, ld, (int)n_rows, K, n_planes, tp_make(dst, (int)n_rows, K));
+}
+
+int mmvae_augment_rows(const mmvae_aug_dims* d, const float* packed, const uint16_t* x_planes, int64_t n_rows, int32_t n_planes,
+                       const int64_t* rows, const float* z0, const float* eps_n, float scale, void* ws, size_t ws_bytes,
+                       float* s_out, float* x_aug, int gemm_bf16, const mmvae_exec* ex, void* stream) {
+    if (int rc = aug_check_dims(d)) return rc;
+    if (!x_planes || !rows || !mmvae_tp_planes_bytes(n_rows, d->D, n_planes)) { set_error("augment_rows: bad planes argument"); return MMVAE_E_BADARG; }
+    if (n_planes != (gemm_bf16 == 2 ? 3 : 1) || !gemm_bf16) {
+        set_error("augment_rows: the planes must be the engine's (three for gemm_bf16 = 2, one for 1)");
+        return MMVAE_E_UNSUPPORTED;
+    }
+    const TPlanes xp = tp_make(const_cast<unsigned short*>(x_planes), (int)n_rows, d->D);
+    return augment_impl(d, packed, nullptr, 0, &xp, n_rows, rows, z0, eps_n, scale, ws, ws_bytes, s_out, x_aug, gemm_bf16, ex, stream);
+}
+
 
 }  // extern "C"

@@ -38,8 +38,11 @@ typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
 
 struct PPArgs {
     const unsigned short* a; int64_t a_plane; int a_Rp;     // A planes [NP][KT][a_Rp][16]
+    const unsigned* a_map;                                  // or null: logical row m of A is row a_map[m] of ROW-MAJOR planes [NP][a_Rp][KT][16]
+                                                            // (k_rp_from_f32: a row's K steps are contiguous; tiles_m x BM entries)
     const unsigned short* b; int64_t b_plane; int b_Rp;     // B planes [NP][KT][b_Rp][16]
     int M, N, KT;                                           // real rows of A / of B, K steps
+    int KT_a;                                               // row-mapped A: K steps per row of the row-major planes
     int KS;                                                 // split of the K steps: workgroup = tile x KS + part
     const float* scale; const float* shift;                 // per column n (affine), or unused
     int affine, relu;
@@ -116,23 +119,33 @@ __global__ __launch_bounds__(512) void k_pp_gemm(const PPArgs g_in) {
     // (a wave's chunk starts at row wv BM / 8 of the tile: 20 rows for the 160-row tile, so the row's bit 3 is not the lane's bit 4 there)
     const unsigned swz_a = (unsigned)((((lane & 1) ^ (((wv * (BM / 8) + (lane >> 1)) >> 3) & 1)) * 16) + (lane >> 1) * 32);
     const unsigned swz_b = (unsigned)((((lane & 1) ^ (((wv * (BN / 8) + (lane >> 1)) >> 3) & 1)) * 16) + (lane >> 1) * 32);
-    const unsigned voff_a = (unsigned)(wv * A_CHUNK) + swz_a, voff_b = (unsigned)(wv * B_CHUNK) + swz_b;
+    unsigned voff_a = (unsigned)(wv * A_CHUNK) + swz_a;
+    const unsigned voff_b = (unsigned)(wv * B_CHUNK) + swz_b;
+    if (g.a_map) {
+        // row-mapped A (the first layer reads the batch's rows out of the resident matrix' planes): the lane's row of the tile lies
+        // at a_map[...] x 32 bytes of the K step's slab; the LDS side of the DMA stays lane-linear
+        // (row-major planes: the 32-byte pieces a tile takes from scattered rows are a quarter of a 128-byte line each, and the next
+        // three K steps find the rest of the line in L2; out of K-step-major planes every piece cost a line of its own from HBM)
+        const int rl = wv * (BM / 8) + (lane >> 1);
+        const unsigned row = (BM == 256 || lane < BM / 4) ? g.a_map[m0 + rl] : 0u;
+        voff_a = row * (unsigned)(g.KT_a * 32) + (unsigned)(((lane & 1) ^ ((rl >> 3) & 1)) * 16);
+    }
     auto dma = [&](int kt, int st) __attribute__((always_inline)) {
-        const unsigned short* sa = g.a + ((int64_t)kt * g.a_Rp + m0) * 16;
+        const unsigned short* sa = g.a_map ? g.a + (int64_t)kt * 16 : g.a + ((int64_t)kt * g.a_Rp + m0) * 16;
         const unsigned short* sb = g.b + ((int64_t)kt * g.b_Rp + n0) * 16;
         const unsigned la = lds_base + 4u * (unsigned)(st * STAGE) + (unsigned)(wv * A_CHUNK);
         const unsigned lb = lds_base + 4u * (unsigned)(st * STAGE + NP * A_PLANE) + (unsigned)(wv * B_CHUNK);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const unsigned short* src = sa + p * g.a_plane;
-            const unsigned dst = la + 4u * (unsigned)(p * A_PLANE);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(la + 4u * (unsigned)(p * A_PLANE)));   // (wave-uniform: an SGPR for M0)
             if (BM == 256 || lane < BM / 4)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff_a), "s"(src) : "memory");
         }
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const unsigned short* src = sb + p * g.b_plane;
-            const unsigned dst = lb + 4u * (unsigned)(p * B_PLANE);
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lb + 4u * (unsigned)(p * B_PLANE)));
             if (BN == 256 || lane < BN / 4)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff_b), "s"(src) : "memory");
         }
@@ -357,11 +370,53 @@ __global__ __launch_bounds__(256) void k_tp_from_f32(const float* __restrict__ s
     }
 }
 
+// fp32 [R][ld] (columns < K) -> ROW-MAJOR slice planes [NP][Rp][KT][16] (the layout of a row-mapped A operand): a thread owns four
+// consecutive k of a row.  Elements with k >= K and rows >= R are not written (the caller zero-fills once).
+template <int NP>
+__global__ __launch_bounds__(256) void k_rp_from_f32(const float* __restrict__ src, int64_t ld, int R, int K, unsigned short* __restrict__ dst,
+                                                     int64_t plane, int KT) {
+    const int q4 = K >> 2;                                  // K % 4 == 0
+    const int64_t n = (int64_t)R * q4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / q4;
+        const int k = (int)(i - row * q4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + row * ld + k);
+        unsigned w0[3], w1[3];
+        if (NP == 3) { split3(v.x, v.y, w0); split3(v.z, v.w, w1); }
+        else { w0[0] = cvt_pk_bf16(v.x, v.y); w1[0] = cvt_pk_bf16(v.z, v.w); }
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+            *reinterpret_cast<uint2*>(dst + pl * plane + (row * KT * 16 + k)) = make_uint2(w0[pl], w1[pl]);
+    }
+}
+int launch_rp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst) {
+    if ((K & 3) || (ld & 3) || (reinterpret_cast<uintptr_t>(src) & 15)) { set_error("rp_from_f32: K, ld multiples of 4, 16-byte aligned rows"); return MMVAE_E_BADARG; }
+    const unsigned blocks = (unsigned)imin64(cdiv64((int64_t)R * (K >> 2), 256), 16384);
+    if (NP == 3) hipLaunchKernelGGL(k_rp_from_f32<3>, dim3(blocks), dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.KT);
+    else hipLaunchKernelGGL(k_rp_from_f32<1>, dim3(blocks), dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.KT);
+    HIP_LAUNCH_CHECK("k_rp_from_f32");
+    return 0;
+}
+
 int launch_tp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst) {
     const dim3 grid(cdiv(R, 32), cdiv(dst.KT, 8));
     if (NP == 3) hipLaunchKernelGGL(k_tp_from_f32<3>, grid, dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.Rp, dst.KT);
     else hipLaunchKernelGGL(k_tp_from_f32<1>, grid, dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.Rp, dst.KT);
     HIP_LAUNCH_CHECK("k_tp_from_f32");
+    return 0;
+}
+
+// the row map of a row-mapped A operand: out[i] = rows[i] clamped to the matrix, i < n; 0 for the padding entries up to n_pad
+__global__ __launch_bounds__(256) void k_pp_rowmap(const int64_t* __restrict__ rows, int n, int64_t n_rows, unsigned* __restrict__ out, int n_pad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    int64_t r = i < n ? rows[i] : 0;
+    r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
+    out[i] = (unsigned)r;
+}
+int launch_pp_rowmap(hipStream_t s, const int64_t* rows, int n, int64_t n_rows, unsigned* out, int n_pad) {
+    hipLaunchKernelGGL(k_pp_rowmap, dim3(cdiv(n_pad, 256)), dim3(256), 0, s, rows, n, n_rows, out, n_pad);
+    HIP_LAUNCH_CHECK("k_pp_rowmap");
     return 0;
 }
 
@@ -393,11 +448,14 @@ int launch_pp_zero_flags(hipStream_t s, float* scratch) {
 // One layer.  Tile and K split: the (tile, KS) pair with the lowest modelled time (below).  `force` (MMVAE_AUG_TILE): force % 10 =
 // 1 / 2 / 3 / 4 = 256 x 256 / 256 x 128 / 128 x 128 / 160 x 256 (0: by the model), force / 10 = KS (0: by the model).
 int launch_pp_gemm(hipStream_t s, int NP, TPlanes a, TPlanes b, int M, int N, const float* scale, const float* shift, bool affine, bool relu,
-                   float* out32, int64_t ld32, int ncols32, const TPlanes* outp, float* scratch, int64_t scratch_floats, int flag_slot, int force) {
+                   float* out32, int64_t ld32, int ncols32, const TPlanes* outp, float* scratch, int64_t scratch_floats, int flag_slot, int force,
+                   const unsigned* a_map, int a_map_rows) {
     if (a.KT != b.KT) { set_error("pp_gemm: operands disagree on the K steps (%d, %d)", a.KT, b.KT); return MMVAE_E_BADARG; }
     if (flag_slot < 0 || flag_slot >= PP_FLAG_SLOTS) { set_error("pp_gemm: flag slot %d", flag_slot); return MMVAE_E_BADARG; }
     PPArgs g{};
-    g.a = a.p; g.a_plane = a.plane; g.a_Rp = a.Rp;
+    g.a = a.p; g.a_plane = a.plane; g.a_Rp = a.Rp; g.a_map = a_map;
+    g.KT_a = a.KT;
+    if (a_map && (int64_t)a.Rp * a.KT * 32 >= ((int64_t)1 << 32)) { set_error("pp_gemm: a row-mapped operand spans 4 GB per plane at most"); return MMVAE_E_UNSUPPORTED; }
     g.b = b.p; g.b_plane = b.plane; g.b_Rp = b.Rp;
     g.M = M; g.N = N; g.KT = a.KT; g.KS = 1;
     g.scale = scale; g.shift = shift; g.affine = affine ? 1 : 0; g.relu = relu ? 1 : 0;
@@ -419,7 +477,7 @@ int launch_pp_gemm(hipStream_t s, int NP, TPlanes a, TPlanes b, int M, int N, co
     for (int t = 0; t < 4; ++t) {
         if (f_tile && t != f_tile - 1) continue;
         const int bm = cands[t].bm, bn = cands[t].bn;
-        if (b.Rp < cdiv(N, bn) * bn || a.Rp < cdiv(M, bm) * bm) continue;
+        if (b.Rp < cdiv(N, bn) * bn || (a_map ? a_map_rows : a.Rp) < cdiv(M, bm) * bm) continue;
         const int64_t tiles = (int64_t)cdiv(M, bm) * cdiv(N, bn);
         // (a forced split that does not fit the partial slots: the largest that does)
         int f_fit = f_ks;

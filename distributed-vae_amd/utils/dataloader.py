@@ -194,6 +194,17 @@ class DeviceLoader:
             self._data16_version = ver
         return self._data16
 
+    def data_planes(self, n_planes: int):
+        """``self.data`` as the planes x planes GEMM engine's tiled slice planes (``_native.tp_planes``; made on first use, once
+        per data set and plane count) for the augmenter's row-indexed forward, or None where the library does not offer it."""
+        if self.data.device.type != "cuda":
+            return None
+        ver = self.data._version                      # an in-place edit of the matrix makes the planes stale
+        cache = getattr(self, "_planes", None)
+        if cache is None or cache[0] != (ver, n_planes):
+            self._planes = ((ver, n_planes), N.tp_planes(self.data, n_planes))
+        return self._planes[1]
+
     def unread_epoch(self):
         """Hand an epoch back unconsumed: the caller took this epoch's rows (``iter_rows``) but cannot use them and will draw
         the same epoch again through another iterator (the trainer's fallback from row-indexed steps to gathered batches)."""

@@ -344,6 +344,23 @@ int mmvae_augment(const mmvae_aug_dims *d, const float *packed, const float *x, 
                   const float *z0, const float *eps, float scale, void *ws, size_t ws_bytes, float *s_out,
                   float *x_aug, int gemm_bf16, const mmvae_exec *ex, void *stream);
 
+/* The same forward on a batch that is ROWS OF A RESIDENT MATRIX, never assembled (the augmented counterpart of
+ * mmvae_train_step_rows; the reference gathers the batch in its DataLoader, mmidas/utils/dataloader.py:114-132, and hands it to
+ * netA, cpl_mixvae.py:418-423): the matrix is kept as the GEMM engine's tiled bf16 slice planes -- made ONCE per data set by
+ * mmvae_tp_planes (n_planes 3: the three exact slices of the fp32x3 engine, gemm_bf16 = 2; 1: the matrix rounded to bf16,
+ * gemm_bf16 = 1; mmvae_tp_planes_bytes of ZERO-FILLED device memory, 0 for unsupported arguments: K % 4 == 0, a plane --
+ * n_rows rounded up to 256 x K rounded up to 16 x 2 bytes -- below 4 GB) -- and the first
+ * layer's loads take the batch's rows out of it through `rows` (int64 [B] on the device, clamped to the matrix).  The arms
+ * share x (as x.expand).  Same results, bit for bit, as mmvae_augment on the gathered batch.  MMVAE_E_UNSUPPORTED for
+ * gemm_bf16 = 0 (the fp32 matrix-instruction engine has no planes). */
+size_t mmvae_tp_planes_bytes(int64_t n_rows, int32_t K, int32_t n_planes);
+int mmvae_tp_planes(const float *src, int64_t ld, int64_t n_rows, int32_t K, int32_t n_planes, uint16_t *dst,
+                    void *stream);
+int mmvae_augment_rows(const mmvae_aug_dims *d, const float *packed, const uint16_t *x_planes, int64_t n_rows,
+                       int32_t n_planes, const int64_t *rows, const float *z0, const float *eps, float scale,
+                       void *ws, size_t ws_bytes, float *s_out, float *x_aug, int gemm_bf16,
+                       const mmvae_exec *ex, void *stream);
+
 /* ---- device-resident data path ------------------------------------
  * out[i, :] = data[idx[i], :], i < n: the batch assembly of the reference's DataLoader
  * (mmidas/utils/dataloader.py:114-132: shuffled index batches collated from a host TensorDataset, pinned, copied to

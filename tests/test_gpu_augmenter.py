@@ -221,6 +221,70 @@ def test_pipelined_epoch_equals_unpipelined():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_rows_forward_is_bit_identical_to_the_gathered_batch(mode):
+    """Augmenter_smartseq.forward_rows (mmvae_augment_rows): the batch is rows of a resident matrix kept as the GEMM engine's
+    slice planes (made once, mmvae_tp_planes) and the first layer's loads take the rows out of it through a row map -- no
+    gathered batch, no per-batch conversion.  Same bits as forward() on data[rows]; rows repeat and come in any order; a tile
+    shape forced for every layer (row tiles of 160 and of 256) gives the same."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd import _native as N
+    NZ, Z, D, ND, A, B, NR = 50, 10, 1000, 500, 2, 300, 777
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=5)
+    g = torch.Generator().manual_seed(17)
+    data = ((torch.rand(NR, D, generator=g) < 0.3).float() * torch.randn(NR, D, generator=g).abs() * 3).to(DEV)
+    rows = torch.randint(0, NR, (B,), generator=g).to(DEV)
+    rows[5] = rows[4]
+    rows[0], rows[1] = NR - 1, 0
+    z0, eps = torch.randn(A, B, NZ, generator=g), torch.randn(A, B, Z, generator=g)
+    for code in (0, 4, 1):
+        m = _model(NZ, Z, D, ND, sd)
+        m.gemm_dtype = mode
+        m._exec().tune[3] = code
+        m.set_explicit_noise(z0, eps)
+        s1, x1 = m(data[rows].expand(A, -1, -1), True, 0.1)
+        planes = N.tp_planes(data, m.planes_needed())
+        assert planes is not None and m.planes_needed() == (3 if mode == "fp32" else 1)
+        s2, x2 = m.forward_rows(planes, NR, rows, A, 0.1)
+        assert torch.equal(s1, s2) and torch.equal(x1, x2), code
+    m.gemm_dtype = "fp32_mfma"                                   # the fp32 matrix-instruction engine has no planes
+    assert m.planes_needed() == 0
+
+
+def test_pipelined_epoch_reads_rows_of_a_resident_loader(monkeypatch):
+    """With a device-resident loader the augmented epoch does not assemble its batches: the loader keeps the engine's slice
+    planes of its matrix and the augmenter's first layer reads the epoch's rows in place.  Loss vectors and final parameters
+    are bit-identical to the epoch on gathered batches (MMVAE_ROWS=0)."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.augmentation import Augmenter_smartseq
+    from distributed_vae_amd.cpl_mixvae import cpl_mixVAE
+    from distributed_vae_amd.utils import dataloader as DL
+    from oracle import restatement as R
+    A, D, C = 2, 128, 6
+    NZ, Z, ND = 8, 4, 40
+    X = R.synthetic_batch(400, D, seed=3)
+    res = []
+    for rows_on in ("1", "0"):
+        monkeypatch.setenv("MMVAE_ROWS", rows_on)
+        tr, te, al = DL.get_loaders(X.numpy(), seed=546, batch_size=64, device=DEV)
+        torch.manual_seed(123)
+        t = cpl_mixVAE(saving_folder="", device=DEV, save_flag=False)
+        t.init_model(n_categories=C, state_dim=2, input_dim=D, fc_dim=16, lowD_dim=4, x_drop=0.5, s_drop=0.0, n_arm=A)
+        netA = Augmenter_smartseq(NZ, Z, D, ND)
+        netA.load_state_dict(OA.random_state_dict(NZ, Z, D, ND, seed=2))
+        t.set_augmenter(netA)
+        t.model._noise_seed, t.model._noise_offset = 9, 0
+        torch.manual_seed(77)                                   # the augmenter's torch.randn draws
+        bufs = []
+        for _ in range(2):
+            bufs += [b.clone() for b in t.epoch_steps(tr)]
+        torch.cuda.synchronize()
+        assert t.used_aug_rows == (rows_on == "1")
+        res.append((torch.stack(bufs).cpu(), t.model.flat_parameters().clone().cpu()))
+    assert res[0][0].shape[0] >= 8
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_trainer_train_loop_with_augmenter_loaders_consensus_and_validation(tmp_path):
     """The whole mirrored loop of cpl_mixvae.py:397-790 on the device: device-resident loaders, augmenter in front of
     every step (pipelined), per-epoch consensus, the validation block (batch_size-1 test loader = one batch), the

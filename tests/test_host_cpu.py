@@ -183,6 +183,12 @@ def test_widened_entry_points_validate_arguments_on_the_host():
     assert L.mmvae_augment(C.byref(ok), None, None, 0, None, None, 0.1, None, 0, None, None, 0, None, None) == -1
     # data path
     assert L.mmvae_gather_rows(None, 8, 4, None, 2, 8, None, None) == -1
+    # the resident matrix as the augmenter engine's slice planes, and the forward on rows of it
+    assert L.mmvae_tp_planes_bytes(50000, 5000, 3) == 3 * 313 * 50176 * 32 and L.mmvae_tp_planes_bytes(50000, 5000, 1) == 313 * 50176 * 32
+    assert L.mmvae_tp_planes_bytes(50000, 5000, 2) == 0 and L.mmvae_tp_planes_bytes(50000, 5002, 3) == 0       # planes, K % 4
+    assert L.mmvae_tp_planes_bytes(500000, 5000, 3) == 0                                                       # a plane of 4 GB or more
+    assert L.mmvae_tp_planes(None, 5000, 100, 5000, 3, None, None) == -1
+    assert L.mmvae_augment_rows(C.byref(ok), None, None, 100, 3, None, None, None, 0.1, None, 0, None, None, 2, None, None) == -1
     # eval labels: needs eval mode
     d = N.Dims(2, 32, 64, 16, 4, 6, 2)
     h = N.Hyper(0.005, 1.0, 1.0, 1.0, 1e-8, 0.01, 0.5, 0.0, 0, 1, 0)     # training = 1
