@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64 * AL_NW) void k_aug_latent(const float* __restri
                                                           const float* __restrict__ P, int ld5,
                                                           const float* __restrict__ z0, const float* __restrict__ eps_n,
                                                           float zscale, float* __restrict__ s_out,
-                                                          float* __restrict__ H6) {
+                                                          float* __restrict__ H6, TPlanes h6p, int h6_np) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Wn = sm;                      // [NZ][NZ+1]
     float* W5 = Wn + NZ * (NZ + 1);      // [N5][NZ+1]
@@ -379,8 +379,33 @@ __global__ __launch_bounds__(64 * AL_NW) void k_aug_latent(const float* __restri
             if (j0 < N5) g0 += W6[j0 * (Z + 1) + k] * v;
             if (j1 < N5) g1 += W6[j1 * (Z + 1) + k] * v;
         }
-        if (j0 < ld5) H6[row * ld5 + j0] = j0 < N5 ? fmaxf(g0 * s6c0 + s6h0, 0.f) : 0.f;
-        if (j1 < ld5) H6[row * ld5 + j1] = j1 < N5 ? fmaxf(g1 * s6c1 + s6h1, 0.f) : 0.f;
+        const float o0 = j0 < N5 ? fmaxf(g0 * s6c0 + s6h0, 0.f) : 0.f, o1 = j1 < N5 ? fmaxf(g1 * s6c1 + s6h1, 0.f) : 0.f;
+        if (h6_np) {
+            // the planes x planes engine takes h6 as tiled slice planes (gemm_pp.hip): the even lane writes its column and its
+            // right neighbour's as one dword per plane (no fp32 copy, no conversion launch)
+            const float n0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o0), 0xF5, 0xF, 0xF, false));
+            const float n1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, o1), 0xF5, 0xF, 0xF, false));
+            if (!(lane & 1)) {
+                const float v[2] = {o0, o1}, nb[2] = {n0, n1};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int n = lane + 64 * q;
+                    if ((n >> 4) >= h6p.KT) continue;
+                    const int64_t e = ((int64_t)(n >> 4) * h6p.Rp + row) * 16 + (n & 15);
+                    if (h6_np == 3) {
+                        unsigned w[3];
+                        split3(v[q], nb[q], w);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(h6p.p + pl * h6p.plane + e) = w[pl];
+                    } else {
+                        *reinterpret_cast<unsigned*>(h6p.p + e) = cvt_pk_bf16(v[q], nb[q]);
+                    }
+                }
+            }
+        } else {
+            if (j0 < ld5) H6[row * ld5 + j0] = o0;
+            if (j1 < ld5) H6[row * ld5 + j1] = o1;
+        }
     }
 }
 
@@ -545,12 +570,12 @@ static int augment_impl(const mmvae_aug_dims* d, const float* packed, const floa
             return launch_pp_gemm(s, NP, a, b, M, L.g[i].N, packed + L.g[i].sc, packed + L.g[i].sh, affine, relu, out32, ld32, nc32, outp,
                                   scr, W.scratch_floats, i, tune_tile, mapped ? rmap : nullptr, mapped ? W.rowmap_n : 0);
         };
-        if ((rc = launch_pp_zero_flags(s, scr))) return rc;
+        // (the forward's first launch also zeroes the flag words of the K-split combines)
         if (xp) {
-            if ((rc = launch_pp_rowmap(s, rows, T, xp_rows, rmap, W.rowmap_n))) return rc;
+            if ((rc = launch_pp_rowmap(s, rows, T, xp_rows, rmap, W.rowmap_n, scr))) return rc;
             if ((rc = layer(0, *xp, T, true, true, nullptr, 0, 0, &H1, true))) return rc;
         } else {
-            if ((rc = launch_tp_from_f32(s, x, d->D, T, d->D, NP, X))) return rc;
+            if ((rc = launch_tp_from_f32(s, x, d->D, T, d->D, NP, X, scr))) return rc;
             if ((rc = layer(0, X, T, true, true, nullptr, 0, 0, &H1))) return rc;
         }
         if ((rc = layer(1, H1, T, true, true, nullptr, 0, 0, &H2))) return rc;
@@ -565,10 +590,9 @@ static int augment_impl(const mmvae_aug_dims* d, const float* packed, const floa
             // loops, not the 43 KB of weights every workgroup stages, are what the kernel spends its time on)
             const int blocks = (int)imin64(cdiv64(R, AL_NW * 2), 1024);
             hipLaunchKernelGGL(k_aug_latent, dim3(blocks), dim3(64 * AL_NW), shm, s, packed, L, d->A, d->B, d->N5, d->Z, d->NZ,
-                               shared ? 1 : 0, w + W.P, W.ld5, z0, eps_n, scale, s_out, w + W.H6);
+                               shared ? 1 : 0, w + W.P, W.ld5, z0, eps_n, scale, s_out, w + W.H6, H6, NP);
             HIP_LAUNCH_CHECK("k_aug_latent");
         }
-        if ((rc = launch_tp_from_f32(s, w + W.H6, W.ld5, R, d->N5, NP, H6))) return rc;
         if ((rc = layer(5, H6, R, true, true, nullptr, 0, 0, &H7))) return rc;
         if ((rc = layer(6, H7, R, true, true, nullptr, 0, 0, &H8))) return rc;
         if ((rc = layer(7, H8, R, true, true, nullptr, 0, 0, &H9))) return rc;
@@ -588,7 +612,7 @@ static int augment_impl(const mmvae_aug_dims* d, const float* packed, const floa
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_aug_latent), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         const int blocks = (int)imin64(cdiv64(R, AL_NW * 2), 1024);
         hipLaunchKernelGGL(k_aug_latent, dim3(blocks), dim3(64 * AL_NW), shm, s, packed, L, d->A, d->B, d->N5, d->Z, d->NZ,
-                           shared ? 1 : 0, w + W.P, W.ld5, z0, eps_n, scale, s_out, w + W.H6);
+                           shared ? 1 : 0, w + W.P, W.ld5, z0, eps_n, scale, s_out, w + W.H6, TPlanes{}, 0);
         HIP_LAUNCH_CHECK("k_aug_latent");
     }
     if ((rc = aug_gemm(s, ft, true, true, w + W.H6, W.ld5, R, packed, L.g[5], w + W.h7, W.ld3))) return rc;

@@ -880,7 +880,7 @@ inline int tp_rp(int R) { return rup(R, 256); }
 inline int tp_kt(int K) { return cdiv(K, 16); }
 inline int64_t tp_plane_elems(int R, int K) { return (int64_t)tp_kt(K) * tp_rp(R) * 16; }
 inline TPlanes tp_make(unsigned short* p, int R, int K) { return TPlanes{p, tp_plane_elems(R, K), tp_rp(R), tp_kt(K)}; }
-int launch_tp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst);
+int launch_tp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst, float* zero_flags_of_scratch = nullptr);
 int launch_rp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst);   // row-major planes [NP][Rp][KT][16]
 constexpr int PP_MAX_WG = 256;                           // workgroups of a K-split k_pp_gemm launch at most (partial slots)
 constexpr int PP_MAX_KS = 8;
@@ -891,7 +891,7 @@ int launch_pp_zero_flags(hipStream_t s, float* scratch);
 int launch_pp_gemm(hipStream_t s, int NP, TPlanes a, TPlanes b, int M, int N, const float* scale, const float* shift, bool affine, bool relu,
                    float* out32, int64_t ld32, int ncols32, const TPlanes* outp, float* scratch, int64_t scratch_floats, int flag_slot, int force = 0,
                    const unsigned* a_map = nullptr, int a_map_rows = 0);
-int launch_pp_rowmap(hipStream_t s, const int64_t* rows, int n, int64_t n_rows, unsigned* out, int n_pad);
+int launch_pp_rowmap(hipStream_t s, const int64_t* rows, int n, int64_t n_rows, unsigned* out, int n_pad, float* zero_flags_of_scratch = nullptr);
 // evaluation labels / consensus (consensus.hip)
 int launch_classify(const float* cc, int64_t n_cells, int C, int32_t* labels, hipStream_t s);
 int launch_confmat(const int32_t* labels, int A, int64_t n, int C, int64_t* counts, hipStream_t s);

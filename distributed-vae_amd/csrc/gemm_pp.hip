@@ -331,7 +331,10 @@ __global__ __launch_bounds__(512) void k_pp_gemm(const PPArgs g_in) {
 // one K step and plane) in 16-byte pieces.  grid (ceil(R / 32), ceil(KT / 8)).
 template <int NP>
 __global__ __launch_bounds__(256) void k_tp_from_f32(const float* __restrict__ src, int64_t ld, int R, int K, unsigned short* __restrict__ dst,
-                                                     int64_t plane, int Rp, int KT) {
+                                                     int64_t plane, int Rp, int KT, unsigned* __restrict__ zero_words, int n_zero) {
+    // (the first launch of an augmenter forward also zeroes the flag words of the forward's K-split combines)
+    if (zero_words && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;
     constexpr int KSTR = 32 * 8 + 8;                       // dwords per (plane, K step) of the tile: 32 rows x 8 dwords (+ pad)
     __shared__ __attribute__((aligned(16))) unsigned tile[NP * 8 * KSTR];
     const int t = threadIdx.x, row0 = blockIdx.x * 32, kt0 = blockIdx.y * 8;
@@ -398,24 +401,29 @@ int launch_rp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K
     return 0;
 }
 
-int launch_tp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst) {
+int launch_tp_from_f32(hipStream_t s, const float* src, int64_t ld, int R, int K, int NP, TPlanes dst, float* zero_flags_of_scratch) {
     const dim3 grid(cdiv(R, 32), cdiv(dst.KT, 8));
-    if (NP == 3) hipLaunchKernelGGL(k_tp_from_f32<3>, grid, dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.Rp, dst.KT);
-    else hipLaunchKernelGGL(k_tp_from_f32<1>, grid, dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.Rp, dst.KT);
+    unsigned* const zw = reinterpret_cast<unsigned*>(zero_flags_of_scratch);
+    if (NP == 3) hipLaunchKernelGGL(k_tp_from_f32<3>, grid, dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.Rp, dst.KT, zw, PP_FLAG_WORDS);
+    else hipLaunchKernelGGL(k_tp_from_f32<1>, grid, dim3(256), 0, s, src, ld, R, K, dst.p, dst.plane, dst.Rp, dst.KT, zw, PP_FLAG_WORDS);
     HIP_LAUNCH_CHECK("k_tp_from_f32");
     return 0;
 }
 
 // the row map of a row-mapped A operand: out[i] = rows[i] clamped to the matrix, i < n; 0 for the padding entries up to n_pad
-__global__ __launch_bounds__(256) void k_pp_rowmap(const int64_t* __restrict__ rows, int n, int64_t n_rows, unsigned* __restrict__ out, int n_pad) {
+__global__ __launch_bounds__(256) void k_pp_rowmap(const int64_t* __restrict__ rows, int n, int64_t n_rows, unsigned* __restrict__ out, int n_pad,
+                                                   unsigned* __restrict__ zero_words, int n_zero) {
+    if (zero_words && blockIdx.x == 0)
+        for (int j = threadIdx.x; j < n_zero; j += 256) zero_words[j] = 0u;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
     int64_t r = i < n ? rows[i] : 0;
     r = r < 0 ? 0 : (r >= n_rows ? n_rows - 1 : r);
     out[i] = (unsigned)r;
 }
-int launch_pp_rowmap(hipStream_t s, const int64_t* rows, int n, int64_t n_rows, unsigned* out, int n_pad) {
-    hipLaunchKernelGGL(k_pp_rowmap, dim3(cdiv(n_pad, 256)), dim3(256), 0, s, rows, n, n_rows, out, n_pad);
+int launch_pp_rowmap(hipStream_t s, const int64_t* rows, int n, int64_t n_rows, unsigned* out, int n_pad, float* zero_flags_of_scratch) {
+    hipLaunchKernelGGL(k_pp_rowmap, dim3(cdiv(n_pad, 256)), dim3(256), 0, s, rows, n, n_rows, out, n_pad,
+                       reinterpret_cast<unsigned*>(zero_flags_of_scratch), PP_FLAG_WORDS);
     HIP_LAUNCH_CHECK("k_pp_rowmap");
     return 0;
 }
@@ -438,7 +446,8 @@ static int pp_launch(hipStream_t s, PPArgs& g) {
 }
 
 // the scratch of launch_pp_gemm: PP_FLAG_WORDS flag words (PP_FLAG_SLOTS launches' worth: a caller zeroes them ONCE, with
-// launch_pp_zero_flags, in front of up to PP_FLAG_SLOTS launches that each name their own slot), then the partial slots
+// launch_pp_zero_flags -- or by the zero_flags_of_scratch argument of launch_tp_from_f32 / launch_pp_rowmap, whose kernels then do it on
+// the side --, in front of up to PP_FLAG_SLOTS launches that each name their own slot), then the partial slots
 int64_t pp_scratch_floats() { return PP_FLAG_WORDS + (int64_t)PP_MAX_WG * 256 * 256; }
 int launch_pp_zero_flags(hipStream_t s, float* scratch) {
     if (hipMemsetAsync(scratch, 0, PP_FLAG_WORDS * sizeof(unsigned), s) != hipSuccess) { set_error("pp_gemm: flag memset failed"); return MMVAE_E_LAUNCH; }
