@@ -131,6 +131,39 @@ def test_k_split_combined_in_the_launch(code):
     assert _rel(outs[1], outs[0]) < 5e-6
 
 
+def test_production_shape_forward_is_bit_reproducible_beside_other_work():
+    """The K-split combine inside the GEMM launches adds a tile's partial accumulators in a fixed order whatever the order
+    its workgroups arrive in: sixty forwards at the benchmark shape -- half of them while another stream keeps the chip busy
+    with train steps, so that workgroups of a tile are dispatched far apart -- give the same bits, and none is poisoned
+    (a partial that never arrived would be NaN)."""
+    import distributed_vae_amd  # noqa: F401
+    from distributed_vae_amd.nn_model import mixVAE_model
+    from distributed_vae_amd.cpl_mixvae import FusedAdam
+    NZ, Z, D, ND, A, B = 50, 10, 5000, 500, 2, 5000
+    sd = OA.random_state_dict(NZ, Z, D, ND, seed=D)
+    m = _model(NZ, Z, D, ND, sd)
+    g = torch.Generator().manual_seed(3)
+    x = ((torch.rand(B, D, generator=g) < 0.2).float() * torch.randn(B, D, generator=g).abs() * 3).to(DEV)
+    z0, eps = torch.randn(A, B, NZ, generator=g), torch.randn(A, B, Z, generator=g)
+    m.set_explicit_noise(z0, eps)
+    ref = m(x.expand(A, -1, -1), True, 0.1)[1].clone()
+    assert bool(torch.isfinite(ref).all())
+    vae = mixVAE_model(input_dim=D, fc_dim=100, n_categories=92, state_dim=2, lowD_dim=10, x_drop=0.5, s_drop=0.0, n_arm=A,
+                       lam=1, lam_pc=1, tau=0.005, beta=1.0, hard=False, variational=True, device=DEV, eps=1e-8, momentum=0.01,
+                       ref_prior=False, loss_mode="MSE").to(DEV)
+    opt = FusedAdam(vae, lr=1e-3)
+    side = torch.cuda.Stream(device=DEV)
+    for rep in range(60):
+        if rep >= 30:
+            vae.fused_train_step(x.expand(A, -1, -1), 1.0, opt)         # on the current stream, beside the forward below
+            with torch.cuda.stream(side):
+                out = m(x.expand(A, -1, -1), True, 0.1)[1]
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            out = m(x.expand(A, -1, -1), True, 0.1)[1]
+        assert torch.equal(out, ref), rep
+
+
 def test_device_noise_statistics_and_determinism():
     """Without the explicit hook the module draws torch.randn on the device like the reference: same seed, same
     output; different arms differ; s has the spread the noise implies."""
