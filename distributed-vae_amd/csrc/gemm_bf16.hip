@@ -1136,6 +1136,9 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
 // S16 (bf16 storage): x is read from its bf16 copy (g.fo.x addresses 2-byte elements; the loss and dZ11 then see the rounded
 // x) and dZ11 is WRITTEN as bf16 (g.fo.dz likewise) -- exactly the values the d(d10) product here and the dW11 GEMM take
 // anyway, so only the loss's view of x changes; the kernel moves 2 x 2 + 2 bytes per cell and gene instead of 2 x 4 + 4.
+#ifndef BF16FC_ABL
+#define BF16FC_ABL 0     // timing ablations of k_bf16_fc11g (diagnostic builds only; results wrong): 1 no W11 reloads, 2 no x loads, 4 no dZ11 stores
+#endif
 template <bool S16>
 __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
     const GemmArgs g = g_in;
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
         tile_store<false, false>(Ws[1], w1, ow, j0, KT, K);
         if (tid < BT) bias_s[tid] = bnext;
         __syncthreads();
-        if (t + 1 < t1) {
+        if (!(BF16FC_ABL & 1) && t + 1 < t1) {
             tile_load<false, false>(w0, ow, j0 + BT, 0, K);
             tile_load<false, false>(w1, ow, j0 + BT, KT, K);
             if (tid < BT) bnext = bias[min(j0 + BT + tid, D - 1)];
@@ -1209,7 +1212,8 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
 #pragma unroll
                     for (int qp = 0; qp < 2; ++qp) {
                         const int gene = j0 + 32 * (2 * half + gl) + 8 * (2 * qp + hh);                   // D % 8 == 0
-                        xraw[gl][qp] = *reinterpret_cast<const u32x4v*>(reinterpret_cast<const unsigned short*>(xa) + rowoff + min(gene, D - 8));
+                        if (BF16FC_ABL & 2) xraw[gl][qp] = u32x4v{0x3c003c00u, 0x3c003c00u, 0u, 0u};
+                        else xraw[gl][qp] = *reinterpret_cast<const u32x4v*>(reinterpret_cast<const unsigned short*>(xa) + rowoff + min(gene, D - 8));
                     }
                 } else {
 #pragma unroll
@@ -1280,7 +1284,8 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
                         u32x4v w;
                         w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
                         const int gene = j0 + 32 * gi + 8 * (2 * qp + hh);
-                        if (cell < B && gene < D) *reinterpret_cast<u32x4v*>(reinterpret_cast<unsigned short*>(dza) + (int64_t)cell * D + gene) = w;
+                        if (!(BF16FC_ABL & 4) && cell < B && gene < D) *reinterpret_cast<u32x4v*>(reinterpret_cast<unsigned short*>(dza) + (int64_t)cell * D + gene) = w;
+                        if (BF16FC_ABL & 4) asm volatile("" :: "v"(w));
                     }
                 }
                 // d(d10) += dZ11 piece (registers) x W11 rows 32 gi .. + 31 (LDS): two K steps of sixteen genes
