@@ -1139,7 +1139,11 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11(const GemmArgs g_in) {
 #ifndef BF16FC_ABL
 #define BF16FC_ABL 0     // timing ablations of k_bf16_fc11g (diagnostic builds only; results wrong): 1 no W11 reloads, 2 no x loads, 4 no dZ11 stores
 #endif
-template <bool S16>
+// W16: W11 is read from slice 0 of its planes ([D -> rup 128][128] bf16, launch_x3_planes) in sixteen-byte pieces of eight elements
+// that go to the LDS image as they are, instead of fp32 rounded by every block (half the bytes from L2, no conversion; the
+// timing ablation prices the fp32 tiles at 13 of the kernel's 84 us: profiles/r04_bf16_fc11g_ablation.txt; 84 -> 75 us.  Requesting
+// x one half tile ahead in the registers this frees was measured too: 75.1 against 74.5 us, not kept)
+template <bool S16, bool W16 = false>
 __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
     const GemmArgs g = g_in;
     __shared__ __attribute__((aligned(16))) unsigned Ws[2][BT * LDB];   // W11 tile: [gene][k = h], two K tiles
@@ -1169,10 +1173,35 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
         tile_store<false, false>(Ds[1], t1r, od, c0, KT, K);
     }
     TileRegsT<false> w0, w1;
+    OctRegs wo0, wo1;
+    const unsigned no_map[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto w_request = [&](int j) __attribute__((always_inline)) {
+        if constexpr (W16) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                oct_load<false, false>(wo0, ow, j, 0, 2 * KT, p, no_map);
+                oct_load<false, false>(wo1, ow, j, KT, 2 * KT, p, no_map);
+            }
+        } else {
+            tile_load<false, false>(w0, ow, j, 0, K);
+            tile_load<false, false>(w1, ow, j, KT, K);
+        }
+    };
+    auto w_store = [&](int j) __attribute__((always_inline)) {
+        if constexpr (W16) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                oct_store<false>(Ws[0], wo0, ow, j, 0, 2 * KT, p);
+                oct_store<false>(Ws[1], wo1, ow, j, KT, 2 * KT, p);
+            }
+        } else {
+            tile_store<false, false>(Ws[0], w0, ow, j, 0, K);
+            tile_store<false, false>(Ws[1], w1, ow, j, KT, K);
+        }
+    };
     float bnext = 0.f;
     if (t0 < t1) {
-        tile_load<false, false>(w0, ow, t0 * BT, 0, K);
-        tile_load<false, false>(w1, ow, t0 * BT, KT, K);
+        w_request(t0 * BT);
         if (tid < BT) bnext = bias[min(t0 * BT + tid, D - 1)];
     }
     f32x16 gd[4] = {zero16(), zero16(), zero16(), zero16()};   // d(d10)[cell = 32 wv + row][h = 32 nt + (lane & 31)]
@@ -1187,13 +1216,11 @@ __global__ __launch_bounds__(256, 2) void k_bf16_fc11g(const GemmArgs g_in) {
     const int tr_off = ((lane & 15) >> 2) * (2 * LDB) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     for (int t = t0; t < t1; ++t) {
         const int j0 = t * BT;
-        tile_store<false, false>(Ws[0], w0, ow, j0, 0, K);
-        tile_store<false, false>(Ws[1], w1, ow, j0, KT, K);
+        w_store(j0);
         if (tid < BT) bias_s[tid] = bnext;
         __syncthreads();
         if (!(BF16FC_ABL & 1) && t + 1 < t1) {
-            tile_load<false, false>(w0, ow, j0 + BT, 0, K);
-            tile_load<false, false>(w1, ow, j0 + BT, KT, K);
+            w_request(j0 + BT);
             if (tid < BT) bnext = bias[min(j0 + BT + tid, D - 1)];
         }
 #pragma unroll
@@ -1892,6 +1919,8 @@ int launch_x3_planes(const Ctx& c, const float* params, int which, const mmvae_n
         // bf16 configuration on bf16 storage: slice 0 of W1's planes IS bf16(W1) -- fc1 reads its narrow operand from it in
         // sixteen-byte pieces of eight elements, like x, instead of fp32 rounded by every block tile (half the bytes)
         jobs[n++] = plane_job(c, PL_W1, params + c.po.o[0], d.D, c.po.per_arm);
+        // ... and slice 0 of [W11 | b11]'s planes is bf16(W11) for the fused fc11 kernel (the bias column meets a zero of d10)
+        jobs[n++] = plane_job(c, PL_W11, params + c.po.o[26], d.H, c.po.per_arm, params + c.po.o[27], c.po.per_arm);
     }
     if (which & 9) {   // bit 3: the small layers alone (a backward pass that is its own call)
         if (chain_x3_ok(c) && !c.small_planes) {   // the small layers' weights for the chain kernels: slot s = [N][K] of fc2..fc5, fc6..fc10
@@ -2010,7 +2039,14 @@ int launch_fc11_bf16(const Ctx& c, const float* params, const float* x, int64_t 
                 g.fo.x = reinterpret_cast<const float*>(c.x16);
                 g.fo_arm = (int64_t)d.B * d.D / 2;          // (arm stride of dZ11 in floats: B * D two-byte elements)
                 c.dz16 = true;
-                launch_k(c, k_bf16_fc11g<true>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, g);
+                if (bf16_narrow_planes(c) && KT == 64) {   // W11 from slice 0 of its planes (launch_x3_planes): [rup(D, 128)][128] bf16
+                    const PlaneGeom pg = plane_geom(c, PL_W11);
+                    g.b = kmajor(reinterpret_cast<const float*>(c.ws + pg.ws_off), pg.Cp, pg.Rp, pg.Cp);
+                    g.b.src16 = 1;
+                    g.b_arm = 3 * (int64_t)pg.Rp * pg.Cp / 2;       // arm stride in FLOATS of the pointer arithmetic (planes: 2-byte elements)
+                    launch_k(c, k_bf16_fc11g<true, true>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, g);
+                } else
+                    launch_k(c, k_bf16_fc11g<true>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, g);
             } else
                 launch_k(c, k_bf16_fc11g<false>, dim3(cdiv(d.B, BT), NS, d.A), dim3(256), 0, g);
             HIP_LAUNCH_CHECK("k_bf16_fc11g");
