@@ -1,5 +1,8 @@
 #!/bin/bash
-# ablations of k_bf16_fc11g (builds with -DBF16FC_ABL=<mask> as distributed-vae_amd/ab/libmmvae_abl<mask>.so): kernel averages of the bf16 step
+# ablations of k_bf16_fc11g: kernel averages of the bf16 step for diagnostic builds distributed-vae_amd/ab/libmmvae_abl<mask>.so, made in
+# the build container first (they travel with the snapshot):
+#   for m in 1 2 4 7; do hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-gpu-rdc -fno-slp-vectorize -DBF16FC_ABL=$m -c csrc/gemm_bf16.hip -o /tmp/gb_$m.o;
+#     hipcc --offload-arch=gfx950 -shared -fPIC -o ab/libmmvae_abl$m.so $(ls csrc/_obj/*.o | grep -v gemm_bf16.o) /tmp/gb_$m.o -ldl; done
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for m in 0 1 2 4 7; do
